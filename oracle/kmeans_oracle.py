@@ -1,0 +1,224 @@
+"""CPU oracle for the K-Means part of the SCD hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under scd_amd/ may import this module; it is
+the checker for tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+
+It restates, in numpy, the algorithm of
+  * /root/reference/local_utils/sskm_constrained.py            (ConSSKM, K_Means :15-187)
+  * /root/reference/gcd/methods/clustering/faster_mix_k_means_pytorch.py (SSKM, :47-275)
+with ONE deliberate sharpening that the HIP path shares: every *decision*
+(argmin of the E-step, the k-means++ draw, best-of-restarts) is taken on values
+computed in float64 from the given float inputs and then rounded once to
+float32, with ties broken towards the lowest index.  The reference takes the
+same decisions on float32 values whose summation order is whatever the torch
+build uses (sskm_constrained.py:212-213), so the two agree except on rows whose
+top-2 margin is inside float32 round-off; the golden fixtures
+(tests/golden/kmeans_*.npz, produced by oracle/gen_golden.py from the reference
+itself) pin that agreement on clustered data.
+
+Parity status: pinned against reference outputs generated in the build
+container (labels, centres, inertia, k-means++ picks).  The OR-Tools solver the
+constrained E-step calls is a third-party dependency absent from
+/root/reference (ortools==9.3.10497, requirements.txt:103): for that sub-step
+only the optimal total cost and feasibility are pinned (see transport_oracle).
+"""
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+def check_random_state(seed):
+    """sklearn.utils.check_random_state semantics used at sskm_constrained.py:29,142,166."""
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, (int, np.integer)):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError("bad seed %r" % (seed,))
+
+
+def pairwise_distance64(a, b, block=2048):
+    """Squared Euclidean distances, difference form, float64.
+
+    Follows pairwise_distance (sskm_constrained.py:189-224): ((A[:,None]-B[None])**2).sum(-1).
+    """
+    a = np.asarray(a, dtype=F64)
+    b = np.asarray(b, dtype=F64)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=F64)
+    for s in range(0, a.shape[0], block):
+        blk = a[s:s + block]
+        # (x-c)^2 summed; keep the difference form (no ||x||^2 - 2xc + ||c||^2 cancellation)
+        d = blk[:, None, :] - b[None, :, :]
+        out[s:s + block] = np.einsum("nkd,nkd->nk", d, d)
+    return out
+
+
+def pairwise_distance(a, b, batch_size=None):
+    """float32 result of the reference call (sskm_constrained.py:189)."""
+    return pairwise_distance64(a, b).astype(F32)
+
+
+def estep(x, centers):
+    """argmin_k ||x-c_k||^2 (ties -> lowest k) and float32 min distance.
+
+    Reference: torch.min(dist, dim=1) at faster_mix_k_means_pytorch.py:140,192.
+    NaN centres (empty clusters, :203) never win: NaN distances are treated as +inf,
+    which is what torch.min does not guarantee - documented divergence, the
+    reference propagates NaN.
+    """
+    d = pairwise_distance64(x, centers)
+    d = np.where(np.isnan(d), np.inf, d)
+    lab = np.argmin(d, axis=1)
+    mind = d[np.arange(d.shape[0]), lab]
+    return lab.astype(np.int64), mind.astype(F32), d
+
+
+def mstep(x, labels, k):
+    """centres[idx] = mean of members (sskm_constrained.py:125-128); empty -> NaN."""
+    x64 = np.asarray(x, dtype=F64)
+    d = x64.shape[1]
+    sums = np.zeros((k, d), dtype=F64)
+    np.add.at(sums, labels, x64)
+    cnt = np.bincount(labels, minlength=k).astype(F64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        c = sums / cnt[:, None]
+    return c.astype(F32), cnt.astype(np.int64)
+
+
+def kpp_draw(d2_f32, r):
+    """One k-means++ draw (sskm_constrained.py:38-42).
+
+    prob = d2/d2.sum() in float32; torch's CPU cumsum accumulates in double and
+    rounds each prefix to float32; `cum_prob >= r` compares in float32.
+    Returns the first index, or -1 when no prefix reaches r (the reference then
+    raises IndexError at :42).
+    """
+    d2 = np.asarray(d2_f32, dtype=F32)
+    tot = F32(np.sum(d2.astype(F64)))
+    prob = (d2 / tot).astype(F32)
+    cum = np.cumsum(prob.astype(F64)).astype(F32)
+    hit = np.nonzero(cum >= F32(r))[0]
+    return int(hit[0]) if hit.size else -1
+
+
+def kpp(x, pre_centers, k, random_state, trace=None):
+    """K_Means.kpp (sskm_constrained.py:28-44 / faster_mix...:82-110)."""
+    rs = check_random_state(random_state)
+    x = np.asarray(x, dtype=F32)
+    if pre_centers is not None:
+        c = np.asarray(pre_centers, dtype=F32).reshape(-1, x.shape[1])
+    else:
+        c = x[rs.randint(0, len(x))].reshape(1, -1)
+    d2 = pairwise_distance64(x, c).min(axis=1)
+    while c.shape[0] < k:
+        r = rs.rand()
+        ind = kpp_draw(d2.astype(F32), r)
+        if ind < 0:
+            raise IndexError("k-means++ draw fell off the end of cum_prob")
+        if trace is not None:
+            trace.append(ind)
+        c = np.concatenate([c, x[ind:ind + 1]], axis=0)
+        d2 = np.minimum(d2, pairwise_distance64(x, x[ind:ind + 1])[:, 0])
+    return c
+
+
+def _center_shift_sq(c_new, c_old):
+    """(sum_k ||c_k - c_k_old||_2)^2  (sskm_constrained.py:135-136)."""
+    d = np.asarray(c_new, dtype=F64) - np.asarray(c_old, dtype=F64)
+    return float(np.sum(np.sqrt(np.sum(d * d, axis=1))) ** 2)
+
+
+class K_Means:
+    """SSKM oracle: faster_mix_k_means_pytorch.K_Means (:47-275).
+
+    `assign` is the E-step hook: the constrained variant swaps it for the
+    min-cost-flow assignment (sskm_constrained.py:116).
+    """
+
+    def __init__(self, k=3, tolerance=1e-4, max_iterations=100, init="k-means++", n_init=10,
+                 random_state=None, n_jobs=None, pairwise_batch_size=None, mode=None):
+        self.k = k
+        self.tolerance = tolerance
+        self.max_iterations = max_iterations
+        self.init = init
+        self.n_init = n_init
+        self.random_state = random_state
+        self.n_jobs = n_jobs
+        self.pairwise_batch_size = pairwise_batch_size
+        self.mode = mode
+        self.trace = []
+
+    # E-step on the unlabelled rows -> (labels int64, float32 inertia contribution)
+    def assign(self, x, centers):
+        lab, mind, _ = estep(x, centers)
+        return lab, F32(np.sum(mind.astype(F64)))
+
+    def fit_once(self, x, random_state):
+        x = np.asarray(x, dtype=F32)
+        if self.init == "k-means++":
+            centers = kpp(x, None, self.k, random_state, self.trace)
+        elif self.init == "random":
+            rs = check_random_state(self.random_state)
+            centers = x[rs.choice(len(x), self.k, replace=False)].copy()
+        else:
+            centers = x[: self.k].copy()
+        best = (None, None, None)
+        it = 0
+        for it in range(self.max_iterations):
+            old = centers.copy()
+            labels, inertia = self.assign(x, centers)
+            centers, _ = mstep(x, labels, self.k)
+            if best[1] is None or inertia < best[1]:
+                best = (labels.copy(), inertia, centers.copy())
+            if _center_shift_sq(centers, old) < self.tolerance:
+                break
+        return best[0], best[1], best[2], it + 1
+
+    def fit_mix_once(self, u, l, l_targets, random_state):
+        u = np.asarray(u, dtype=F32)
+        l = np.asarray(l, dtype=F32)
+        l_targets = np.asarray(l_targets)
+        classes = np.unique(l_targets)                       # torch.unique sorts (:165)
+        l_centers = np.stack([l[l_targets == c].astype(F64).mean(0) for c in classes]).astype(F32)
+        cat = np.concatenate([l, u])
+        l_num = len(l_targets)
+        labels = -np.ones(len(cat), dtype=np.int64)
+        lut = {c: i for i, c in enumerate(classes.tolist())}
+        labels[:l_num] = [lut[t] for t in l_targets.tolist()]
+        centers = kpp(u, l_centers, self.k, random_state, self.trace)
+        best = (None, None, None)
+        for it in range(self.max_iterations):
+            old = centers.copy()
+            u_lab, u_inertia = self.assign(u, centers)
+            ld = l.astype(F64) - centers[labels[:l_num]].astype(F64)
+            l_inertia = F32(np.sum(ld * ld))
+            inertia = F32(F32(u_inertia) + l_inertia)
+            labels[l_num:] = u_lab
+            centers, _ = mstep(cat, labels, self.k)
+            if best[1] is None or inertia < best[1]:
+                best = (labels.copy(), inertia, centers.copy())
+            if _center_shift_sq(centers, old) < self.tolerance:
+                break
+        # reference returns `i + 1` with i the stale labelled-sample loop index
+        # (faster_mix...:181,216 / sskm_constrained.py:104,139) => n_iter == l_num
+        return best[0], best[1], best[2], l_num
+
+    def _run(self, once, *args):
+        rs = check_random_state(self.random_state)
+        best_inertia = None
+        for _ in range(self.n_init):
+            labels, inertia, centers, n_iters = once(*args, rs)
+            if best_inertia is None or inertia < best_inertia:
+                self.labels_ = labels.copy()
+                self.cluster_centers_ = centers.copy()
+                best_inertia = inertia
+                self.inertia_ = inertia
+                self.n_iter_ = n_iters
+
+    def fit(self, x):
+        self._run(self.fit_once, x)
+
+    def fit_mix(self, u, l, l_targets):
+        self._run(self.fit_mix_once, u, l, l_targets)
