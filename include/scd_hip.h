@@ -1,0 +1,148 @@
+/* scd_hip.h - C ABI of libscd_hip.so: the MI355X (gfx950) hot path of Visual-AI/SCD.
+ *
+ * The reference has no C ABI: its hot path is Python calling torch/sklearn/OR-Tools
+ * (SURVEY.md section 8b).  Each entry point below replaces the reference code cited
+ * next to it (paths relative to /root/reference); INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative scd_status; scd_last_error()
+ *    returns a thread-local message for the last failure;
+ *  - device pointers are raw (tensor.data_ptr()); the library never allocates or frees
+ *    caller-visible memory: scratch comes from the `ws` argument whose size the matching
+ *    *_ws_bytes() query returns (16-byte aligned);
+ *  - all device work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *    asynchronous; no call synchronises the device unless stated;
+ *  - one handle per device / rank; handles are not shared between host threads.
+ */
+#ifndef SCD_HIP_H
+#define SCD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scd_ctx* scd_handle;
+typedef struct scd_encoder scd_encoder;
+
+enum scd_status { SCD_OK = 0, SCD_EINVAL = -1, SCD_EHIP = -2, SCD_ERCCL = -3, SCD_EINFEASIBLE = -4 };
+enum scd_dtype { SCD_F32 = 0, SCD_F16 = 1 };
+enum scd_sim_mode { SCD_SIM_RAW = 0, SCD_SIM_SOFTMAX = 1 };
+
+int scd_version(void);
+const char* scd_last_error(void);
+int scd_create(int device, scd_handle* out);
+int scd_destroy(scd_handle h);
+
+/* ---- L2 normalisation: F.normalize(feats, dim=-1) main_unsup.py:130; clip_lang_util.py:103-105 ---- */
+int scd_l2norm_rows(scd_handle h, const void* x, int dtype, int64_t n, int d, void* out, void* stream);
+
+/* ---- similarity + top-k: main_unsup.py:504-531, main_ptsup.py:526-545 (a5); argmax re-classification
+ *      main_unsup.py:601-614, main_ptsup.py:668-676, get_clip_preds_fast main_ptsup.py:78-99 (a6).
+ * F  [n,d] fp16 row-major (image features);  Wt [v,d] fp16 row-major = zeroshot_weights.T (name-major).
+ * logits = scale * F @ Wt^T; order = (value desc, index asc) on the exact (float64) dot products.
+ * idx_out int64 [n,k]; val_out float32 [n,k] (softmax probability when mode == SCD_SIM_SOFTMAX). k <= 8.
+ * fallback_rows_out (device int32, may be NULL) counts rows that took the exact full-row path. */
+size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k);
+int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
+                 int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws, size_t ws_bytes,
+                 void* stream);
+/* W [r,c] fp16 -> Wt [c,r]  (zeroshot_weights [512,V] -> name-major) */
+int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_t c, void* out, void* stream);
+/* out[i,:] = Wt[idx[i],:]  (the `zeroshot_weights[:, nouns.index(n)]` gather, main_unsup.py:601-602) */
+int scd_gather_rows_f16(scd_handle h, const void* Wt, const int64_t* idx, int64_t m, int d, void* out, void* stream);
+
+/* zeroshot_classifier pooling (local_utils/clip_lang_util.py:103-107): emb fp16 [n_names*t_per, d] prompt embeddings ->
+ * per name normalise, mean, normalise; written as columns col0.. of out fp16 [d, ld_out] (torch.stack(dim=1) layout). */
+int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t_per, int d, int64_t col0, int64_t ld_out, void* out,
+                    void* stream);
+
+/* ---- K-Means: local_utils/sskm_constrained.py, gcd/methods/clustering/faster_mix_k_means_pytorch.py ---- */
+/* one-off per data set: centred, power-of-two scaled fp16 copy of X and its row norms (E-step operand) */
+size_t scd_kmeans_prep_bytes(int64_t n, int d);
+int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* prep, void* stream);
+/* E-step: labels[i] = argmin_k ||x_i - c_k||^2, ties -> lowest k, decided on float64 values
+ * (torch.min(dist,1) faster_mix_k_means_pytorch.py:140,192).  refine_rows_out (device int32, may be NULL)
+ * receives the number of rows re-evaluated exactly. */
+size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k);
+int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
+                     int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream);
+/* d2_out[i] = ||x_i - c_{labels[i]}||^2 (float64 sum rounded to float32) */
+int scd_kmeans_rowdist(scd_handle h, const float* X, const float* C, const int32_t* labels, int64_t n, int d, int k,
+                       float* d2_out, void* stream);
+/* pairwise_distance (sskm_constrained.py:189-224): out[n,k] float32 (mode 0: d2, 1: sqrt(d2)); when cost_out != NULL
+ * also writes the int32 flow costs round(1000*sqrt(d2)) (:324). */
+int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int64_t n, int d, int k, int mode, float* out,
+                    int32_t* cost_out, void* stream);
+/* M-step partials (sskm_constrained.py:125-128) + inertia of the same labels against C_old (:118-120):
+ * sums[k,d] float64, counts[k] int64, inertia[2] float64 = {rows < split, rows >= split}.  Partials are what a
+ * multi-GPU caller all-reduces before scd_kmeans_finalize. */
+size_t scd_kmeans_mstep_ws_bytes(int64_t n, int d, int k);
+int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d, int k,
+                     int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes,
+                     void* stream);
+/* centres = sums / counts (empty -> NaN, as torch mean of an empty selection); shift_out (device double, may be NULL)
+ * = (sum_k ||c_k - c_old_k||_2)^2  (sskm_constrained.py:135-136) */
+int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old,
+                        float* C_out, double* shift_out, void* stream);
+/* incremental k-means++ (kpp, sskm_constrained.py:28-44): d2 = min(d2, ||x - c_new||^2) */
+int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int64_t n, int d, float* d2_inout,
+                          void* stream);
+/* one draw: prob = d2/float32(total); first i with float32(prefix + cumsum_f64(prob))[i] >= r; idx_out device int64
+ * (-1: none on this shard).  total / prefix (device doubles, may be NULL = local sum / 0) make the draw shard-aware for
+ * multi-GPU k-means++; probsum_out (device double, may be NULL) receives this shard's sum of prob. */
+size_t scd_kpp_draw_ws_bytes(int64_t n);
+int scd_kpp_draw(scd_handle h, const float* d2, int64_t n, float r, const double* total, const double* prefix,
+                 int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream);
+/* deterministic float64 sum of a float32 vector (inertia, d2.sum()) */
+int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out, void* stream);
+
+/* ---- vote histogram: Counter(...).most_common(m) per cluster, main_unsup.py:573-586, main_ptsup.py:636-648.
+ * name_idx int64 [n, ld] (first top_k columns used); preds int64 [n]; clusters int64 [n_clusters] (ids to vote for);
+ * known int64 [n_known] vocabulary ids to drop (may be NULL).  Output per cluster c: keys_out[c, 0..m) and
+ * counts_out[c, 0..m) in most_common order (count desc, first-seen asc), padded with -1 / 0. */
+size_t scd_vote_hist_ws_bytes(int64_t n, int top_k);
+int scd_vote_hist(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int top_k, const int64_t* preds,
+                  const int64_t* clusters, int n_clusters, const int64_t* known, int n_known, int m,
+                  int64_t* keys_out, int32_t* counts_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- host solvers (CPU, synchronous) ---- */
+/* linear_assignment (gcd/project_utils/cluster_utils.py:234-493), same tie-breaking; pairs_out [min(n,m),2] sorted */
+int scd_munkres(const int64_t* cost, int n, int m, int64_t* pairs_out, int* n_pairs_out);
+/* solve_min_cost_flow_graph (sskm_constrained.py:331-356) on the transportation form: cost int32 [n,k] */
+int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
+                        int64_t* total_cost_out);
+
+/* ---- encoders: CLIP ViT-B/16 visual / text (third-party `clip`, call sites main_unsup.py:127,
+ *      clip_lang_util.py:101-102) and DINO ViT-B/16 (gcd/models/vision_transformer.py:135-219) ---- */
+typedef struct scd_encoder_desc {
+    int kind;          /* 0 CLIP visual, 1 CLIP text, 2 DINO/GCD ViT */
+    int width, layers, heads, mlp_dim;
+    int tokens;        /* 197 / 77 */
+    int patch, image;  /* 16, 224 (visual) */
+    int vocab;         /* 49408 (text) */
+    int out_dim;       /* 512 (CLIP) or 0 = no projection (DINO) */
+    int act;           /* 0 QuickGELU, 1 erf GELU */
+    float ln_eps;
+} scd_encoder_desc;
+/* weights: array of device pointers in the order documented in DESIGN.md (fp16 matrices, fp32 vectors). */
+int scd_encoder_create(scd_handle h, const scd_encoder_desc* desc, const void* const* weights, int n_weights,
+                       scd_encoder** out);
+int scd_encoder_destroy(scd_encoder* e);
+size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch);
+/* pixels [B,3,H,W] (dtype f32/f16) -> out fp16 [B,out] (L2-normalised when normalize != 0) */
+int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const void* pixels, int dtype, int batch, void* out,
+                         int normalize, void* ws, size_t ws_bytes, void* stream);
+/* tokens int32 [B,77] -> out fp16 [B,out] */
+int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out,
+                         int normalize, void* ws, size_t ws_bytes, void* stream);
+/* building block exposed for tests: C[m,n] = A[m,k] @ W[n,k]^T (+bias)(act)(+residual), fp16 in/out, fp32 accumulate */
+int scd_gemm_f16(scd_handle h, const void* A, const void* W, const float* bias, const void* residual, void* C,
+                 int64_t m, int n, int k, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCD_HIP_H */

@@ -1,0 +1,130 @@
+"""ctypes binding of libscd_hip.so (include/scd_hip.h).
+
+The library is the product: if it is missing and cannot be built, importing fails
+loudly - there is no CPU or torch fallback for any hot-path op.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libscd_hip.so")
+
+SCD_OK, SCD_EINVAL, SCD_EHIP, SCD_ERCCL, SCD_EINFEASIBLE = 0, -1, -2, -3, -4
+SCD_F32, SCD_F16 = 0, 1
+SIM_RAW, SIM_SOFTMAX = 0, 1
+
+
+class ScdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libscd_hip: %s (status %d)" % (msg, code))
+        self.code = code
+
+
+class EncoderDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("tokens", C.c_int), ("patch", C.c_int), ("image", C.c_int), ("vocab", C.c_int), ("out_dim", C.c_int),
+                ("act", C.c_int), ("ln_eps", C.c_float)]
+
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/scd_hip.h
+SIGNATURES = {
+    "scd_version": (_i, []),
+    "scd_last_error": (C.c_char_p, []),
+    "scd_create": (_i, [_i, C.POINTER(_vp)]),
+    "scd_destroy": (_i, [_vp]),
+    "scd_l2norm_rows": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp]),
+    "scd_sim_topk_ws_bytes": (_sz, [_i64, _i, _i64, _i]),
+    "scd_sim_topk": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_transpose_f16": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "scd_gather_rows_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_prompt_pool": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp]),
+    "scd_kmeans_prep_bytes": (_sz, [_i64, _i]),
+    "scd_kmeans_prepare": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_kmeans_estep_ws_bytes": (_sz, [_i64, _i, _i]),
+    "scd_kmeans_estep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kmeans_rowdist": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "scd_kmeans_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "scd_kmeans_mstep_ws_bytes": (_sz, [_i64, _i, _i]),
+    "scd_kmeans_mstep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "scd_kmeans_min_update": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_kpp_draw_ws_bytes": (_sz, [_i64]),
+    "scd_kpp_draw": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_sum_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),
+    "scd_vote_hist": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "scd_munkres": (_i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
+    "scd_transport_solve": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(_i64)]),
+    "scd_encoder_create": (_i, [_vp, C.POINTER(EncoderDesc), C.POINTER(_vp), _i, C.POINTER(_vp)]),
+    "scd_encoder_destroy": (_i, [_vp]),
+    "scd_encoder_ws_bytes": (_sz, [_vp, _i]),
+    "scd_vit_encode_image": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "scd_clip_encode_text": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "scd_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load (building first if the .so is absent and hipcc is available)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            from . import build as _build
+            _build.build(verbose=False)
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def check(status):
+    if status != SCD_OK:
+        raise ScdError(status, load().scd_last_error().decode("utf-8", "replace"))
+
+
+_handles = {}
+
+
+def handle(device=None):
+    """One scd_handle per device (rank)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise ScdError(SCD_EHIP, "no HIP device visible: the scd_amd hot path has no CPU fallback")
+    if device is None:
+        device = torch.cuda.current_device()
+    device = int(device)
+    h = _handles.get(device)
+    if h is None:
+        out = _vp()
+        check(load().scd_create(device, C.byref(out)))
+        h = _handles[device] = out
+    return h
+
+
+def stream_ptr():
+    import torch
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device (or host) pointer of a tensor / numpy array; None -> NULL."""
+    if t is None:
+        return _vp(0)
+    if hasattr(t, "data_ptr"):
+        return _vp(t.data_ptr())
+    return _vp(t.ctypes.data)

@@ -1,0 +1,179 @@
+"""`clip`-compatible module surface backed by libscd_hip.so.
+
+Mirrors the third-party openai/CLIP package API used by the reference
+(main_unsup.py:237 `clip.load("ViT-B/16")`; clip_lang_util.py:101 `clip.tokenize`).
+Checkpoints: `load` looks for a state dict at $SCD_ROOT/clip/ViT-B-16.pt (torch.save of the
+openai state dict); without one it builds seeded random-init weights and says so
+(`model.synthetic == True`) - there is no network in the build/benchmark environment.
+"""
+import gzip
+import html
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from .model import CLIP, DinoViT
+from . import weights
+
+_MODELS = {"ViT-B/16": weights.CLIP_VITB16}
+MEAN = (0.48145466, 0.4578275, 0.40821073)
+STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def available_models():
+    return list(_MODELS)
+
+
+def _preprocess(n_px):
+    """Resize(n_px, bicubic) -> CenterCrop -> RGB -> ToTensor -> Normalize (SURVEY.md appendix B 'Preprocess')."""
+    def run(img):
+        from PIL import Image
+        img = img.convert("RGB")
+        w, h = img.size
+        s = n_px / min(w, h)
+        img = img.resize((max(n_px, int(round(w * s))), max(n_px, int(round(h * s)))), Image.BICUBIC)
+        w, h = img.size
+        l, t = (w - n_px) // 2, (h - n_px) // 2
+        img = img.crop((l, t, l + n_px, t + n_px))
+        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        return (x - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1)
+    return run
+
+
+def load(name="ViT-B/16", device=None, jit=False, download_root=None, seed=0):
+    if name not in _MODELS:
+        raise RuntimeError("Model %s not found; available models = %s" % (name, available_models()))
+    root = download_root or os.environ.get("SCD_ROOT", "")
+    path = os.path.join(root, "clip", name.replace("/", "-") + ".pt") if root else ""
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.state_dict() if hasattr(sd, "state_dict") else sd
+        synthetic = False
+    else:
+        sd = weights.synthetic_clip_state_dict(seed=seed)
+        synthetic = True
+    model = CLIP(sd)
+    model.synthetic = synthetic
+    if device is None or str(device).startswith("cuda"):
+        if torch.cuda.is_available():
+            model.cuda()
+    return model, _preprocess(_MODELS[name]["image"])
+
+
+# ----------------------------------------------------------------------------- tokenizer
+class SimpleTokenizer:
+    """Byte-level BPE of openai/CLIP simple_tokenizer (lower-cased, SOT 49406, EOT 49407).
+    Needs the merges file bpe_simple_vocab_16e6.txt.gz ($SCD_CLIP_BPE or $SCD_ROOT/clip/)."""
+
+    def __init__(self, bpe_path):
+        import regex as re
+        bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+        cs = bs[:]
+        n = 0
+        for b in range(256):
+            if b not in bs:
+                bs.append(b)
+                cs.append(256 + n)
+                n += 1
+        self.byte_encoder = dict(zip(bs, [chr(c) for c in cs]))
+        merges = gzip.open(bpe_path).read().decode("utf-8").split("\n")
+        merges = [tuple(m.split()) for m in merges[1:49152 - 256 - 2 + 1]]
+        vocab = list(self.byte_encoder.values())
+        vocab = vocab + [v + "</w>" for v in vocab]
+        for m in merges:
+            vocab.append("".join(m))
+        vocab.extend(["<|startoftext|>", "<|endoftext|>"])
+        self.encoder = dict(zip(vocab, range(len(vocab))))
+        self.bpe_ranks = dict(zip(merges, range(len(merges))))
+        self.cache = {"<|startoftext|>": "<|startoftext|>", "<|endoftext|>": "<|endoftext|>"}
+        self.pat = re.compile(r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+""",
+                              re.IGNORECASE)
+        self.sot, self.eot = self.encoder["<|startoftext|>"], self.encoder["<|endoftext|>"]
+
+    def bpe(self, token):
+        if token in self.cache:
+            return self.cache[token]
+        word = tuple(token[:-1]) + (token[-1] + "</w>",)
+        pairs = set(zip(word[:-1], word[1:]))
+        if not pairs:
+            return token + "</w>"
+        while True:
+            bigram = min(pairs, key=lambda p: self.bpe_ranks.get(p, float("inf")))
+            if bigram not in self.bpe_ranks:
+                break
+            first, second = bigram
+            new, i = [], 0
+            while i < len(word):
+                try:
+                    j = word.index(first, i)
+                    new.extend(word[i:j])
+                    i = j
+                except ValueError:
+                    new.extend(word[i:])
+                    break
+                if word[i] == first and i < len(word) - 1 and word[i + 1] == second:
+                    new.append(first + second)
+                    i += 2
+                else:
+                    new.append(word[i])
+                    i += 1
+            word = tuple(new)
+            if len(word) == 1:
+                break
+            pairs = set(zip(word[:-1], word[1:]))
+        out = " ".join(word)
+        self.cache[token] = out
+        return out
+
+    def encode(self, text):
+        text = " ".join(html.unescape(html.unescape(text)).split()).strip().lower()
+        ids = []
+        for tok in self.pat.findall(text):
+            tok = "".join(self.byte_encoder[b] for b in tok.encode("utf-8"))
+            ids.extend(self.encoder[t] for t in self.bpe(tok).split(" "))
+        return ids
+
+
+class HashTokenizer:
+    """Stand-in used ONLY when the BPE merges file is absent (synthetic benchmarks): one id per word,
+    a stable hash into [1, 49405].  Results are not comparable with real CLIP tokenisation."""
+    sot, eot = 49406, 49407
+
+    def encode(self, text):
+        import zlib
+        return [1 + zlib.crc32(w.encode("utf-8")) % 49405 for w in text.lower().replace("_", " ").split()]
+
+
+_tokenizer = None
+
+
+def _get_tokenizer():
+    global _tokenizer
+    if _tokenizer is None:
+        cands = [os.environ.get("SCD_CLIP_BPE", ""), os.path.join(os.environ.get("SCD_ROOT", ""), "clip", "bpe_simple_vocab_16e6.txt.gz")]
+        path = next((p for p in cands if p and os.path.exists(p)), None)
+        if path:
+            _tokenizer = SimpleTokenizer(path)
+        else:
+            warnings.warn("CLIP BPE merges file not found ($SCD_CLIP_BPE); using the synthetic hash tokenizer")
+            _tokenizer = HashTokenizer()
+    return _tokenizer
+
+
+def tokenize(texts, context_length=77, truncate=False):
+    """-> IntTensor [len(texts), context_length]; raises if a text is too long (like the package)."""
+    if isinstance(texts, str):
+        texts = [texts]
+    tk = _get_tokenizer()
+    out = torch.zeros(len(texts), context_length, dtype=torch.int32)
+    for i, t in enumerate(texts):
+        ids = [tk.sot] + tk.encode(t) + [tk.eot]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError("Input %s is too long for context length %d" % (t, context_length))
+            ids = ids[:context_length]
+            ids[-1] = tk.eot
+        out[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return out

@@ -1,0 +1,37 @@
+// Handle management and error reporting for libscd_hip.so.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void scd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int scd_version(void) { return 100; }
+extern "C" const char* scd_last_error(void) { return g_err; }
+
+extern "C" int scd_create(int device, scd_handle* out) {
+    SCD_REQUIRE(out, "scd_create: null out");
+    int count = 0;
+    SCD_HIP(hipGetDeviceCount(&count));
+    SCD_REQUIRE(device >= 0 && device < count, "scd_create: device %d out of range (%d visible)", device, count);
+    SCD_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SCD_HIP(hipGetDeviceProperties(&prop, device));
+    SCD_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                "scd_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    scd_ctx* c = new scd_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return SCD_OK;
+}
+
+extern "C" int scd_destroy(scd_handle h) {
+    delete h;
+    return SCD_OK;
+}

@@ -1,0 +1,63 @@
+// Internal helpers shared by the HIP translation units of libscd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+#include "../../include/scd_hip.h"
+
+struct scd_ctx {
+    int device;
+    int n_cu;
+};
+
+void scd_set_error(const char* fmt, ...);
+
+#define SCD_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            scd_set_error(__VA_ARGS__);                         \
+            return SCD_EINVAL;                                  \
+        }                                                       \
+    } while (0)
+
+#define SCD_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            scd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SCD_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define SCD_LAUNCH_CHECK() SCD_HIP(hipGetLastError())
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline size_t scd_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int64_t scd_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+__host__ __device__ __forceinline__ long long scd_cdiv_dev(long long a, long long b) { return (a + b - 1) / b; }
+// ---- wavefront (64 lanes) reductions ----
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#endif

@@ -1,0 +1,477 @@
+// Transformer encoder towers for gfx950: CLIP ViT-B/16 visual and text (third-party `clip`, call sites
+// /root/reference/main_unsup.py:127 and local_utils/clip_lang_util.py:101-102; structure in SURVEY.md appendix B)
+// and the DINO/GCD ViT-B/16 of /root/reference/gcd/models/vision_transformer.py:135-219.
+//
+// Data layout: activations are token-major [image*T + token][width] fp16 (the residual stream is fp16 like the
+// reference's `clip.load` model on GPU); LayerNorm statistics, softmax and every GEMM accumulate in fp32.
+// Internally the batch is padded to a multiple of 128 images so every GEMM is an exact multiple of its
+// 128x128x64 tile (197*128 rows).
+#include "common.h"
+#include "gemm.h"
+#include <vector>
+
+struct scd_encoder {
+    scd_encoder_desc d;
+    std::vector<const void*> w;
+};
+
+enum { W_PATCH = 0, W_PATCH_B = 1, W_CLS = 2, W_POS = 3, W_LNPRE_W = 4, W_LNPRE_B = 5, W_LNPOST_W = 6, W_LNPOST_B = 7,
+       W_PROJ = 8, W_LAYER0 = 9, W_PER_LAYER = 12 };
+enum { L_LN1_W = 0, L_LN1_B, L_QKV_W, L_QKV_B, L_PROJ_W, L_PROJ_B, L_LN2_W, L_LN2_B, L_FC1_W, L_FC1_B, L_FC2_W, L_FC2_B };
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; width % 256 == 0; lane owns 4-element groups (i*64+lane)*4
+template <int MAXG>
+__device__ __forceinline__ void ln_row(const float (&v)[MAXG][4], int groups, int width, float eps, const float* g,
+                                       const float* b, half_t* out, int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+        if (i < groups) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean = wave_sum_f32(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+        if (i < groups) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    const float rstd = rsqrtf(wave_sum_f32(q) / (float)width + eps);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i)
+        if (i < groups) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 gg = *(const float4*)(g + c);
+            const float4 bb = *(const float4*)(b + c);
+            half4 o;
+            o[0] = (half_t)((v[i][0] - mean) * rstd * gg.x + bb.x);
+            o[1] = (half_t)((v[i][1] - mean) * rstd * gg.y + bb.y);
+            o[2] = (half_t)((v[i][2] - mean) * rstd * gg.z + bb.z);
+            o[3] = (half_t)((v[i][3] - mean) * rstd * gg.w + bb.w);
+            *(half4*)(out + c) = o;
+        }
+}
+
+// rows: if row_index != NULL, input row = row_index[r] (gather of CLS / EOT rows)
+__global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict__ x, const int* __restrict__ row_index,
+                                                        long long rows, int width, float eps, const float* __restrict__ g,
+                                                        const float* __restrict__ b, half_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long long src = row_index ? row_index[r] : r;
+    const int groups = width >> 8;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < groups) {
+            const half4 h4 = *(const half4*)(x + src * width + (i * 64 + lane) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (float)h4[j];
+        }
+    ln_row<4>(v, groups, width, eps, g, b, out + r * width, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// im2col for the stride-16 patch convolution: out[(b*np + p)][c*P*P + i*P + j] = img[b][c][py*P+i][px*P+j]
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_kernel(const T* __restrict__ img, int batch, int batch_pad, int image, int patch,
+                                                     half_t* __restrict__ out) {
+    const int gp = image / patch, np = gp * gp, kk = 3 * patch * patch;
+    const long long total8 = (long long)batch_pad * np * kk / 8;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total8) return;
+    const long long e = t * 8;
+    const int col = (int)(e % kk);
+    const long long row = e / kk;
+    const int b = (int)(row / np), p = (int)(row % np);
+    half8 o;
+    if (b < batch) {
+        const int c = col / (patch * patch), rem = col % (patch * patch), i = rem / patch, j = rem % patch;
+        const int py = p / gp, px = p % gp;
+        const T* src = img + (((size_t)b * 3 + c) * image + (py * patch + i)) * image + px * patch + j;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)(float)src[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)0.f;
+    }
+    *(half8*)(out + e) = o;
+}
+
+// token assembly (+ optional ln_pre): x[b][0] = cls + pos[0]; x[b][1+p] = patch[b*np+p] + patch_bias + pos[1+p]
+__global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __restrict__ patch, const float* __restrict__ patch_b,
+                                                              const float* __restrict__ cls, const float* __restrict__ pos,
+                                                              long long rows, int T, int width, const float* __restrict__ lg,
+                                                              const float* __restrict__ lb, float eps, half_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long long b = r / T;
+    const int t = (int)(r % T);
+    const int groups = width >> 8;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < groups) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 pp = *(const float4*)(pos + (size_t)t * width + c);
+            float4 a;
+            if (t == 0) {
+                a = *(const float4*)(cls + c);
+            } else {
+                const half4 h4 = *(const half4*)(patch + ((size_t)b * (T - 1) + (t - 1)) * width + c);
+                a = make_float4((float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]);
+                if (patch_b) {
+                    const float4 pb = *(const float4*)(patch_b + c);
+                    a.x += pb.x; a.y += pb.y; a.z += pb.z; a.w += pb.w;
+                }
+            }
+            v[i][0] = a.x + pp.x; v[i][1] = a.y + pp.y; v[i][2] = a.z + pp.z; v[i][3] = a.w + pp.w;
+        }
+    if (lg) {
+        ln_row<4>(v, groups, width, eps, lg, lb, out + r * width, lane);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < groups) {
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (half_t)v[i][j];
+                *(half4*)(out + r * width + (i * 64 + lane) * 4) = o;
+            }
+    }
+}
+
+// text: x[b][t] = tok_emb[token] + pos[t]; eot_row[b] = b*T + argmax_t token (first maximum, like torch.argmax)
+__global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__ tokens, int batch, const half_t* __restrict__ emb,
+                                                         int vocab, const float* __restrict__ pos, long long rows, int T,
+                                                         int width, half_t* __restrict__ out, int* __restrict__ eot_row) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long long b = r / T;
+    const int t = (int)(r % T);
+    int tok = 0;
+    if (b < batch) tok = tokens[b * T + t];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    for (int c = lane * 4; c < width; c += 256) {
+        const half4 e4 = *(const half4*)(emb + (size_t)tok * width + c);
+        const float4 pp = *(const float4*)(pos + (size_t)t * width + c);
+        half4 o;
+        o[0] = (half_t)((float)e4[0] + pp.x); o[1] = (half_t)((float)e4[1] + pp.y);
+        o[2] = (half_t)((float)e4[2] + pp.z); o[3] = (half_t)((float)e4[3] + pp.w);
+        *(half4*)(out + r * width + c) = o;
+    }
+    if (t == 0 && lane == 0) {
+        int best = 0, bt = -2147483647;
+        if (b < batch)
+            for (int i = 0; i < T; ++i) {
+                const int v = tokens[b * T + i];
+                if (v > bt) { bt = v; best = i; }
+            }
+        eot_row[b] = (int)(b * T + best);
+    }
+}
+
+__global__ void cls_rows_kernel(int* rows, int n, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = i * T;
+}
+
+// copy the first `batch` rows to the caller, optionally L2-normalised (F.normalize semantics)
+__global__ void __launch_bounds__(256) emit_kernel(const half_t* __restrict__ in, int batch, int dim, int normalize,
+                                                   half_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= batch) return;
+    float s = 0.f;
+    for (int j = lane; j < dim; j += 64) {
+        const float v = (float)in[(size_t)r * dim + j];
+        s = fmaf(v, v, s);
+    }
+    s = wave_sum_f32(s);
+    const float inv = normalize ? 1.0f / fmaxf(sqrtf(s), 1e-12f) : 1.0f;
+    for (int j = lane; j < dim; j += 64) out[(size_t)r * dim + j] = (half_t)((float)in[(size_t)r * dim + j] * inv);
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One block (4 waves) per (image, head); head_dim = 64.  K rows and V^T live in LDS; a wave owns 32-query blocks.
+// S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows, B = Q rows): lane = query, registers = keys, so the softmax
+// reductions are in-lane plus one exchange between lanes l and l+32; the exponentiated S^T registers are then the
+// B operand of O^T = V^T P^T directly (k order of the accumulator layout: key = 16s + 8(j>>2) + 4h + (j&3)).
+template <int NB>   // NB = ceil(T/32): 7 for T=197, 3 for T=77
+__global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width,
+                                                        int heads, int causal) {
+    constexpr int TP = NB * 32;
+    constexpr int VSTRIDE = TP + 4;                 // halves; 2*(TP+4) bytes per V^T row keeps ds_read_b64 conflict-free
+    __shared__ __attribute__((aligned(16))) char kl[TP * 128];
+    __shared__ __attribute__((aligned(16))) half_t vt[64 * VSTRIDE];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int img = blockIdx.x / heads, head = blockIdx.x % heads;
+    const size_t row0 = (size_t)img * T;
+    const int ld = 3 * width;
+    const half_t* qbase = qkv + row0 * ld + head * 64;
+    const half_t* kbase = qbase + width;
+    const half_t* vbase = qbase + 2 * width;
+
+    // stage K (swizzled 128-B rows) and V^T; rows >= T are zero
+    for (int i = tid; i < TP * 8; i += 256) {
+        const int row = i >> 3, ch = i & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        half8 vv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vv[q] = (half_t)0.f;
+        if (row < T) {
+            kv = *(const uint4*)(kbase + (size_t)row * ld + 8 * ch);
+            vv = *(const half8*)(vbase + (size_t)row * ld + 8 * ch);
+        }
+        *(uint4*)(kl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vt[(8 * ch + q) * VSTRIDE + row] = vv[q];
+    }
+    __syncthreads();
+
+    for (int qb = wave; qb < NB; qb += 4) {
+        const int query = qb * 32 + r;
+        const int qrow = query < T ? query : T - 1;
+        half8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qbase + (size_t)qrow * ld + 16 * s + 8 * hh);
+        f32x16 sacc[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = kb * 32 + r;
+                const half8 kf = *(const half8*)(kl + row * 128 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 4));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // scale, mask, softmax over keys (registers x key blocks x the partner half-lane)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                float v = sacc[kb][i] * 0.125f;
+                if (key >= T || (causal && key > query)) v = -INFINITY;
+                sacc[kb][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __expf(sacc[kb][i] - mx);
+                sacc[kb][i] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+        f32x16 oacc[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const half_t* vrow = vt + (db * 32 + r) * VSTRIDE + kb * 32 + 16 * s + 4 * hh;
+                    const half4 lo = *(const half4*)(vrow);
+                    const half4 hi = *(const half4*)(vrow + 8);
+                    half8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        if (query < T) {
+            half_t* orow = out + (row0 + query) * width + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 o;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) o[q4] = (half_t)(oacc[db][4 * g + q4] * inv);
+                    *(half4*)(orow + db * 32 + 8 * g + 4 * hh) = o;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline int batch_pad(int b) { return (b + 127) / 128 * 128; }
+
+struct EncWs {
+    half_t *x, *y, *qkv, *h, *cls, *outp;
+    int* rows;
+    size_t total;
+};
+static EncWs carve(const scd_encoder_desc& d, int bp, char* base) {
+    EncWs w;
+    const size_t rows = (size_t)bp * d.tokens;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += scd_align(bytes); return p; };
+    w.x = (half_t*)take(rows * d.width * 2);
+    w.y = (half_t*)take(rows * d.width * 2);
+    w.qkv = (half_t*)take(rows * 3 * d.width * 2);
+    w.h = (half_t*)take(rows * d.mlp_dim * 2);
+    w.cls = (half_t*)take((size_t)bp * d.width * 2);
+    w.outp = (half_t*)take((size_t)bp * (d.out_dim > 0 ? d.out_dim : d.width) * 2);
+    w.rows = (int*)take((size_t)bp * 4);
+    w.total = off + 256;
+    return w;
+}
+
+extern "C" int scd_encoder_create(scd_handle h, const scd_encoder_desc* desc, const void* const* weights, int n_weights,
+                                  scd_encoder** out) {
+    SCD_REQUIRE(h && desc && weights && out, "scd_encoder_create: null argument");
+    const scd_encoder_desc& d = *desc;
+    SCD_REQUIRE(d.kind >= 0 && d.kind <= 2, "scd_encoder_create: bad kind %d", d.kind);
+    SCD_REQUIRE(d.width % 256 == 0 && d.width <= 1024 && d.width == d.heads * 64, "scd_encoder_create: width %d / heads %d (head_dim must be 64)", d.width, d.heads);
+    SCD_REQUIRE(d.mlp_dim % 128 == 0 && d.layers > 0, "scd_encoder_create: bad mlp_dim/layers");
+    SCD_REQUIRE(d.out_dim == 0 || d.out_dim % 128 == 0, "scd_encoder_create: out_dim %d must be a multiple of 128", d.out_dim);
+    SCD_REQUIRE(n_weights == W_LAYER0 + W_PER_LAYER * d.layers, "scd_encoder_create: expected %d weight pointers, got %d",
+                W_LAYER0 + W_PER_LAYER * d.layers, n_weights);
+    if (d.kind == 1) {
+        SCD_REQUIRE(d.tokens == 77 && d.vocab > 0, "scd_encoder_create: text tower expects 77 tokens");
+        SCD_REQUIRE(weights[W_PATCH] && weights[W_POS] && weights[W_LNPOST_W] && weights[W_LNPOST_B] && weights[W_PROJ] && d.out_dim > 0,
+                    "scd_encoder_create: text tower weight missing");
+    } else {
+        SCD_REQUIRE(d.patch > 0 && d.image % d.patch == 0 && (3 * d.patch * d.patch) % 64 == 0, "scd_encoder_create: bad patch/image");
+        const int np = (d.image / d.patch) * (d.image / d.patch);
+        SCD_REQUIRE(d.tokens == np + 1 && d.tokens == 197, "scd_encoder_create: visual tower expects 197 tokens, got %d", d.tokens);
+        SCD_REQUIRE(weights[W_PATCH] && weights[W_CLS] && weights[W_POS] && weights[W_LNPOST_W] && weights[W_LNPOST_B],
+                    "scd_encoder_create: visual tower weight missing");
+        SCD_REQUIRE((d.out_dim > 0) == (weights[W_PROJ] != nullptr), "scd_encoder_create: projection / out_dim mismatch");
+    }
+    for (int l = 0; l < d.layers; ++l)
+        for (int j = 0; j < W_PER_LAYER; ++j)
+            SCD_REQUIRE(weights[W_LAYER0 + l * W_PER_LAYER + j], "scd_encoder_create: layer %d weight %d is null", l, j);
+    scd_encoder* e = new scd_encoder();
+    e->d = d;
+    e->w.assign(weights, weights + n_weights);
+    *out = e;
+    return SCD_OK;
+}
+
+extern "C" int scd_encoder_destroy(scd_encoder* e) {
+    delete e;
+    return SCD_OK;
+}
+
+extern "C" size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch) {
+    if (!e || batch <= 0) return 0;
+    return carve(e->d, batch_pad(batch), nullptr).total;
+}
+
+static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t st) {
+    const scd_encoder_desc& d = e->d;
+    const long long rows = (long long)bp * d.tokens;
+    const int act = d.act == 0 ? SCD_ACT_QUICKGELU : SCD_ACT_GELU;
+    const int causal = d.kind == 1;
+    for (int l = 0; l < d.layers; ++l) {
+        const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
+        layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN1_W],
+                                                                       (const float*)lw[L_LN1_B], w.y);
+        int rc = scd_gemm_launch(w.y, (const half_t*)lw[L_QKV_W], (const float*)lw[L_QKV_B], nullptr, w.qkv, rows, 3 * d.width,
+                                 d.width, SCD_ACT_NONE, st);
+        if (rc) return rc;
+        if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal);
+        else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal);
+        rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
+                             SCD_ACT_NONE, st);
+        if (rc) return rc;
+        layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
+                                                                       (const float*)lw[L_LN2_B], w.y);
+        rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
+        if (rc) return rc;
+        rc = scd_gemm_launch(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
+                             SCD_ACT_NONE, st);
+        if (rc) return rc;
+    }
+    return SCD_OK;
+}
+
+static int run_head(const scd_encoder* e, const EncWs& w, int batch, int bp, void* out, int normalize, hipStream_t st) {
+    const scd_encoder_desc& d = e->d;
+    // final LayerNorm on the gathered CLS / EOT rows, then the projection
+    layernorm_kernel<<<(unsigned)scd_cdiv(bp, 4), 256, 0, st>>>(w.x, w.rows, bp, d.width, d.ln_eps, (const float*)e->w[W_LNPOST_W],
+                                                                 (const float*)e->w[W_LNPOST_B], w.cls);
+    const half_t* fin = w.cls;
+    int dim = d.width;
+    if (d.out_dim > 0) {
+        int rc = scd_gemm_launch(w.cls, (const half_t*)e->w[W_PROJ], nullptr, nullptr, w.outp, bp, d.out_dim, d.width, SCD_ACT_NONE, st);
+        if (rc) return rc;
+        fin = w.outp;
+        dim = d.out_dim;
+    }
+    emit_kernel<<<(unsigned)scd_cdiv(batch, 4), 256, 0, st>>>(fin, batch, dim, normalize, (half_t*)out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const void* pixels, int dtype, int batch, void* out,
+                                    int normalize, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(h && e && pixels && out && ws && batch > 0, "scd_vit_encode_image: bad arguments");
+    SCD_REQUIRE(e->d.kind == 0 || e->d.kind == 2, "scd_vit_encode_image: encoder is not a visual tower");
+    SCD_REQUIRE(dtype == SCD_F32 || dtype == SCD_F16, "scd_vit_encode_image: bad dtype %d", dtype);
+    SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_vit_encode_image: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const scd_encoder_desc& d = e->d;
+    const int bp = batch_pad(batch);
+    EncWs w = carve(d, bp, (char*)ws);
+    const int np = d.tokens - 1, kk = 3 * d.patch * d.patch;
+    const long long total8 = (long long)bp * np * kk / 8;
+    half_t* cols = w.qkv;      // [bp*np, kk] scratch (fits: kk <= 3*width)
+    SCD_REQUIRE(kk <= 3 * d.width, "scd_vit_encode_image: patch too large for scratch");
+    if (dtype == SCD_F32) im2col_kernel<float><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const float*)pixels, batch, bp, d.image, d.patch, cols);
+    else im2col_kernel<half_t><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const half_t*)pixels, batch, bp, d.image, d.patch, cols);
+    int rc = scd_gemm_launch(cols, (const half_t*)e->w[W_PATCH], nullptr, nullptr, w.y, (long long)bp * np, d.width, kk, SCD_ACT_NONE, st);
+    if (rc) return rc;
+    const long long rows = (long long)bp * d.tokens;
+    assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
+                                                                         (const float*)e->w[W_POS], rows, d.tokens, d.width,
+                                                                         (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
+                                                                         d.ln_eps, w.x);
+    cls_rows_kernel<<<(bp + 255) / 256, 256, 0, st>>>(w.rows, bp, d.tokens);
+    rc = run_blocks(e, w, bp, st);
+    if (rc) return rc;
+    return run_head(e, w, batch, bp, out, normalize, st);
+}
+
+extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
+                                    void* ws, size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(h && e && tokens && out && ws && batch > 0, "scd_clip_encode_text: bad arguments");
+    SCD_REQUIRE(e->d.kind == 1, "scd_clip_encode_text: encoder is not a text tower");
+    SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_clip_encode_text: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const scd_encoder_desc& d = e->d;
+    const int bp = batch_pad(batch);
+    EncWs w = carve(d, bp, (char*)ws);
+    const long long rows = (long long)bp * d.tokens;
+    embed_text_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(tokens, batch, (const half_t*)e->w[W_PATCH], d.vocab,
+                                                                    (const float*)e->w[W_POS], rows, d.tokens, d.width, w.x, w.rows);
+    int rc = run_blocks(e, w, bp, st);
+    if (rc) return rc;
+    return run_head(e, w, batch, bp, out, normalize, st);
+}

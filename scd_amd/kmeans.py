@@ -1,0 +1,328 @@
+"""Host orchestration of (semi-supervised / size-constrained) K-Means on the HIP ops.
+
+Mirrors K_Means of /root/reference/gcd/methods/clustering/faster_mix_k_means_pytorch.py:47-275 (SSKM) and
+/root/reference/local_utils/sskm_constrained.py:15-187 (ConSSKM): same constructor arguments, fit / fit_mix,
+labels_ / cluster_centers_ / inertia_ / n_iter_, same RandomState consumption (one rand() per added centre).
+
+Where the reference ships the N x K distance matrix to the host every iteration (:116), this keeps everything
+on the device: E-step (MFMA filter + float64 refine), M-step partial sums, centre finalisation and the
+k-means++ draws are C-ABI calls; only three scalars per Lloyd iteration (inertia x2, centre shift) reach the host.
+
+Multi-GPU (one process per GPU): when `group` is given, X is this rank's shard; the per-iteration exchange is
+ONE all-reduce of [sums | counts | inertia] (float64) - SURVEY.md 8(e) - and the k-means++ draw exchanges the
+shard totals.  The compute backend is injectable (`backend=`) so that the collective logic is testable with
+gloo on CPU; the default and only product backend is scd_amd.ops (HIP).
+"""
+import numpy as np
+import torch
+
+
+def check_random_state(seed):
+    if seed is None or seed is np.random:
+        return np.random.mtrand._rand
+    if isinstance(seed, (int, np.integer)):
+        return np.random.RandomState(seed)
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    raise ValueError("%r cannot be used to seed a numpy.random.RandomState instance" % seed)
+
+
+class HipBackend:
+    """The product compute backend: every method is a libscd_hip.so call (scd_amd.ops)."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def prepare(self, x):
+        return self.ops.KMeansData(x)
+
+    def estep(self, data, centers):
+        return data.estep(centers)
+
+    def rowdist(self, data, centers, labels):
+        return data.rowdist(centers, labels)
+
+    def min_update(self, data, c_new, d2):
+        data.min_update(c_new, d2)
+
+    def dist(self, data, centers, sqrt=False, with_cost=False):
+        return data.dist(centers, sqrt=sqrt, with_cost=with_cost)
+
+    def mstep(self, x, labels32, c_old, k, split):
+        return self.ops.kmeans_mstep(x, labels32, c_old, k, split)
+
+    def finalize(self, sums, counts, c_old):
+        return self.ops.kmeans_finalize(sums, counts, c_old)
+
+    def sum_f32(self, x):
+        return self.ops.sum_f32(x)
+
+    def kpp_draw(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+        return self.ops.kpp_draw(d2, r, total, prefix, want_idx, want_probsum)
+
+    def transport(self, cost, size_min, size_max):
+        return self.ops.transport_solve(cost, size_min, size_max)
+
+
+class _Dist:
+    """Thin wrapper over torch.distributed for the three exchanges k-means needs."""
+
+    def __init__(self, group):
+        import torch.distributed as dist
+        self.d = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allreduce_(self, t):
+        self.d.all_reduce(t, op=self.d.ReduceOp.SUM, group=self.group)
+        return t
+
+    def allgather(self, t):
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.d.all_gather(out, t, group=self.group)
+        return torch.stack(out)
+
+    def broadcast_(self, t, src):
+        self.d.broadcast(t, src=self.d.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        return t
+
+
+class KMeansEngine:
+    """Shared implementation; the two reference-named K_Means classes configure it."""
+
+    constrained = False
+
+    def __init__(self, k=3, tolerance=1e-4, max_iterations=100, init="k-means++", n_init=10, random_state=None, n_jobs=None,
+                 pairwise_batch_size=None, backend=None, group=None):
+        self.k = k
+        self.tolerance = tolerance
+        self.max_iterations = max_iterations
+        self.init = init
+        self.n_init = n_init
+        self.random_state = random_state
+        self.n_jobs = n_jobs
+        self.pairwise_batch_size = pairwise_batch_size
+        self.backend = backend
+        self.group = group
+        self.stats = {"estep_calls": 0, "refined_rows": 0}
+
+    # ------------------------------------------------------------------ helpers
+    def _be(self):
+        if self.backend is None:
+            self.backend = HipBackend()
+        return self.backend
+
+    def _dist(self):
+        return _Dist(self.group) if self.group is not None else None
+
+    def _class_means(self, l, l_targets):
+        """l_centers = per-class mean in torch.unique order (sskm_constrained.py:88-96)."""
+        classes = torch.unique(l_targets)
+        rank = torch.searchsorted(classes, l_targets).to(torch.int32)
+        sums, counts, _ = self._be().mstep(l, rank.contiguous(), None, int(classes.numel()), 0)
+        dd = self._dist()
+        if dd:
+            dd.allreduce_(sums)
+            dd.allreduce_(counts)
+        cent, _ = self._be().finalize(sums, counts, None)
+        return classes, rank.to(torch.int64), cent
+
+    def kpp(self, X, pre_centers=None, k=10, random_state=None, data=None):
+        """K_Means.kpp (sskm_constrained.py:28-44): incremental, all on device; one rand() per added centre."""
+        rs = check_random_state(random_state)
+        be = self._be()
+        dd = self._dist()
+        if data is None:
+            data = be.prepare(X)
+        x = data.x
+        if pre_centers is not None:
+            C = pre_centers.reshape(-1, x.shape[1]).to(torch.float32)
+        else:
+            first = rs.randint(0, self._global_len(x, dd))
+            C = self._fetch_row(x, first, dd).reshape(1, -1)
+        labels = be.estep(data, C)
+        d2 = be.rowdist(data, C, labels)
+        picks = []
+        while C.shape[0] < k:
+            r = rs.rand()
+            if dd is None:
+                idx, _ = be.kpp_draw(d2, r)
+                row = x.index_select(0, idx.clamp(min=0)).reshape(1, -1)
+                picks.append(idx)
+            else:
+                tot = dd.allreduce_(be.sum_f32(d2))
+                _, ps = be.kpp_draw(d2, r, total=tot, want_idx=False, want_probsum=True)
+                allps = dd.allgather(ps).reshape(-1)
+                prefix = allps[: dd.rank].sum().reshape(1) if dd.rank > 0 else torch.zeros_like(ps)
+                idx, _ = be.kpp_draw(d2, r, total=tot, prefix=prefix.contiguous())
+                hits = dd.allgather(idx).reshape(-1)
+                owners = torch.nonzero(hits >= 0)
+                owner = int(owners[0]) if owners.numel() else -1
+                picks.append(torch.tensor([-1 if owner < 0 else 0], device=idx.device))
+                row = x.index_select(0, idx.clamp(min=0)).reshape(1, -1).contiguous()
+                if owner >= 0:
+                    dd.broadcast_(row, owner)
+            C = torch.cat((C, row), dim=0)
+            be.min_update(data, row.reshape(-1), d2)
+        if picks and bool((torch.cat([p.reshape(-1) for p in picks]) < 0).any()):
+            # the reference indexes an empty nonzero() here (sskm_constrained.py:42)
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+        return C
+
+    @staticmethod
+    def _global_len(x, dd):
+        if dd is None:
+            return len(x)
+        n = torch.tensor([len(x)], dtype=torch.int64, device=x.device)
+        return int(dd.allreduce_(n))
+
+    @staticmethod
+    def _fetch_row(x, gidx, dd):
+        if dd is None:
+            return x[gidx].clone()
+        lens = dd.allgather(torch.tensor([len(x)], dtype=torch.int64, device=x.device)).reshape(-1).tolist()
+        owner, off = 0, gidx
+        while off >= lens[owner]:
+            off -= lens[owner]
+            owner += 1
+        row = x[off].clone() if dd.rank == owner else torch.empty(x.shape[1], dtype=x.dtype, device=x.device)
+        return dd.broadcast_(row.contiguous(), owner)
+
+    # E-step on the unlabelled rows -> (int32 labels on device, float32 inertia contribution or None)
+    def _assign(self, data, centers):
+        self.stats["estep_calls"] += 1
+        return self._be().estep(data, centers), None
+
+    def _lloyd(self, data_u, cat, labels, l_num, centers):
+        """Iterations shared by fit_once / fit_mix_once (sskm_constrained.py:110-138)."""
+        be = self._be()
+        dd = self._dist()
+        best = (None, None, None)
+        it = 0
+        for it in range(self.max_iterations):
+            old = centers
+            u_lab, u_inertia = self._assign(data_u, old)
+            labels[l_num:] = u_lab.to(labels.dtype)
+            lab32 = labels.to(torch.int32).contiguous()
+            sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num)
+            if dd:
+                packed = torch.cat([sums.reshape(-1), counts.to(torch.float64), inertia2])
+                dd.allreduce_(packed)
+                kd = sums.numel()
+                sums = packed[:kd].reshape(sums.shape)
+                counts = packed[kd:kd + self.k].round().to(torch.int64)
+                inertia2 = packed[kd + self.k:]
+            centers, shift = be.finalize(sums, counts, old)
+            host = torch.cat([inertia2, shift.reshape(1)]).cpu().numpy()          # the only per-iteration D2H
+            ui = np.float32(host[1]) if u_inertia is None else np.float32(u_inertia)
+            inertia = np.float32(ui + np.float32(host[0]))
+            if best[1] is None or inertia < best[1]:
+                best = (labels.clone(), inertia, centers.clone())
+            if host[2] < self.tolerance:
+                break
+        return best[0], best[1], best[2], it + 1
+
+    # ------------------------------------------------------------------ reference API
+    def fit_once(self, X, random_state, data=None):
+        be = self._be()
+        if data is None:
+            data = be.prepare(X)
+        x = data.x
+        if self.init == "k-means++":
+            centers = self.kpp(x, k=self.k, random_state=random_state, data=data)
+        elif self.init == "random":
+            rs = check_random_state(self.random_state)
+            idx = rs.choice(len(x), self.k, replace=False)
+            centers = x[torch.as_tensor(idx, device=x.device)].clone()
+        else:
+            centers = x[: self.k].clone()
+        labels = torch.empty(len(x), dtype=torch.int64, device=x.device)
+        return self._lloyd(data, x, labels, 0, centers)
+
+    def fit_mix_once(self, u_feats, l_feats, l_targets, random_state, data=None, cat=None):
+        be = self._be()
+        if data is None:
+            data = be.prepare(u_feats)
+        u = data.x
+        l = l_feats.to(device=u.device, dtype=torch.float32).contiguous()
+        l_targets = l_targets.to(u.device)
+        if cat is None:
+            cat = torch.cat((l, u)).contiguous()
+        classes, l_rank, l_centers = self._class_means(l, l_targets)
+        l_num = len(l_targets)
+        labels = torch.empty(len(cat), dtype=torch.int64, device=u.device)
+        labels[:l_num] = l_rank
+        centers = self.kpp(u, l_centers, k=self.k, random_state=random_state, data=data)
+        lab, inertia, cent, _ = self._lloyd(data, cat, labels, l_num, centers)
+        # reference quirk: returns `i + 1` with i the stale labelled-row index (sskm_constrained.py:104,139)
+        return lab, inertia, cent, l_num
+
+    def _run(self, once, *args, **kw):
+        rs = check_random_state(self.random_state)
+        best_inertia = None
+        for _ in range(self.n_init):
+            labels, inertia, centers, n_iters = once(*args, rs, **kw)
+            if best_inertia is None or inertia < best_inertia:
+                self.labels_ = labels.clone()
+                self.cluster_centers_ = centers.clone()
+                best_inertia = inertia
+                self.inertia_ = torch.tensor(float(inertia), dtype=torch.float32)
+                self.n_iter_ = n_iters
+
+    def fit(self, X):
+        data = self._be().prepare(X)
+        self._run(self.fit_once, X, data=data)
+
+    def fit_mix(self, u_feats, l_feats, l_targets):
+        data = self._be().prepare(u_feats)
+        l = l_feats.to(device=data.x.device, dtype=torch.float32).contiguous()
+        cat = torch.cat((l, data.x)).contiguous()
+        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat)
+        self.cluster_centers_ = self.cluster_centers_.type_as(u_feats) if torch.is_floating_point(u_feats) else self.cluster_centers_
+
+
+class ConstrainedEngine(KMeansEngine):
+    """sskm_constrained.K_Means: the E-step is the min-cost-flow assignment (:116, :226-274).
+    The flow problem has global capacity constraints, so it does not shard: with `group` set the int32 costs are
+    gathered to rank 0, solved there, and the labels scattered back ('replicas only' sub-step)."""
+
+    constrained = True
+
+    def __init__(self, k=3, tolerance=1e-4, max_iterations=100, size_min=100, size_max=1000, init="k-means++", n_init=10,
+                 random_state=None, n_jobs=None, pairwise_batch_size=None, backend=None, group=None):
+        super().__init__(k, tolerance, max_iterations, init, n_init, random_state, n_jobs, pairwise_batch_size, backend, group)
+        self.size_min = size_min
+        self.size_max = size_max
+
+    def _assign(self, data, centers):
+        be = self._be()
+        d_sqrt, cost = be.dist(data, centers, sqrt=True, with_cost=True)
+        dd = self._dist()
+        if dd is None:
+            labels_np, _ = be.transport(cost.cpu().numpy(), self.size_min, self.size_max)
+            labels = torch.from_numpy(labels_np).to(cost.device)
+        else:
+            lens = dd.allgather(torch.tensor([cost.shape[0]], dtype=torch.int64, device=cost.device)).reshape(-1).tolist()
+            mx = max(lens)
+            pad = torch.zeros((mx, cost.shape[1]), dtype=torch.int32, device=cost.device)
+            pad[: cost.shape[0]] = cost
+            allc = dd.allgather(pad)
+            lab_all = torch.zeros((dd.world, mx), dtype=torch.int32, device=cost.device)
+            if dd.rank == 0:
+                full = torch.cat([allc[r, : lens[r]] for r in range(dd.world)]).cpu().numpy()
+                lab_np, _ = be.transport(full, self.size_min, self.size_max)
+                off = 0
+                for r in range(dd.world):
+                    lab_all[r, : lens[r]] = torch.from_numpy(lab_np[off:off + lens[r]]).to(cost.device)
+                    off += lens[r]
+            dd.broadcast_(lab_all, 0)
+            labels = lab_all[dd.rank, : cost.shape[0]].contiguous()
+        # distances[:] = D[arange, labels] ** 2 in float32, inertia = sum (:271-272)
+        picked = d_sqrt.gather(1, labels.to(torch.int64).reshape(-1, 1)).reshape(-1)
+        sq = (picked * picked).contiguous()
+        tot = be.sum_f32(sq)
+        if dd:
+            dd.allreduce_(tot)
+        return labels.to(torch.int32), np.float32(float(tot))

@@ -1,0 +1,172 @@
+"""Drop-in for /root/reference/local_utils/clip_lang_util.py on libscd_hip.so: imagenet_templates (:13-94),
+zeroshot_classifier (:96-108), get_wordnet_dict (:113-137), get_nouns (:139-149), accuracy (:151-154),
+assign_name (:156-180), assign_name_on_leftover (:182-206), assign_name_logits (:208-234)."""
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..gcd.project_utils.cluster_utils import linear_assignment
+
+imagenet_templates = [
+    'a bad photo of a {}.',
+    'a photo of many {}.',
+    'a sculpture of a {}.',
+    'a photo of the hard to see {}.',
+    'a low resolution photo of the {}.',
+    'a rendering of a {}.',
+    'graffiti of a {}.',
+    'a bad photo of the {}.',
+    'a cropped photo of the {}.',
+    'a tattoo of a {}.',
+    'the embroidered {}.',
+    'a photo of a hard to see {}.',
+    'a bright photo of a {}.',
+    'a photo of a clean {}.',
+    'a photo of a dirty {}.',
+    'a dark photo of the {}.',
+    'a drawing of a {}.',
+    'a photo of my {}.',
+    'the plastic {}.',
+    'a photo of the cool {}.',
+    'a close-up photo of a {}.',
+    'a black and white photo of the {}.',
+    'a painting of the {}.',
+    'a painting of a {}.',
+    'a pixelated photo of the {}.',
+    'a sculpture of the {}.',
+    'a bright photo of the {}.',
+    'a cropped photo of a {}.',
+    'a plastic {}.',
+    'a photo of the dirty {}.',
+    'a jpeg corrupted photo of a {}.',
+    'a blurry photo of the {}.',
+    'a photo of the {}.',
+    'a good photo of the {}.',
+    'a rendering of the {}.',
+    'a {} in a video game.',
+    'a photo of one {}.',
+    'a doodle of a {}.',
+    'a close-up photo of the {}.',
+    'a photo of a {}.',
+    'the origami {}.',
+    'the {} in a video game.',
+    'a sketch of a {}.',
+    'a doodle of the {}.',
+    'a origami {}.',
+    'a low resolution photo of a {}.',
+    'the toy {}.',
+    'a rendition of the {}.',
+    'a photo of the clean {}.',
+    'a photo of a large {}.',
+    'a rendition of a {}.',
+    'a photo of a nice {}.',
+    'a photo of a weird {}.',
+    'a blurry photo of a {}.',
+    'a cartoon {}.',
+    'art of a {}.',
+    'a sketch of the {}.',
+    'a embroidered {}.',
+    'a pixelated photo of a {}.',
+    'itap of the {}.',
+    'a jpeg corrupted photo of the {}.',
+    'a good photo of a {}.',
+    'a plushie {}.',
+    'a photo of the nice {}.',
+    'a photo of the small {}.',
+    'a photo of the weird {}.',
+    'the cartoon {}.',
+    'art of the {}.',
+    'a drawing of the {}.',
+    'a photo of the large {}.',
+    'a black and white photo of a {}.',
+    'the plushie {}.',
+    'a dark photo of a {}.',
+    'itap of a {}.',
+    'graffiti of the {}.',
+    'a toy {}.',
+    'itap of my {}.',
+    'a photo of a cool {}.',
+    'a photo of a small {}.',
+    'a tattoo of the {}.',
+]
+
+
+def zeroshot_classifier(classnames, templates, model, names_per_batch=16):
+    """[embed_dim, n_names] fp16 on the device: per name normalise(encode_text(prompts)) -> mean -> normalise, stacked
+    along dim=1.  The reference runs one 80x77 forward per name; here names are batched (names_per_batch*len(templates)
+    prompts per encode_text call) and the pooling is one fused kernel per batch."""
+    from .. import clip
+    n, t = len(classnames), len(templates)
+    out = None
+    for s in range(0, n, names_per_batch):
+        names = classnames[s:s + names_per_batch]
+        texts = [template.format(c) for c in names for template in templates]
+        emb = model.encode_text(clip.tokenize(texts).cuda())
+        if out is None:
+            out = torch.empty((emb.shape[1], n), dtype=torch.float16, device=emb.device)
+        ops.prompt_pool(emb.contiguous(), len(names), t, out, s)
+    return out
+
+
+def _data_file(name):
+    for root in (os.environ.get("SCD_DATA", ""), os.path.join(os.environ.get("SCD_ROOT", ""), "data")):
+        p = os.path.join(root, name)
+        if root and os.path.exists(p):
+            return p
+    raise FileNotFoundError("%s not found under $SCD_DATA or $SCD_ROOT/data (the reference hard-codes "
+                            "/disk/work/xhhuang/scd_v1/language_ncd_yandong/data, clip_lang_util.py:141-148)" % name)
+
+
+def get_nouns(corpus='wordnet'):
+    fname = {'wordnet': 'wordnet_all_noun.txt', 'wikibird': 'wiki_birdclass_names.txt',
+             'wikidog': 'wiki_dogclass_names.txt'}[corpus]
+    with open(_data_file(fname)) as f:
+        return [line.rstrip('\n') for line in f]
+
+
+def get_wordnet_dict():
+    from nltk.corpus import wordnet as wn          # optional dependency, host-only metadata
+    wnid_to_synset, wnid_to_name, name_to_wnids = {}, {}, defaultdict(list)
+    for n in wn.all_synsets('n'):
+        wnid = "n{:08d}".format(n.offset())
+        wnid_to_synset[wnid] = n
+        name = n.lemma_names()[0].lower().replace('-', '_')
+        wnid_to_name[wnid] = name
+        name_to_wnids[name].append(wnid)
+    return wnid_to_synset, wnid_to_name, name_to_wnids
+
+
+def accuracy(output, target, topk=(1,)):
+    """Counts (not %) of targets within the top-k logits (evaluation helper, host-side glue)."""
+    pred = output.topk(max(topk), 1, True, True)[1].t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [float(correct[:k].reshape(-1).float().sum(0, keepdim=True).cpu().numpy()) for k in topk]
+
+
+def _assign(unique_name_idx, cluster_to_counter, picker):
+    col = {uidx: nidx for nidx, uidx in enumerate(unique_name_idx)}
+    keys = list(cluster_to_counter.keys())
+    D = max(len(unique_name_idx), len(keys))
+    w = np.zeros((D, D), dtype=int)
+    for i, ck in enumerate(keys):
+        for k, v in picker(cluster_to_counter[ck]):
+            w[i, col[k]] += v
+    ind = linear_assignment(w.max() - w)
+    return ind, w
+
+
+def assign_name(unique_name_idx, cluster_to_counter, num_common=4):
+    return _assign(unique_name_idx, cluster_to_counter, lambda ct: ct.most_common(num_common))
+
+
+def assign_name_on_leftover(unique_name_idx, cluster_to_counter, voted_unique_name_idx):
+    return _assign(unique_name_idx, cluster_to_counter,
+                   lambda ct: [(k, v) for k, v in ct.most_common(5) if k not in voted_unique_name_idx])
+
+
+def assign_name_logits(unique_name_idx, cluster_to_logitcounter):
+    return _assign(unique_name_idx, cluster_to_logitcounter,
+                   lambda ct: sorted(ct.items(), key=lambda kv: kv[1], reverse=True)[:4])

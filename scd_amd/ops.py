@@ -1,0 +1,286 @@
+"""Tensor-level wrappers over the C ABI (include/scd_hip.h).
+
+torch is plumbing here: it owns device memory and the current stream; every
+computation below is a call into libscd_hip.so.  Nothing in this module falls
+back to torch math - a missing library or device raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, handle, ptr, stream_ptr, SCD_F16, SCD_F32, SIM_RAW, SIM_SOFTMAX
+
+_L = _lib.load
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.ScdError(_lib.SCD_EINVAL, "tensor must live on the HIP device (got %s)" % t.device)
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- normalise / layout
+def l2norm_rows(x):
+    """F.normalize(x, dim=-1) (main_unsup.py:130)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    dt = {torch.float32: SCD_F32, torch.float16: SCD_F16}[x.dtype]
+    check(_L().scd_l2norm_rows(handle(), ptr(x), dt, x.shape[0], x.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+def transpose_f16(w):
+    """[r,c] fp16 -> [c,r] (zeroshot_weights [512,V] -> name-major Wt [V,512])."""
+    _need_cuda(w)
+    w = w.contiguous()
+    out = torch.empty((w.shape[1], w.shape[0]), dtype=torch.float16, device=w.device)
+    check(_L().scd_transpose_f16(handle(), ptr(w), w.shape[0], w.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+def gather_rows_f16(wt, idx):
+    _need_cuda(wt, idx)
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty((idx.numel(), wt.shape[1]), dtype=torch.float16, device=wt.device)
+    check(_L().scd_gather_rows_f16(handle(), ptr(wt), ptr(idx), idx.numel(), wt.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+# ----------------------------------------------------------------------------- similarity
+def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
+    """Top-k of scale * f @ wt.T per row.  f [n,d] fp16, wt [v,d] fp16 (name-major).
+    Returns (idx int64 [n,k], val float32 [n,k])."""
+    _need_cuda(f, wt)
+    f = f.to(torch.float16).contiguous()
+    wt = wt.to(torch.float16).contiguous()
+    n, d = f.shape
+    v = wt.shape[0]
+    idx = torch.empty((n, k), dtype=torch.int64, device=f.device)
+    val = torch.empty((n, k), dtype=torch.float32, device=f.device)
+    fb = torch.zeros(1, dtype=torch.int32, device=f.device)
+    nb = _L().scd_sim_topk_ws_bytes(n, d, v, k)
+    ws = _ws(nb, f.device)
+    m = SIM_SOFTMAX if mode == "softmax" else SIM_RAW
+    check(_L().scd_sim_topk(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb), ptr(ws), nb,
+                            stream_ptr()))
+    if return_fallback:
+        return idx, val, fb
+    return idx, val
+
+
+def sim_argmax(f, wsel_t, scale=100.0):
+    """argmax(scale * f @ wsel_t.T, -1) (main_unsup.py:603-614)."""
+    idx, val = sim_topk(f, wsel_t, 1, "raw", scale)
+    return idx[:, 0], val[:, 0]
+
+
+def prompt_pool(emb, n_names, t_per, out, col0):
+    """normalise -> mean -> normalise of each name's prompt embeddings into columns of out [d, V]."""
+    _need_cuda(emb, out)
+    check(_L().scd_prompt_pool(handle(), ptr(emb), n_names, t_per, emb.shape[1], col0, out.shape[1], ptr(out), stream_ptr()))
+
+
+# ----------------------------------------------------------------------------- k-means
+class KMeansData:
+    """X (float32 [n,d], device) plus the prepared fp16 E-step operand."""
+
+    def __init__(self, x):
+        _need_cuda(x)
+        self.x = x.to(torch.float32).contiguous()
+        self.n, self.d = self.x.shape
+        self.prep = _ws(_L().scd_kmeans_prep_bytes(self.n, self.d), self.x.device)
+        check(_L().scd_kmeans_prepare(handle(), ptr(self.x), self.n, self.d, ptr(self.prep), stream_ptr()))
+        self._ws = {}
+
+    def ws(self, key, nbytes):
+        w = self._ws.get(key)
+        if w is None or w.numel() < nbytes:
+            w = self._ws[key] = _ws(nbytes, self.x.device)
+        return w
+
+    def estep(self, centers, return_refined=False):
+        k = centers.shape[0]
+        centers = centers.to(torch.float32).contiguous()
+        labels = torch.empty(self.n, dtype=torch.int32, device=self.x.device)
+        ref = torch.zeros(1, dtype=torch.int32, device=self.x.device)
+        nb = _L().scd_kmeans_estep_ws_bytes(self.n, self.d, k)
+        ws = self.ws(("e", k), nb)
+        check(_L().scd_kmeans_estep(handle(), ptr(self.x), ptr(self.prep), ptr(centers), self.n, self.d, k, ptr(labels),
+                                    ptr(ref), ptr(ws), nb, stream_ptr()))
+        return (labels, ref) if return_refined else labels
+
+    def rowdist(self, centers, labels):
+        centers = centers.to(torch.float32).contiguous()
+        out = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
+        check(_L().scd_kmeans_rowdist(handle(), ptr(self.x), ptr(centers), ptr(labels), self.n, self.d, centers.shape[0],
+                                      ptr(out), stream_ptr()))
+        return out
+
+    def min_update(self, c_new, d2):
+        c_new = c_new.to(torch.float32).contiguous()
+        check(_L().scd_kmeans_min_update(handle(), ptr(self.x), ptr(c_new), self.n, self.d, ptr(d2), stream_ptr()))
+
+    def dist(self, centers, sqrt=False, with_cost=False):
+        centers = centers.to(torch.float32).contiguous()
+        k = centers.shape[0]
+        out = torch.empty((self.n, k), dtype=torch.float32, device=self.x.device)
+        cost = torch.empty((self.n, k), dtype=torch.int32, device=self.x.device) if with_cost else None
+        check(_L().scd_kmeans_dist(handle(), ptr(self.x), ptr(centers), self.n, self.d, k, 1 if sqrt else 0, ptr(out), ptr(cost),
+                                   stream_ptr()))
+        return (out, cost) if with_cost else out
+
+
+def kmeans_mstep(x, labels32, c_old, k, split=0):
+    """(sums float64 [k,d], counts int64 [k], inertia float64 [2]) partials of one rank."""
+    _need_cuda(x, labels32)
+    n, d = x.shape
+    sums = torch.empty((k, d), dtype=torch.float64, device=x.device)
+    counts = torch.empty(k, dtype=torch.int64, device=x.device)
+    inertia = torch.zeros(2, dtype=torch.float64, device=x.device)
+    nb = _L().scd_kmeans_mstep_ws_bytes(n, d, k)
+    ws = _ws(nb, x.device)
+    check(_L().scd_kmeans_mstep(handle(), ptr(x), ptr(labels32), ptr(c_old), n, d, k, int(split), ptr(sums), ptr(counts),
+                                ptr(inertia), ptr(ws), nb, stream_ptr()))
+    return sums, counts, inertia
+
+
+def kmeans_finalize(sums, counts, c_old=None):
+    k, d = sums.shape
+    c = torch.empty((k, d), dtype=torch.float32, device=sums.device)
+    shift = torch.zeros(1, dtype=torch.float64, device=sums.device)
+    check(_L().scd_kmeans_finalize(handle(), ptr(sums), ptr(counts), k, d, ptr(c_old), ptr(c), ptr(shift), stream_ptr()))
+    return c, shift
+
+
+def kpp_draw(d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+    """Device-side k-means++ draw.  Returns (idx int64[1] or None, probsum float64[1] or None); idx -1 = no hit."""
+    _need_cuda(d2)
+    idx = torch.empty(1, dtype=torch.int64, device=d2.device) if want_idx else None
+    ps = torch.empty(1, dtype=torch.float64, device=d2.device) if want_probsum else None
+    check(_L().scd_kpp_draw(handle(), ptr(d2), d2.numel(), float(np.float32(r)), ptr(total), ptr(prefix), ptr(idx), ptr(ps),
+                            None, 0, stream_ptr()))
+    return idx, ps
+
+
+def sum_f32(x):
+    _need_cuda(x)
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    check(_L().scd_sum_f32(handle(), ptr(x), x.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+# ----------------------------------------------------------------------------- vote
+def vote_hist(name_idx, top_k, preds, clusters, m, known=None):
+    """most_common(m) of every cluster's Counter: (keys int64 [C,m], counts int32 [C,m]); -1/0 padded."""
+    _need_cuda(name_idx, preds)
+    name_idx = name_idx.to(torch.int64).contiguous()
+    preds = preds.to(torch.int64).contiguous()
+    dev = name_idx.device
+    clusters = torch.as_tensor(clusters, dtype=torch.int64, device=dev).contiguous()
+    kn = None if known is None or len(known) == 0 else torch.as_tensor(known, dtype=torch.int64, device=dev).contiguous()
+    n, ld = name_idx.shape
+    nc = clusters.numel()
+    keys = torch.empty((nc, m), dtype=torch.int64, device=dev)
+    counts = torch.empty((nc, m), dtype=torch.int32, device=dev)
+    nb = _L().scd_vote_hist_ws_bytes(n, top_k)
+    ws = _ws(nb, dev)
+    check(_L().scd_vote_hist(handle(), ptr(name_idx), n, ld, top_k, ptr(preds), ptr(clusters), nc, ptr(kn),
+                             0 if kn is None else kn.numel(), m, ptr(keys), ptr(counts), ptr(ws), nb, stream_ptr()))
+    return keys, counts
+
+
+# ----------------------------------------------------------------------------- host solvers
+def munkres(cost):
+    """linear_assignment (cluster_utils.py:234): int array [n,m] -> sorted pairs [min(n,m),2]."""
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(cost)), dtype=np.int64)
+    n, m = x.shape
+    out = np.zeros((max(1, min(n, m)), 2), dtype=np.int64)
+    npairs = C.c_int(0)
+    check(_L().scd_munkres(ptr(x), n, m, ptr(out), C.byref(npairs)))
+    res = out[: npairs.value].astype(int)
+    res.shape = (-1, 2)
+    return res
+
+
+def transport_solve(cost, size_min, size_max):
+    """Size-constrained assignment; raises Exception('There was an issue with the min cost flow input.')
+    when infeasible (sskm_constrained.py:349-350)."""
+    c = np.ascontiguousarray(cost, dtype=np.int32)
+    n, k = c.shape
+    labels = np.empty(n, dtype=np.int32)
+    total = C.c_int64(0)
+    rc = _L().scd_transport_solve(ptr(c), n, k, int(size_min), int(size_max), ptr(labels), C.byref(total))
+    if rc == _lib.SCD_EINFEASIBLE:
+        raise Exception("There was an issue with the min cost flow input.")
+    check(rc)
+    return labels, total.value
+
+
+# ----------------------------------------------------------------------------- encoders
+def gemm_f16(a, w, bias=None, residual=None, act=0):
+    _need_cuda(a, w)
+    m, k = a.shape
+    n = w.shape[0]
+    c = torch.empty((m, n), dtype=torch.float16, device=a.device)
+    check(_L().scd_gemm_f16(handle(), ptr(a), ptr(w), ptr(bias), ptr(residual), ptr(c), m, n, k, int(act), stream_ptr()))
+    return c
+
+
+class Encoder:
+    """Owns the device weights (kept alive here) and the scd_encoder handle."""
+
+    def __init__(self, desc, weights):
+        self.desc = desc
+        self.weights = weights              # list of tensors / None in the C order
+        arr = (C.c_void_p * len(weights))(*[None if w is None else w.data_ptr() for w in weights])
+        enc = C.c_void_p()
+        d = _lib.EncoderDesc(**desc)
+        check(_L().scd_encoder_create(handle(), C.byref(d), arr, len(weights), C.byref(enc)))
+        self._enc = enc
+        self._ws = None
+        self.out_dim = desc["out_dim"] if desc["out_dim"] > 0 else desc["width"]
+        self.device = next(w for w in weights if w is not None).device
+
+    def __del__(self):
+        try:
+            if getattr(self, "_enc", None):
+                _L().scd_encoder_destroy(self._enc)
+        except Exception:
+            pass
+
+    def _workspace(self, batch):
+        nb = _L().scd_encoder_ws_bytes(self._enc, batch)
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = _ws(nb, self.device)
+        return self._ws, nb
+
+    def encode_image(self, pixels, normalize=False):
+        _need_cuda(pixels)
+        pixels = pixels.contiguous()
+        if pixels.dtype not in (torch.float16, torch.float32):
+            pixels = pixels.float()
+        b = pixels.shape[0]
+        out = torch.empty((b, self.out_dim), dtype=torch.float16, device=pixels.device)
+        ws, nb = self._workspace(b)
+        dt = SCD_F16 if pixels.dtype == torch.float16 else SCD_F32
+        check(_L().scd_vit_encode_image(handle(), self._enc, ptr(pixels), dt, b, ptr(out), 1 if normalize else 0, ptr(ws), nb,
+                                        stream_ptr()))
+        return out
+
+    def encode_text(self, tokens, normalize=False):
+        _need_cuda(tokens)
+        tokens = tokens.to(torch.int32).contiguous()
+        b = tokens.shape[0]
+        out = torch.empty((b, self.out_dim), dtype=torch.float16, device=tokens.device)
+        ws, nb = self._workspace(b)
+        check(_L().scd_clip_encode_text(handle(), self._enc, ptr(tokens), b, ptr(out), 1 if normalize else 0, ptr(ws), nb,
+                                        stream_ptr()))
+        return out

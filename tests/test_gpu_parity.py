@@ -1,0 +1,399 @@
+"""HIP path vs oracle on a real MI355X (run with -m gpu).  Every call goes through the C ABI (scd_amd.ops -> ctypes)."""
+import os
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kmeans_oracle as ko
+from oracle import naming_oracle as no
+from oracle import transport_oracle as to
+from oracle import clip_oracle as co
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device; they must not be skipped on the GPU box"
+    from scd_amd import ops as o
+    return o
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+def test_gemm_identity_asymmetric(ops):
+    # A = I (padded), asymmetric integer W: catches any row/col or lane-map swap exactly
+    m, n, k = 128, 256, 128
+    a = torch.zeros(m, k)
+    a[torch.arange(m), torch.arange(m)] = 1.0
+    w = (torch.arange(n).view(n, 1) * 3 + torch.arange(k).view(1, k) * 7) % 61 - 30.0
+    c = ops.gemm_f16(a.half().cuda(), w.half().cuda())
+    assert torch.equal(c.float().cpu(), (a @ w.t()))
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 768), (384, 768, 3072), (25216, 2304, 768)])
+@pytest.mark.parametrize("variant", ["plain", "bias_qgelu", "bias_res", "gelu"])
+def test_gemm_matches_fp32(ops, m, n, k, variant):
+    if m > 1000 and variant != "bias_res":
+        pytest.skip("big shape once")
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).half().cuda()
+    bias = torch.randn(n, generator=g).cuda() if variant != "plain" else None
+    res = torch.randn(m, n, generator=g).half().cuda() if variant == "bias_res" else None
+    act = {"plain": 0, "bias_qgelu": 1, "bias_res": 0, "gelu": 2}[variant]
+    c = ops.gemm_f16(a, w, bias, res, act).float()
+    ref = a.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if act == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if res is not None:
+        ref = ref + res.float()
+    err = (c - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err     # fp16 output rounding
+
+
+# ----------------------------------------------------------------------------------------------- k-means pieces
+@pytest.mark.parametrize("n,d,k,seed", [(500, 8, 4, 1), (1500, 32, 10, 2), (3000, 768, 20, 3), (4097, 768, 100, 4),
+                                        (2000, 768, 200, 5)])
+def test_estep_bit_exact(ops, n, d, k, seed):
+    x, y, cent = synth.clustered_features(n, d, k, seed=seed, center_seed=seed + 50, noise=0.9)
+    rs = np.random.RandomState(seed)
+    c = (cent + 0.05 * rs.randn(k, d)).astype(np.float32)
+    data = ops.KMeansData(dev(x))
+    lab, ref = data.estep(dev(c), return_refined=True)
+    olab, omind, _ = ko.estep(x, c)
+    assert np.array_equal(lab.cpu().numpy().astype(np.int64), olab)
+    assert int(ref.item()) < n                                   # the filter did decide most rows
+    d2 = data.rowdist(dev(c), lab).cpu().numpy()
+    assert np.array_equal(d2, omind)                             # float32(float64 sum): bit-exact
+
+
+def test_estep_unstructured_data_takes_refine_path(ops):
+    # no cluster structure and near-duplicate centres: margins are tiny, the exact path must carry the result
+    rs = np.random.RandomState(0)
+    x = rs.randn(3000, 64).astype(np.float32) + 5.0
+    c = np.repeat(rs.randn(6, 64).astype(np.float32) + 5.0, 2, axis=0)
+    c[1::2] += 1e-6
+    c[3] = c[2]                                                   # exact duplicate: tie -> lowest index
+    data = ops.KMeansData(dev(x))
+    lab, ref = data.estep(dev(c), return_refined=True)
+    olab, _, _ = ko.estep(x, c)
+    assert np.array_equal(lab.cpu().numpy(), olab)
+    assert int(ref.item()) > 0 and 3 not in set(lab.cpu().numpy().tolist())
+
+
+def test_estep_nan_centre_never_wins(ops):
+    x, _, cent = synth.clustered_features(1000, 32, 5, seed=8)
+    c = cent.copy()
+    c[2] = np.nan                                                 # empty cluster after an M-step
+    lab = ops.KMeansData(dev(x)).estep(dev(c)).cpu().numpy()
+    olab, _, _ = ko.estep(x, c)
+    assert np.array_equal(lab, olab) and 2 not in set(lab.tolist())
+
+
+def test_dist_and_costs(ops):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kmeans_sskm.npz"))
+    a, b = g["pd_a"], g["pd_b"]
+    data = ops.KMeansData(dev(a))
+    d2 = data.dist(dev(b)).cpu().numpy()
+    assert np.array_equal(d2, ko.pairwise_distance(a, b))
+    assert np.allclose(d2, g["pd_batched"], rtol=2e-6, atol=1e-6)        # the reference's own output
+    ds, cost = data.dist(dev(b), sqrt=True, with_cost=True)
+    assert np.array_equal(cost.cpu().numpy(), to.int_costs(d2))
+    from scd_amd.local_utils.sskm_constrained import pairwise_distance
+    out = pairwise_distance(dev(a), dev(b), 100)
+    assert out.device.type == "cpu" and np.array_equal(out.numpy(), d2)   # CPU result when batched (:209)
+
+
+def test_mstep_finalize_and_inertia(ops):
+    x, y, cent = synth.clustered_features(5000, 768, 37, seed=9)
+    rs = np.random.RandomState(1)
+    labels = rs.randint(0, 37, size=5000).astype(np.int32)
+    labels[labels == 5] = 6                                       # cluster 5 empty -> NaN centre
+    sums, counts, inertia = ops.kmeans_mstep(dev(x), dev(labels), dev(cent), 37, 1234)
+    oc, ocnt = ko.mstep(x, labels, 37)
+    assert np.array_equal(counts.cpu().numpy(), ocnt)
+    c, shift = ops.kmeans_finalize(sums, counts, dev(cent))
+    cn = c.cpu().numpy()
+    assert np.isnan(cn[5]).all()
+    ok = ~np.isnan(oc)
+    assert np.array_equal(cn[ok], oc[ok])                         # float32(float64 sum / n): bit-exact
+    d = x.astype(np.float64) - cent[labels].astype(np.float64)
+    rowd = (d * d).sum(1)
+    ref = np.array([rowd[:1234].sum(), rowd[1234:].sum()])
+    assert np.allclose(inertia.cpu().numpy(), ref, rtol=1e-12)
+    assert np.isnan(shift.item())                                 # NaN centre => NaN shift (never "converged")
+    # linearity: the partial sums of two halves add up to the whole
+    s1, c1, _ = ops.kmeans_mstep(dev(x[:2500]), dev(labels[:2500]), None, 37, 0)
+    s2, c2, _ = ops.kmeans_mstep(dev(x[2500:]), dev(labels[2500:]), None, 37, 0)
+    assert torch.allclose(s1 + s2, sums, rtol=1e-13, atol=1e-13) and torch.equal(c1 + c2, counts)
+
+
+def test_kpp_draw_and_sum(ops):
+    rs = np.random.RandomState(3)
+    for n in (7, 1000, 95001):
+        d2 = (rs.rand(n) ** 3).astype(np.float32)
+        d2[rs.randint(0, n, size=max(1, n // 10))] = 0.0
+        t = dev(d2)
+        assert float(ops.sum_f32(t).item()) == pytest.approx(float(d2.astype(np.float64).sum()), rel=1e-14)
+        for r in (0.0, 1e-9, 0.25, 0.5, 0.999999, 1.0):
+            idx, _ = ops.kpp_draw(t, r)
+            assert int(idx.item()) == ko.kpp_draw(d2, r), (n, r)
+    # shard-aware form: two shards reproduce the single-device draw
+    d2 = rs.rand(5000).astype(np.float32)
+    tot = ops.sum_f32(dev(d2))
+    a, b = dev(d2[:2000]), dev(d2[2000:])
+    _, pa = ops.kpp_draw(a, 0.5, total=tot, want_idx=False, want_probsum=True)
+    for r in (0.1, 0.39, 0.41, 0.9):
+        ia, _ = ops.kpp_draw(a, r, total=tot)
+        ib, _ = ops.kpp_draw(b, r, total=tot, prefix=pa)
+        want = ko.kpp_draw(d2, r)
+        got = int(ia.item()) if int(ia.item()) >= 0 else 2000 + int(ib.item())
+        assert got == want
+
+
+def test_min_update_exact(ops):
+    x, _, _ = synth.clustered_features(3001, 768, 10, seed=12)
+    data = ops.KMeansData(dev(x))
+    d2 = torch.full((3001,), 1e30, device="cuda")
+    data.min_update(dev(x[17]), d2)
+    ref = ko.pairwise_distance64(x, x[17:18])[:, 0].astype(np.float32)
+    assert np.array_equal(d2.cpu().numpy(), ref) and d2[17].item() == 0.0
+
+
+# ----------------------------------------------------------------------------------------------- k-means end to end
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_sskm_matches_reference_golden(ops, golden, tag):
+    from scd_amd.gcd.methods.clustering.faster_mix_k_means_pytorch import K_Means
+    g = golden("kmeans_sskm.npz")
+    n, d, k, seed = g[tag + "_shape"].tolist()
+    x, y, mask_lab = synth.blob_case(n, d, k, seed)
+    u, l, lt = dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab])
+    km = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=3, random_state=seed, n_jobs=None,
+                 pairwise_batch_size=1024)
+    km.fit_mix(u, l, lt)
+    assert km.labels_.dtype == torch.int64 and km.labels_.is_cuda
+    assert np.array_equal(km.labels_.cpu().numpy(), g[tag + "_labels"])             # the reference's own labels
+    assert np.allclose(km.cluster_centers_.cpu().numpy(), g[tag + "_centers"], rtol=1e-5, atol=1e-6)
+    assert abs(float(km.inertia_) - float(g[tag + "_inertia"])) <= 1e-5 * float(g[tag + "_inertia"])
+    assert km.n_iter_ == int(g[tag + "_n_iter"])
+    # and bit-for-bit against the oracle (same float64 decision semantics)
+    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=seed)
+    okm.fit_mix(x[~mask_lab], x[mask_lab], y[mask_lab])
+    assert np.array_equal(km.labels_.cpu().numpy(), okm.labels_)
+    assert np.array_equal(km.cluster_centers_.cpu().numpy(), okm.cluster_centers_)
+    assert float(km.inertia_) == float(okm.inertia_)
+    km2 = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=2, random_state=seed + 1,
+                  pairwise_batch_size=512)
+    km2.fit(u)
+    assert np.array_equal(km2.labels_.cpu().numpy(), g[tag + "_fit_labels"])
+    assert abs(float(km2.inertia_) - float(g[tag + "_fit_inertia"])) <= 1e-5 * float(g[tag + "_fit_inertia"])
+
+
+def test_constrained_matches_reference_golden(ops, golden):
+    from scd_amd.local_utils.sskm_constrained import K_Means, _labels_constrained
+    g = golden("kmeans_constrained.npz")
+    n, d, k, seed = g["m_shape"].tolist()
+    x, y, mask_lab = synth.blob_case(n, d, k, seed)
+    km = K_Means(k=k, tolerance=1e-4, max_iterations=5, init="k-means++", size_min=30, size_max=80, n_init=2,
+                 random_state=5, n_jobs=None, pairwise_batch_size=128)
+    km.fit_mix(dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab]))
+    lab = km.labels_.cpu().numpy()
+    cnt = np.bincount(lab[mask_lab.sum():], minlength=k)
+    assert cnt.min() >= 30 and cnt.max() <= 80
+    assert abs(float(km.inertia_) - float(g["m_inertia"])) <= 1e-3 * float(g["m_inertia"])
+    assert (lab != g["m_labels"]).mean() < 0.02                   # flow optimum is not unique under cost ties
+    # the 6-point docstring example of the vendored estimator (k_means_constrained_.py:777-793)
+    km6 = K_Means(k=2, size_min=2, size_max=5, random_state=0, n_init=10, max_iterations=100)
+    km6.fit(dev(g["kat_x"]))
+    assert np.array_equal(km6.labels_.cpu().numpy(), g["kat_labels"])
+    # raw assignment: optimal total cost equals the reference run's
+    dist = np.zeros(g["a_d2"].shape[0], dtype=np.float32)
+    lab2, inertia = _labels_constrained(None, None, np.sqrt(g["a_d2"]), 30, 80, dist)
+    cost = to.int_costs(g["a_d2"])
+    assert int(cost[np.arange(len(lab2)), lab2].sum()) == int(g["a_total"])
+    with pytest.raises(Exception, match="min cost flow"):
+        _labels_constrained(None, None, np.ones((5, 2), dtype=np.float32), 3, 5, np.zeros(5, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------------------------- similarity / vote
+def test_sim_topk_golden_and_oracle(ops, golden):
+    g = golden("naming.npz")
+    f, w = g["tk_x"].astype(np.float16), g["tk_w"].astype(np.float16)
+    wt = ops.transpose_f16(dev(w))
+    assert torch.equal(wt.cpu(), torch.from_numpy(w).t())
+    for mode in ("softmax", "raw"):
+        idx, val = ops.sim_topk(dev(f), wt, 5, mode)
+        oi, ov = no.sim_topk(f, w, 5, mode)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.allclose(val.cpu().numpy(), ov, rtol=2e-4, atol=1e-6)
+    # fp32 features of the golden run rounded to fp16 still give the reference's own top-1 nearly everywhere
+    idx, _ = ops.sim_topk(dev(f), wt, 5, "raw")
+    assert (idx[:, 0].cpu().numpy() == g["tk_idx_ptsup"][:, 0]).mean() > 0.99
+
+
+@pytest.mark.parametrize("n,v,d,k", [(300, 21000, 512, 5), (129, 1000, 512, 3), (1000, 100, 512, 1), (64, 37, 64, 8)])
+def test_sim_topk_shapes(ops, n, v, d, k):
+    rs = np.random.RandomState(n + v)
+    f = (rs.randn(n, d) / np.sqrt(d)).astype(np.float16)
+    w = (rs.randn(d, v) / np.sqrt(d)).astype(np.float16)
+    w[:, 5] = w[:, 3]                                             # duplicate names: exact ties -> lower index first
+    wt = ops.transpose_f16(dev(w))
+    idx, val, fb = ops.sim_topk(dev(f), wt, k, "raw", return_fallback=True)
+    oi, ov = no.sim_topk(f, w, k, "raw")
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.allclose(val.cpu().numpy(), ov, rtol=1e-6, atol=1e-5)
+    assert int(fb.item()) <= n // 20
+    a, av = ops.sim_argmax(dev(f), wt)
+    assert np.array_equal(a.cpu().numpy(), oi[:, 0])
+
+
+def test_l2norm_and_gather(ops):
+    rs = np.random.RandomState(1)
+    x = rs.randn(77, 512).astype(np.float32) * 3
+    out = ops.l2norm_rows(dev(x)).cpu().numpy()
+    assert np.allclose(out, x / np.linalg.norm(x, axis=1, keepdims=True), atol=1e-6)
+    xh = dev(x).half()
+    outh = ops.l2norm_rows(xh).float().cpu().numpy()
+    assert np.allclose(np.linalg.norm(outh, axis=1), 1.0, atol=2e-3)
+    wt = dev(rs.randn(300, 512).astype(np.float16))
+    idx = dev(np.array([5, 0, 299, 5]))
+    assert torch.equal(ops.gather_rows_f16(wt, idx), wt[idx])
+
+
+def test_vote_hist_matches_counter(ops):
+    rs = np.random.RandomState(2)
+    n, k, v = 20000, 23, 500
+    preds = rs.randint(0, k + 3, size=n)                          # some rows belong to clusters we do not ask for
+    names = (rs.zipf(1.5, size=(n, 5)) % v).astype(np.int64)
+    clusters = [c for c in range(k) if c % 5 != 4]
+    known = [0, 1, 7]
+    for kn, top_k, m in ((None, 5, 20), (known, 3, 4)):
+        keys, counts = ops.vote_hist(dev(names), top_k, dev(preds), clusters, m, kn)
+        keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
+        ref = no.cluster_counters(names, preds, clusters, top_k, known=kn)
+        for i, c in enumerate(clusters):
+            mc = ref[c].most_common(m)
+            got = [(int(a), int(b)) for a, b in zip(keys[i], counts[i]) if a >= 0]
+            assert got == [(int(a), int(b)) for a, b in mc], c
+
+
+def test_vote_loops_match_reference_traces(ops, golden):
+    from scd_amd import naming
+    g = golden("naming.npz")
+    f, w = g["tk_x"], g["tk_w"]
+    nouns = synth.nouns_list(w.shape[1])
+    wt = ops.transpose_f16(dev(w.astype(np.float16)))
+    fh = dev(f.astype(np.float16))
+    # inputs rounded to fp16 (the dtype the GPU path stores): replay the oracle on the same rounded inputs ...
+    k, topk, ncv, ncl = g["vu_cfg"].tolist()
+    idx, _ = naming.full_vocab_topk(fh, None, 5, True, wt=wt)
+    oidx, _ = no.sim_topk(f.astype(np.float16), w.astype(np.float16), 5, "softmax")
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    cand, up, tr = naming.vote_loop_unsup(idx, g["vu_preds0"], fh, wt, nouns, k, ncv, ncl)
+    otr = no.vote_loop_unsup(oidx, g["vu_preds0"], f.astype(np.float16), w.astype(np.float16), nouns, k, topk, ncv, ncl)
+    assert len(tr) == len(otr)
+    for a, b in zip(tr, otr):
+        for key in ("voted", "ind", "cand", "u_preds"):
+            assert np.array_equal(a[key], b[key]), key
+    # ... and the reference's own trace (fp32 inputs) has the same names at convergence
+    last = int(g["vu_iters"]) - 1
+    assert set(tr[-1]["cand"].tolist()) == set(g["vu_cand_%d" % last].tolist())
+    assert (tr[-1]["u_preds"] == g["vu_preds_%d" % last]).mean() > 0.995
+
+
+# ----------------------------------------------------------------------------------------------- encoders
+def _cos(a, b):
+    a, b = a.double(), b.double()
+    return torch.nn.functional.cosine_similarity(a, b, dim=-1)
+
+
+@pytest.mark.parametrize("layers", [2, 12])
+def test_clip_towers_match_oracle(ops, layers):
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=layers, t_layers=layers))
+    sd16 = {k: (v.half().float() if v.dim() >= 2 and "positional" not in k and "class_emb" not in k else v) for k, v in sd.items()}
+    model = CLIP(sd).cuda().eval()
+    img = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(78))
+    out = model.encode_image(img.cuda()).float().cpu()
+    ref = co.clip_encode_image(sd16, img.half().float())
+    assert out.shape == (5, 512)
+    assert _cos(out, ref).min().item() > 1 - 1e-3                 # north-star tolerance: cosine within 1e-3 (fp16)
+    assert (out - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    tok = torch.zeros(4, 77, dtype=torch.int32)
+    g = torch.Generator().manual_seed(79)
+    for i, ln in enumerate((3, 8, 20, 75)):
+        tok[i, 0] = 49406
+        tok[i, 1:1 + ln] = torch.randint(1, 49405, (ln,), generator=g, dtype=torch.int32)
+        tok[i, 1 + ln] = 49407
+    tout = model.encode_text(tok.cuda()).float().cpu()
+    tref = co.clip_encode_text(sd16, tok.long())
+    assert _cos(tout, tref).min().item() > 1 - 1e-3
+
+
+def test_dino_tower_matches_oracle(ops):
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import DinoViT
+    sd = W.synthetic_dino_state_dict(seed=1, layers=12)
+    sd16 = {k: (v.half().float() if v.dim() >= 2 and "pos_embed" not in k and "cls_token" not in k else v) for k, v in sd.items()}
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(77))
+    out = DinoViT(sd).cuda()(img.cuda()).cpu()
+    ref = co.dino_forward(sd16, img.half().float())
+    assert out.shape == (3, 768) and _cos(out, ref).min().item() > 1 - 1e-3
+
+
+def test_zeroshot_classifier_pooling(ops):
+    from scd_amd.local_utils import clip_lang_util as clu
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    import scd_amd.clip as clip
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(t_layers=2), visual=False)
+    model = CLIP(sd).cuda()
+    names = ["red_fox", "tabby", "kit_fox", "zebra", "grey_whale"]
+    tmpl = clu.imagenet_templates[:9]
+    zs = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=2)
+    assert zs.shape == (512, 5) and zs.dtype == torch.float16
+    sd16 = {k: (v.half().float() if v.dim() >= 2 and "positional" not in k else v) for k, v in sd.items()}
+    ref = no.zeroshot_classifier(names, tmpl, lambda t: co.clip_encode_text(sd16, t.long()).numpy(), clip.tokenize)
+    assert _cos(zs.float().cpu().t(), torch.from_numpy(ref).t()).min().item() > 1 - 1e-3
+    assert np.allclose(np.linalg.norm(zs.float().cpu().numpy(), axis=0), 1.0, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_estep_mstep_properties(ops):
+    """BASELINE C2 size (N_u=95k, D=768, K=100): size-independent properties instead of a CPU all-pairs oracle."""
+    n, d, k = 95000, 768, 100
+    x, y, cent = synth.clustered_features(n, d, k, seed=21, center_seed=22, noise=0.8)
+    data = ops.KMeansData(dev(x))
+    c = dev(cent)
+    lab, ref = data.estep(c, return_refined=True)
+    lab_np = lab.cpu().numpy()
+    assert (lab_np == y).mean() > 0.99                           # recovers the planted partition
+    assert int(ref.item()) < n // 10
+    # spot-check 512 rows against the float64 oracle
+    rs = np.random.RandomState(0)
+    rows = rs.choice(n, 512, replace=False)
+    olab, omind, _ = ko.estep(x[rows], cent)
+    assert np.array_equal(lab_np[rows], olab)
+    d2 = data.rowdist(c, lab)
+    assert np.array_equal(d2.cpu().numpy()[rows], omind)
+    # idempotence: M-step then E-step on converged data keeps the labels; sums add up to the column totals
+    sums, counts, inertia = ops.kmeans_mstep(data.x, lab, c, k, 0)
+    assert int(counts.sum().item()) == n
+    col = x.astype(np.float64).sum(0)
+    assert np.allclose(sums.sum(0).cpu().numpy(), col, rtol=1e-12, atol=1e-9)
+    assert float(inertia[1].item()) == pytest.approx(float(ops.sum_f32(d2).item()), rel=1e-6)
+    c2, shift = ops.kmeans_finalize(sums, counts, c)
+    lab2 = data.estep(c2)
+    assert (lab2 == lab).float().mean().item() > 0.999
