@@ -328,7 +328,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
                             size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && F && Wt && idx_out && val_out && ws, "scd_sim_topk: null argument");
     SCD_REQUIRE(n > 0 && v > 0 && n < (1ll << 31) && v < (1ll << 31), "scd_sim_topk: bad shape n=%lld v=%lld", (long long)n, (long long)v);
-    SCD_REQUIRE(d > 0 && d <= 512 && d % 8 == 0, "scd_sim_topk: d=%d must be a multiple of 8, <= 512", d);
+    SCD_REQUIRE(d > 0 && d <= 512 && d % 16 == 0, "scd_sim_topk: d=%d must be a multiple of 16, <= 512", d);
     SCD_REQUIRE(k >= 1 && k <= TOPM && k <= v, "scd_sim_topk: k=%d must be in [1,%d] and <= v", k, TOPM);
     SCD_REQUIRE(mode == SCD_SIM_RAW || mode == SCD_SIM_SOFTMAX, "scd_sim_topk: bad mode %d", mode);
     SCD_REQUIRE(ws_bytes >= scd_sim_topk_ws_bytes(n, d, v, k), "scd_sim_topk: workspace too small");
