@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py - images/sec of the SCD embedding-and-naming hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1], "ImageNet-100 unsupervised, CLIP ViT-B/16 encode + 21k WordNet vocab"):
+per GPU 126,976 synthetic 224x224 images (already resident in HBM, fp16), K=100 classes, V=21,000 names;
+one step = CLIP ViT-B/16 encode + L2-norm -> full-vocab similarity + top-k -> semi-supervised K-Means
+(k=100, max_iterations=10, n_init=10: the reference's call-site values, main_unsup.py:350) -> vote loop to
+convergence (topk/num_common_vote/num_common_linear = 3/10/2, scripts/evaluate_unsupervised.sh).
+Weak scaling: per-GPU images are fixed; `value` = images of all ranks / max-over-ranks step time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fc1 GEMM of the ViT blocks, MFMA-bound,
+timed live with HIP events) and `cpu_baseline` (the oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMAGES_PER_GPU = 126976
+N_CLASSES = 100
+VOCAB = 21000
+PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_IMAGE = 2 * 17563453440        # CLIP ViT-B/16 visual tower
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--images", type=int, default=IMAGES_PER_GPU, help="images per GPU (default = BASELINE config)")
+    p.add_argument("--batch", type=int, default=512)
+    p.add_argument("--vocab", type=int, default=VOCAB)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(seed=0):
+    """The oracle ('port') timed on the host cores on a bounded sample of the same workload; composed per stage
+    because an end-to-end CPU pass over 127k images would take hours."""
+    import ctypes as C
+    from oracle import clip_oracle as co
+    from scd_amd.clip import weights as W
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t_budget = time.time()
+    # (i) encode: 8 images through the fp32 torch restatement
+    sd = W.synthetic_clip_state_dict(seed=0, text=False)
+    img = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    co.clip_encode_image(sd, img[:2])
+    t0 = time.time()
+    co.clip_encode_image(sd, img)
+    enc_ips = 8 / (time.time() - t0)
+    # (ii)+(iii): C restatement (OpenMP) of sim+top-k and of one Lloyd iteration
+    so = os.path.join(ROOT, "oracle", "c", "liboracle.so")
+    lib = C.CDLL(so)
+    rs = np.random.RandomState(seed)
+    n_s, d, v = 256, 512, VOCAB
+    f = (rs.randn(n_s, d) / np.sqrt(d)).astype(np.float32)
+    wt = (rs.randn(v, d) / np.sqrt(d)).astype(np.float32)
+    idx = np.zeros((n_s, 5), dtype=np.int64)
+    val = np.zeros((n_s, 5), dtype=np.float32)
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    t0 = time.time()
+    lib.oracle_sim_topk(P(f), P(wt), C.c_int64(n_s), d, C.c_int64(v), C.c_double(100.0), 5, P(idx), P(val))
+    sim_ips = n_s / (time.time() - t0)
+    n_k, k = 8192, N_CLASSES
+    x = rs.randn(n_k, d).astype(np.float32)
+    c = rs.randn(k, d).astype(np.float32)
+    lab = np.zeros(n_k, dtype=np.int64)
+    mind = np.zeros(n_k, dtype=np.float32)
+    t0 = time.time()
+    lib.oracle_estep(P(x), P(c), C.c_int64(n_k), d, k, P(lab), P(mind))
+    lib.oracle_mstep(P(x), P(lab), C.c_int64(n_k), d, k, P(c))
+    it_s = time.time() - t0
+    # 10 restarts x (10 Lloyd iterations + ~50 k-means++ sweeps of one centre each ~ 0.5 iteration-equivalents)
+    km_ips = n_k / (it_s * 10 * (10 + 0.5))
+    total = 1.0 / (1.0 / enc_ips + 1.0 / sim_ips + 1.0 / km_ips)
+    return {"value": round(total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "oracle on host: encode 8 imgs (torch fp32, %.2f img/s); sim+top-5 256 rows x V=21000 (C/OpenMP, %.0f img/s); "
+                      "1 Lloyd iter 8192x100x512 (C/OpenMP) scaled to 10 restarts x 10 iters (%.0f img/s); harmonic composition; "
+                      "%.0f s of CPU work" % (enc_ips, sim_ips, km_ips, time.time() - t_budget)}
+
+
+def dominant_kernel_roofline(model, batch):
+    """fc1 GEMM of the ViT blocks (gemm_f16_kernel<QuickGELU,bias,no-residual>): [B*197,768] x [3072,768]^T.
+    Timed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
+    from scd_amd import ops
+    enc = model.visual.enc
+    bp = (batch + 127) // 128 * 128
+    m, n, k = bp * 197, 3072, 768
+    a = (torch.randn(m, k, device="cuda") * 0.5).half()
+    w = enc.weights[9 + 8]           # layer 0 fc1 weight [3072,768]
+    b = enc.weights[9 + 9]
+    for _ in range(3):
+        ops.gemm_f16(a, w, b, None, 1)
+    iters = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm_f16(a, w, b, None, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    tf = 2.0 * m * n * k / sec / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_f16_kernel<QuickGELU,bias> fc1 m=%d n=%d k=%d" % (m, n, k), "avg_launch_us": round(sec * 1e6, 1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        group = dist.group.WORLD
+    dev = torch.device("cuda", local_rank)
+
+    import scd_amd.clip as clip
+    from scd_amd import pipeline
+    model, _ = clip.load("ViT-B/16", device="cuda")
+    images, y, base = pipeline.synthetic_images(args.images, N_CLASSES, seed=rank, device=dev)
+    wt, nouns = pipeline.synthetic_vocab(model, base, args.vocab, 0, dev)
+    mask_lab = pipeline.labelled_split(y, N_CLASSES, seed=5 + rank)
+    l_targets = y[torch.as_tensor(mask_lab, device=dev)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stage_ms = {}
+
+    def step(i, timed):
+        timers = [] if timed else None
+        out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, N_CLASSES, topk=3, num_common_vote=10,
+                           num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers)
+        if timed:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(timers[:-1], timers[1:]):
+                stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+    for i in range(args.warmup):
+        out = step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(100 + i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    # quality of the synthetic run (not part of the metric): cluster purity and names found
+    yn = y.cpu().numpy()
+    u_true = yn[~mask_lab]
+    name_hits = float(np.mean(np.array([int(n.split("_")[1]) for n in out["cand_names"]])[out["u_preds"]] == u_true))
+
+    if rank == 0:
+        total_images = args.images * world * args.steps
+        value = total_images / dt
+        roof = dominant_kernel_roofline(model, args.batch)
+        enc_s = stage_ms.get("encode", 0.0) / 1e3 / args.steps
+        line = {
+            "metric": "images/sec end-to-end (encode+sim+k-means) on 224^2 synth, 21k vocab",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "ImageNet-100 unsupervised (BASELINE configs[1]): CLIP ViT-B/16 encode + V=%d vocab + SSKM k=100 "
+                                   "(10 restarts x 10 iters) + vote loop" % args.vocab,
+                       "images_per_gpu": args.images, "vocab": args.vocab, "n_cluster": N_CLASSES, "encode_batch": args.batch,
+                       "weights": "random-init (seeded), no checkpoint offline", "parallelism": "dp%d" % world},
+            "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
+            "encode_tflops": round(args.images * FLOP_PER_IMAGE / max(enc_s, 1e-9) / 1e12, 1),
+            "vote_iters": out["vote_iters"], "synthetic_name_accuracy": round(name_hits, 4),
+            "roofline": roof,
+        }
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

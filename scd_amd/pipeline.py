@@ -1,0 +1,139 @@
+"""End-to-end hot path (encode -> L2-norm -> full-vocab sim+top-k -> semi-supervised K-Means -> vote loop), i.e. the
+stage order of /root/reference/main_unsup.py:298-641 with the I/O and eval prints removed.  Used by bench.py,
+__graft_entry__.smoke() and main_unsup.py --synthetic.  Everything numeric is a libscd_hip.so call.
+
+Multi-GPU: images (and their features) are sharded over ranks; W is replicated; K-Means exchanges one packed
+all-reduce per Lloyd iteration; the vote gathers the (tiny) top-k index table so that every rank computes the same
+global histogram and Munkres assignment, then re-classifies its own shard.
+"""
+import numpy as np
+import torch
+
+from . import naming, ops
+from .gcd.methods.clustering.faster_mix_k_means_pytorch import K_Means as SemiSupKMeans
+
+
+def encode_images(model, images, batch, out=None):
+    """extract_feature (main_unsup.py:114-147) without the host round trips: encode + F.normalize, features stay in HBM."""
+    n = images.shape[0]
+    if out is None:
+        out = torch.empty((n, model.visual.output_dim), dtype=torch.float16, device=images.device)
+    enc = model.visual.enc
+    for s in range(0, n, batch):
+        out[s:s + batch] = enc.encode_image(images[s:s + batch], normalize=True)
+    return out
+
+
+def _allgather_rows(t, group):
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    lens = [torch.empty(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+    dist.all_gather(lens, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
+    lens = [int(x) for x in lens]
+    mx = max(lens)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    outs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:l] for o, l in zip(outs, lens)]), lens
+
+
+def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2,
+        batch=512, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None):
+    """One pass over `images` (this rank's shard).  Returns dict(feats, labels, cand_names, u_preds, name_idx)."""
+    def mark(name):
+        if timers is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            timers.append((name, ev))
+    mark("start")
+    feats = encode_images(model, images, batch)
+    mark("encode")
+    name_idx, name_val = naming.full_vocab_topk(feats, None, topk, True, wt=wt)
+    mark("sim_topk")
+    mask = torch.as_tensor(mask_lab, device=feats.device)
+    f32 = feats.float()
+    u_feats, l_feats = f32[~mask], f32[mask]
+    km = SemiSupKMeans(k=n_cluster, tolerance=1e-4, max_iterations=kmeans_iters, init='k-means++', n_init=n_init,
+                       random_state=seed, n_jobs=None, pairwise_batch_size=1024, mode=None, group=group)
+    km.fit_mix(u_feats, l_feats, torch.as_tensor(l_targets, device=feats.device))
+    mark("kmeans")
+    u_preds = km.labels_[l_feats.shape[0]:]
+    nidx_u = name_idx[~mask]
+    fu = feats[~mask]
+    if group is None:
+        cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote,
+                                                    num_common_linear, max_iter=50)
+    else:
+        cand, preds, trace = vote_loop_unsup_sharded(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote,
+                                                     num_common_linear, group, max_iter=50)
+    mark("vote")
+    return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace),
+                kmeans=km)
+
+
+def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50):
+    """main_unsup.py:568-614 over row shards: the histogram is global (rows in (rank, row) = global order), so every
+    rank votes on the gathered int tables and re-classifies only its own rows."""
+    import copy
+    from .local_utils.clip_lang_util import assign_name
+    g_idx, lens = _allgather_rows(name_idx, group)
+    first = {}
+    for j, n in enumerate(nouns):
+        first.setdefault(n, j)
+    top_k = min(5, name_idx.shape[1])
+    m = max(ncv, ncl)
+    cur, prev, cand, trace = [0], [1], list(nouns), []
+    u_preds = u_preds.to(torch.int64)
+    while set(cur) != set(prev) and len(trace) < max_iter:
+        g_preds, _ = _allgather_rows(u_preds, group)
+        clusters = list(set(g_preds.cpu().numpy().tolist()))
+        c2c = naming.cluster_counters(g_idx, top_k, g_preds, clusters, m)
+        voted = []
+        for i in clusters:
+            voted += [c[0] for c in c2c[i].most_common(ncv)]
+        voted = list(set(voted))
+        ind, w = assign_name(voted, c2c, num_common=ncl)
+        prev = copy.deepcopy(cur)
+        cur = [nouns[voted[x[1]]] for x in ind[:n_cluster]]
+        cand = copy.deepcopy(cur)
+        cols = torch.tensor([first[n] for n in cand], dtype=torch.int64, device=name_idx.device)
+        u_preds, _ = ops.sim_argmax(f_u, ops.gather_rows_f16(wt, cols))
+        trace.append(dict(cand=cols.cpu().numpy()))
+    return cand, u_preds.cpu().numpy(), trace
+
+
+# ----------------------------------------------------------------------------- synthetic workload
+def synthetic_images(n, n_classes, seed, device, noise=0.35, chunk=4096, dtype=torch.float16):
+    """'Preprocessed' 224x224 images with class structure: img = base[y] + noise*randn (N(0,1)-scaled, so CLIP's
+    mean/std normalisation is already applied).  Returns (images [n,3,224,224] in HBM, y int64 [n])."""
+    g = torch.Generator(device=device).manual_seed(1234 + seed)
+    gb = torch.Generator(device=device).manual_seed(4321)
+    base = torch.randn(n_classes, 3, 224, 224, generator=gb, device=device, dtype=torch.float32)
+    y = torch.randint(0, n_classes, (n,), generator=g, device=device)
+    imgs = torch.empty((n, 3, 224, 224), dtype=dtype, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        z = torch.randn(e - s, 3, 224, 224, generator=g, device=device, dtype=torch.float32)
+        imgs[s:e] = (base[y[s:e]] + noise * z).to(dtype)
+    return imgs, y, base
+
+
+def synthetic_vocab(model, base, v, seed, device, jitter=0.05):
+    """W^T [v,512] fp16: row c < K is the (jittered) CLIP feature of class c's base image (the 'true' name), the rest
+    are random unit vectors.  Returns (wt, nouns)."""
+    protos = model.visual.enc.encode_image(base.to(torch.float16), normalize=True).float()
+    g = torch.Generator(device=device).manual_seed(7 + seed)
+    w = torch.randn(v, protos.shape[1], generator=g, device=device)
+    k = protos.shape[0]
+    w[:k] = protos + jitter * torch.randn(k, protos.shape[1], generator=g, device=device) / protos.shape[1] ** 0.5
+    wt = ops.l2norm_rows(w.contiguous()).to(torch.float16).contiguous()
+    return wt, ["name_%05d" % i for i in range(v)]
+
+
+def labelled_split(y, n_classes, prop=0.5, seed=5):
+    """Classes < K/2 are 'old' and `prop` of their rows are labelled (get_datasets.py:144-145).  Rows are NOT
+    re-ordered: a boolean mask plays the role of the reference's labelled-first ordering."""
+    r = np.random.RandomState(seed)
+    yn = y.cpu().numpy()
+    return (yn < n_classes // 2) & (r.rand(len(yn)) < prop)
