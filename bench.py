@@ -52,15 +52,15 @@ def cpu_baseline(seed=0):
     from oracle import clip_oracle as co
     from scd_amd.clip import weights as W
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(cores, 32))
     t_budget = time.time()
     # (i) encode: 8 images through the fp32 torch restatement
     sd = W.synthetic_clip_state_dict(seed=0, text=False)
-    img = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    img = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(1))
     co.clip_encode_image(sd, img[:2])
     t0 = time.time()
     co.clip_encode_image(sd, img)
-    enc_ips = 8 / (time.time() - t0)
+    enc_ips = 4 / (time.time() - t0)
     # (ii)+(iii): C restatement (OpenMP) of sim+top-k and of one Lloyd iteration
     so = os.path.join(ROOT, "oracle", "c", "liboracle.so")
     lib = C.CDLL(so)
@@ -87,7 +87,7 @@ def cpu_baseline(seed=0):
     km_ips = n_k / (it_s * 10 * (10 + 0.5))
     total = 1.0 / (1.0 / enc_ips + 1.0 / sim_ips + 1.0 / km_ips)
     return {"value": round(total, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "oracle on host: encode 8 imgs (torch fp32, %.2f img/s); sim+top-5 256 rows x V=21000 (C/OpenMP, %.0f img/s); "
+            "sample": "oracle on host: encode 4 imgs (torch fp32, %.2f img/s); sim+top-5 256 rows x V=21000 (C/OpenMP, %.0f img/s); "
                       "1 Lloyd iter 8192x100x512 (C/OpenMP) scaled to 10 restarts x 10 iters (%.0f img/s); harmonic composition; "
                       "%.0f s of CPU work" % (enc_ips, sim_ips, km_ips, time.time() - t_budget)}
 

@@ -45,60 +45,55 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const half_t* __restrict_
     // staging: thread -> (row = p*32 + tid/8, chunk = tid%8), 4 passes per operand
     const int srow = tid >> 3, schunk = tid & 7;
 
-    uint4 ra[4], rw[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ra[p] = *(const uint4*)(Ab + (size_t)(p * 32 + srow) * K + 8 * schunk);
-        rw[p] = *(const uint4*)(Wb + (size_t)(p * 32 + srow) * K + 8 * schunk);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        *(uint4*)(lds[0][0] + lds_off(p * 32 + srow, schunk)) = ra[p];
-        *(uint4*)(lds[0][1] + lds_off(p * 32 + srow, schunk)) = rw[p];
-    }
+    const half_t* ga = Ab + (size_t)srow * K + 8 * schunk;     // + p*32*K + k0
+    const half_t* gw = Wb + (size_t)srow * K + 8 * schunk;
+    const size_t pstride = (size_t)32 * K;
+    uint4 ra0 = *(const uint4*)(ga), ra1 = *(const uint4*)(ga + pstride), ra2 = *(const uint4*)(ga + 2 * pstride),
+          ra3 = *(const uint4*)(ga + 3 * pstride);
+    uint4 rw0 = *(const uint4*)(gw), rw1 = *(const uint4*)(gw + pstride), rw2 = *(const uint4*)(gw + 2 * pstride),
+          rw3 = *(const uint4*)(gw + 3 * pstride);
+    const int so0 = lds_off(srow, schunk), so1 = lds_off(32 + srow, schunk), so2 = lds_off(64 + srow, schunk),
+              so3 = lds_off(96 + srow, schunk);
+    *(uint4*)(lds[0][0] + so0) = ra0; *(uint4*)(lds[0][0] + so1) = ra1;
+    *(uint4*)(lds[0][0] + so2) = ra2; *(uint4*)(lds[0][0] + so3) = ra3;
+    *(uint4*)(lds[0][1] + so0) = rw0; *(uint4*)(lds[0][1] + so1) = rw1;
+    *(uint4*)(lds[0][1] + so2) = rw2; *(uint4*)(lds[0][1] + so3) = rw3;
     __syncthreads();
 
-    f32x16 acc[2][2];
+    f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc00[i] = 0.f; acc01[i] = 0.f; acc10[i] = 0.f; acc11[i] = 0.f; }
 
     const int nk = K >> 6;
+    const int ow0 = wn * 64 + r, ow1 = wn * 64 + 32 + r, oa0 = wm * 64 + r, oa1 = wm * 64 + 32 + r;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k0 = (kt + 1) << 6;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = *(const uint4*)(Ab + (size_t)(p * 32 + srow) * K + k0 + 8 * schunk);
-                rw[p] = *(const uint4*)(Wb + (size_t)(p * 32 + srow) * K + k0 + 8 * schunk);
-            }
-        }
+        // prefetch the next k-tile into registers (the last iteration re-reads its own tile: harmless)
+        const int k0 = (kt + 1 < nk ? kt + 1 : kt) << 6;
+        ra0 = *(const uint4*)(ga + k0); ra1 = *(const uint4*)(ga + pstride + k0);
+        ra2 = *(const uint4*)(ga + 2 * pstride + k0); ra3 = *(const uint4*)(ga + 3 * pstride + k0);
+        rw0 = *(const uint4*)(gw + k0); rw1 = *(const uint4*)(gw + pstride + k0);
+        rw2 = *(const uint4*)(gw + 2 * pstride + k0); rw3 = *(const uint4*)(gw + 3 * pstride + k0);
         const char* la = lds[cur][0];
         const char* lw = lds[cur][1];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const half8 fw0 = *(const half8*)(lw + lds_off(wn * 64 + r, 2 * s + hh));
-            const half8 fw1 = *(const half8*)(lw + lds_off(wn * 64 + 32 + r, 2 * s + hh));
-            const half8 fa0 = *(const half8*)(la + lds_off(wm * 64 + r, 2 * s + hh));
-            const half8 fa1 = *(const half8*)(la + lds_off(wm * 64 + 32 + r, 2 * s + hh));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fa0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fa1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fa0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fa1, acc[1][1], 0, 0, 0);
+            const half8 fw0 = *(const half8*)(lw + lds_off(ow0, 2 * s + hh));
+            const half8 fw1 = *(const half8*)(lw + lds_off(ow1, 2 * s + hh));
+            const half8 fa0 = *(const half8*)(la + lds_off(oa0, 2 * s + hh));
+            const half8 fa1 = *(const half8*)(la + lds_off(oa1, 2 * s + hh));
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fa0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fa1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fa0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fa1, acc11, 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *(uint4*)(lds[cur ^ 1][0] + lds_off(p * 32 + srow, schunk)) = ra[p];
-                *(uint4*)(lds[cur ^ 1][1] + lds_off(p * 32 + srow, schunk)) = rw[p];
-            }
-        }
+        char* na = lds[cur ^ 1][0];
+        char* nw = lds[cur ^ 1][1];
+        *(uint4*)(na + so0) = ra0; *(uint4*)(na + so1) = ra1; *(uint4*)(na + so2) = ra2; *(uint4*)(na + so3) = ra3;
+        *(uint4*)(nw + so0) = rw0; *(uint4*)(nw + so1) = rw1; *(uint4*)(nw + so2) = rw2; *(uint4*)(nw + so3) = rw3;
         __syncthreads();
     }
+    f32x16 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
 
     // epilogue: lane holds, for m = col r, the n-quads 8g+4h .. +3 of each 32x32 tile
 #pragma unroll
