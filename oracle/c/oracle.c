@@ -13,6 +13,17 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 void oracle_estep(const float* x, const float* c, int64_t n, int d, int k, int64_t* labels, float* mind) {
 #pragma omp parallel for schedule(static)
