@@ -84,6 +84,15 @@ class _Dist:
         self.d.all_gather(out, t, group=self.group)
         return torch.stack(out)
 
+    def allgather_cat(self, t):
+        """Concatenate variable-length first dimensions in rank order; returns (cat, lens)."""
+        lens = self.allgather(torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)).reshape(-1).tolist()
+        mx = max(max(lens), 1)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        allp = self.allgather(pad)
+        return torch.cat([allp[r, : lens[r]] for r in range(self.world)]), lens
+
     def broadcast_(self, t, src):
         self.d.broadcast(t, src=self.d.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
         return t
@@ -120,6 +129,9 @@ class KMeansEngine:
     def _class_means(self, l, l_targets):
         """l_centers = per-class mean in torch.unique order (sskm_constrained.py:88-96)."""
         classes = torch.unique(l_targets)
+        dd0 = self._dist()
+        if dd0:
+            classes = torch.unique(dd0.allgather_cat(classes)[0])
         rank = torch.searchsorted(classes, l_targets).to(torch.int32)
         sums, counts, _ = self._be().mstep(l, rank.contiguous(), None, int(classes.numel()), 0)
         dd = self._dist()

@@ -1,0 +1,77 @@
+"""TEST-ONLY compute backend for scd_amd.kmeans.KMeansEngine built on the numpy oracle, so that the multi-process
+collective logic (all-reduce of centroid partials, shard-aware k-means++ draws, gathered constrained E-step) can be
+exercised with gloo on CPU.  The product never uses this: its only backend is scd_amd.ops (HIP)."""
+import numpy as np
+import torch
+
+from oracle import kmeans_oracle as ko
+from oracle import transport_oracle as to
+
+
+class _Data:
+    def __init__(self, x):
+        self.x = x.to(torch.float32).contiguous()
+        self.n, self.d = self.x.shape
+
+
+class OracleBackend:
+    def prepare(self, x):
+        return _Data(x)
+
+    def estep(self, data, centers):
+        lab, _, _ = ko.estep(data.x.numpy(), centers.numpy())
+        return torch.from_numpy(lab.astype(np.int32))
+
+    def rowdist(self, data, centers, labels):
+        d = ko.pairwise_distance64(data.x.numpy(), centers.numpy())
+        return torch.from_numpy(d[np.arange(d.shape[0]), labels.numpy()].astype(np.float32))
+
+    def min_update(self, data, c_new, d2):
+        d = ko.pairwise_distance64(data.x.numpy(), c_new.numpy().reshape(1, -1))[:, 0].astype(np.float32)
+        d2.copy_(torch.minimum(d2, torch.from_numpy(d)))
+
+    def dist(self, data, centers, sqrt=False, with_cost=False):
+        d2 = ko.pairwise_distance(data.x.numpy(), centers.numpy())
+        out = np.sqrt(d2).astype(np.float32) if sqrt else d2
+        if with_cost:
+            return torch.from_numpy(out), torch.from_numpy(to.int_costs(d2))
+        return torch.from_numpy(out)
+
+    def mstep(self, x, labels32, c_old, k, split):
+        xn, lab = x.numpy().astype(np.float64), labels32.numpy().astype(np.int64)
+        sums = np.zeros((k, xn.shape[1]))
+        np.add.at(sums, lab, xn)
+        counts = np.bincount(lab, minlength=k).astype(np.int64)
+        inertia = np.zeros(2)
+        if c_old is not None:
+            d = xn - c_old.numpy().astype(np.float64)[lab]
+            row = (d * d).sum(1)
+            inertia[:] = [row[:split].sum(), row[split:].sum()]
+        return torch.from_numpy(sums), torch.from_numpy(counts), torch.from_numpy(inertia)
+
+    def finalize(self, sums, counts, c_old):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c = (sums.numpy() / counts.numpy().astype(np.float64)[:, None]).astype(np.float32)
+        shift = np.array([np.nan])
+        if c_old is not None:
+            shift = np.array([ko._center_shift_sq(c, c_old.numpy())])
+        return torch.from_numpy(c), torch.from_numpy(shift)
+
+    def sum_f32(self, x):
+        return torch.tensor([float(np.sum(x.numpy().astype(np.float64)))], dtype=torch.float64)
+
+    def kpp_draw(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+        d = d2.numpy().astype(np.float32)
+        tot = np.float32(np.sum(d.astype(np.float64))) if total is None else np.float32(float(total))
+        prob = (d / tot).astype(np.float32).astype(np.float64)
+        ps = torch.tensor([prob.sum()], dtype=torch.float64) if want_probsum else None
+        idx = None
+        if want_idx:
+            cum = (np.cumsum(prob) + (0.0 if prefix is None else float(prefix))).astype(np.float32)
+            hit = np.nonzero(cum >= np.float32(r))[0]
+            idx = torch.tensor([int(hit[0]) if hit.size else -1], dtype=torch.int64)
+        return idx, ps
+
+    def transport(self, cost, size_min, size_max):
+        from scd_amd import ops
+        return ops.transport_solve(cost, size_min, size_max)      # host C++ solver (no device needed)

@@ -1,0 +1,159 @@
+"""CPU-only checks of the product: the C-ABI library loads and exports every symbol include/scd_hip.h declares,
+the host solvers (Munkres, transport) match the reference goldens / the LP optimum, the C oracle restatement matches
+the numpy oracle.  No device compute is called."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import kmeans_oracle as ko
+from oracle import naming_oracle as no
+from oracle import transport_oracle as to
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from scd_amd import _lib
+    return _lib.load()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "scd_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(scd_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"scd_status", "scd_dtype", "scd_sim_mode"}
+    from scd_amd import _lib
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.scd_version() >= 100
+
+
+def test_no_torch_types_in_abi():
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "scd_amd", "lib", "libscd_hip.so")],
+                         capture_output=True, text=True).stdout
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l and "scd_" in l]
+    assert all(not s.startswith("_Z") for s in syms if s.startswith("scd_"))     # extern "C" entry points
+    assert "libtorch" not in subprocess.run(["ldd", os.path.join(ROOT, "scd_amd", "lib", "libscd_hip.so")],
+                                            capture_output=True, text=True).stdout
+
+
+def test_product_does_not_import_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "scd_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_missing_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    from scd_amd import ops, _lib
+    with pytest.raises(_lib.ScdError):
+        ops.l2norm_rows(torch.zeros(4, 8))
+    with pytest.raises(_lib.ScdError):
+        _lib.handle()
+
+
+def test_munkres_matches_reference_goldens(golden):
+    from scd_amd import ops
+    g = golden("munkres.npz")
+    keys = sorted(k[5:] for k in g.files if k.startswith("cost_"))
+    for k in keys:
+        assert np.array_equal(ops.munkres(g["cost_" + k]), g["ind_" + k]), k
+    rs = np.random.RandomState(5)
+    for d, hi in ((150, 2), (257, 3), (200, 40)):
+        x = rs.randint(0, hi, size=(d, d))
+        assert np.array_equal(ops.munkres(x), no.linear_assignment(x))
+    assert ops.munkres(np.zeros((0, 0), dtype=int)).shape == (0, 2)
+
+
+def test_split_cluster_acc_v2_notebook_kat(golden):
+    from scd_amd.gcd.project_utils.cluster_and_log_utils import split_cluster_acc_v2
+    g = golden("acc_v2.npz")
+    t, o, n, m = split_cluster_acc_v2(g["gt"], g["preds"], g["mask"], return_ind_map=True)
+    assert (t, o, n) == (0.85, 0.8, 0.9) and m == {2: 0, 1: 1, 0: 2, 3: 3}
+
+
+def test_assign_name_matches_reference(golden):
+    from collections import Counter
+    from scd_amd.local_utils import clip_lang_util as clu
+    g = golden("naming.npz")
+    for rep in range(3):
+        c2c = {}
+        for ck, nm, ct in zip(g["an%d_keys" % rep].tolist(), g["an%d_names" % rep].tolist(), g["an%d_counts" % rep].tolist()):
+            c2c.setdefault(ck, Counter())[nm] = ct
+        ind, w = clu.assign_name(g["an%d_voted" % rep].tolist(), c2c, num_common=3)
+        assert np.array_equal(w, g["an%d_w" % rep]) and np.array_equal(ind, g["an%d_ind" % rep])
+    assert len(clu.imagenet_templates) == 80
+
+
+@pytest.mark.parametrize("n,k,smin,smax,seed", [(60, 4, 10, 20, 1), (300, 6, 40, 60, 2), (500, 10, 45, 55, 3), (400, 5, 0, 400, 4),
+                                                (200, 8, 25, 25, 5), (1000, 12, 60, 120, 6), (37, 3, 1, 36, 7)])
+def test_transport_optimal_and_feasible(n, k, smin, smax, seed):
+    from scd_amd import ops
+    rs = np.random.RandomState(seed)
+    pts, cen = rs.randn(n, 3), rs.randn(k, 3) * 1.5
+    d2 = ((pts[:, None] - cen[None]) ** 2).sum(-1).astype(np.float32)
+    cost = to.int_costs(d2)
+    lab, tot = ops.transport_solve(cost, smin, smax)
+    _, tot_lp = to.solve_lp(cost, smin, smax)
+    ok, tot_chk = to.check_assignment(cost, lab, smin, smax)
+    assert ok and tot == tot_chk == tot_lp
+
+
+def test_transport_infeasible_raises_like_reference():
+    from scd_amd import ops
+    from scd_amd.local_utils.sskm_constrained import _labels_constrained
+    with pytest.raises(Exception, match="There was an issue with the min cost flow input."):
+        ops.transport_solve(np.ones((5, 2), dtype=np.int32), 3, 5)
+    with pytest.raises(Exception, match="min cost flow"):
+        _labels_constrained(None, None, np.ones((5, 2), dtype=np.float32), 0, 2, np.zeros(5, dtype=np.float32))
+
+
+def test_labels_constrained_reference_golden(golden):
+    from scd_amd.local_utils.sskm_constrained import _labels_constrained
+    g = golden("kmeans_constrained.npz")
+    dist = np.zeros(g["a_d2"].shape[0], dtype=np.float32)
+    lab, inertia = _labels_constrained(None, None, np.sqrt(g["a_d2"]), 30, 80, dist)
+    cost = to.int_costs(g["a_d2"])
+    assert int(cost[np.arange(len(lab)), lab].sum()) == int(g["a_total"])          # same optimum as the reference run
+    assert lab.dtype == np.int32 and abs(float(inertia) - float(g["a_inertia"])) <= 2e-3 * float(g["a_inertia"])
+
+
+def test_c_oracle_matches_numpy_oracle():
+    so = os.path.join(ROOT, "oracle", "c", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "c")], check=True)
+    lib = C.CDLL(so)
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    rs = np.random.RandomState(0)
+    x = rs.randn(700, 48).astype(np.float32)
+    c = rs.randn(9, 48).astype(np.float32)
+    lab = np.zeros(700, dtype=np.int64)
+    mind = np.zeros(700, dtype=np.float32)
+    lib.oracle_estep(P(x), P(c), C.c_int64(700), 48, 9, P(lab), P(mind))
+    olab, omind, _ = ko.estep(x, c)
+    assert np.array_equal(lab, olab) and np.allclose(mind, omind, rtol=1e-6)
+    cen = np.zeros((9, 48), dtype=np.float32)
+    lib.oracle_mstep(P(x), P(lab), C.c_int64(700), 48, 9, P(cen))
+    oc, _ = ko.mstep(x, olab, 9)
+    assert np.allclose(cen, oc, rtol=1e-6, atol=1e-7, equal_nan=True)
+    f = (rs.randn(50, 64) / 8).astype(np.float16).astype(np.float32)
+    w = (rs.randn(64, 333) / 8).astype(np.float16).astype(np.float32)
+    wt = np.ascontiguousarray(w.T)
+    idx = np.zeros((50, 5), dtype=np.int64)
+    val = np.zeros((50, 5), dtype=np.float32)
+    lib.oracle_sim_topk(P(f), P(wt), C.c_int64(50), 64, C.c_int64(333), C.c_double(100.0), 5, P(idx), P(val))
+    oi, ov = no.sim_topk(f, w, 5, "raw")
+    assert np.array_equal(idx, oi) and np.allclose(val, ov, rtol=1e-6)

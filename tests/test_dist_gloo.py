@@ -1,0 +1,86 @@
+"""world_size=2 gloo runs of the multi-GPU k-means logic on CPU (one process per 'GPU', sharded rows).  The compute
+backend is the oracle-backed stand-in of tests/oracle_backend.py; what is under test is the exchange pattern of
+scd_amd/kmeans.py: one packed all-reduce per Lloyd iteration, shard-aware k-means++ draws, gathered constrained E-step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import synth
+        from oracle_backend import OracleBackend
+        from scd_amd.kmeans import KMeansEngine, ConstrainedEngine
+        n, d, k, seed = 900, 16, 6, 21
+        x, y, mask_lab = synth.blob_case(n, d, k, seed)
+        u, l, lt = x[~mask_lab], x[mask_lab], y[mask_lab]
+        cut_u, cut_l = 400, 100                                     # uneven shards
+        su = slice(0, cut_u) if rank == 0 else slice(cut_u, None)
+        sl = slice(0, cut_l) if rank == 0 else slice(cut_l, None)
+        if kind == "sskm":
+            km = KMeansEngine(k=k, max_iterations=6, n_init=2, random_state=3, backend=OracleBackend(), group=dist.group.WORLD)
+        else:
+            km = ConstrainedEngine(k=k, max_iterations=4, size_min=60, size_max=200, n_init=2, random_state=3,
+                                   backend=OracleBackend(), group=dist.group.WORLD)
+        km.fit_mix(torch.from_numpy(u[su]), torch.from_numpy(l[sl]), torch.from_numpy(lt[sl]))
+        q.put((rank, km.labels_.numpy(), km.cluster_centers_.numpy(), float(km.inertia_)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, lab, cen, inertia = q.get(timeout=300)
+        res[r] = (lab, cen, inertia)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_sskm_equals_single_process():
+    from oracle import kmeans_oracle as ko, synth
+    res = _run("sskm")
+    n, d, k, seed = 900, 16, 6, 21
+    x, y, mask_lab = synth.blob_case(n, d, k, seed)
+    u, l, lt = x[~mask_lab], x[mask_lab], y[mask_lab]
+    okm = ko.K_Means(k=k, max_iterations=6, n_init=2, random_state=3)
+    okm.fit_mix(u, l, lt)
+    n_l = len(lt)
+    # each rank holds [its labelled rows ; its unlabelled rows]
+    lab_l = np.concatenate([res[0][0][:100], res[1][0][: n_l - 100]])
+    lab_u = np.concatenate([res[0][0][100:], res[1][0][n_l - 100:]])
+    assert np.array_equal(lab_l, okm.labels_[:n_l]) and np.array_equal(lab_u, okm.labels_[n_l:])
+    assert np.array_equal(res[0][1], res[1][1])                      # identical centroids on every rank
+    assert np.allclose(res[0][1], okm.cluster_centers_, rtol=1e-6, atol=1e-7)
+    assert res[0][2] == res[1][2] == pytest.approx(float(okm.inertia_), rel=1e-6)
+
+
+def test_sharded_constrained_respects_global_bounds():
+    res = _run("con")
+    from oracle import synth
+    _, y, mask_lab = synth.blob_case(900, 16, 6, 21)
+    n_l = int(mask_lab.sum())
+    lab_u = np.concatenate([res[0][0][100:], res[1][0][n_l - 100:]])
+    cnt = np.bincount(lab_u, minlength=6)
+    assert cnt.min() >= 60 and cnt.max() <= 200 and cnt.sum() == 900 - n_l
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
