@@ -98,7 +98,7 @@ def dominant_kernel_roofline(model, batch):
     Timed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
     from scd_amd import ops
     enc = model.visual.enc
-    bp = (batch + 127) // 128 * 128
+    bp = (batch + 255) // 256 * 256
     m, n, k = bp * 197, 3072, 768
     a = (torch.randn(m, k, device="cuda") * 0.5).half()
     w = enc.weights[9 + 8]           # layer 0 fc1 weight [3072,768]

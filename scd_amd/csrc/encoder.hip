@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static inline int batch_pad(int b) { return (b + 127) / 128 * 128; }
+static inline int batch_pad(int b) { return (b + 255) / 256 * 256; }
 
 struct EncWs {
     half_t *x, *y, *qkv, *h, *cls, *outp;

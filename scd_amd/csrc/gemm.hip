@@ -12,9 +12,10 @@
 // tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer after them).
 #include "common.h"
 #include "gemm.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float act_apply(float x, int act) {
-    if (act == SCD_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+    if (act == SCD_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     if (act == SCD_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     return x;
 }
@@ -127,6 +128,206 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const half_t* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: persistent 256x256x64 kernel.  8 waves (2 m x 4 n), wave tile 128(m) x 64(n) = 4x2 MFMA tiles (128 accumulator
+// registers), LDS-DMA staging (global_load_lds, 16 B/lane) into a 2-stage ring of [A 256x64 | W 256x64] = 64 KB per stage.
+// A block owns a contiguous run of output tiles (n fastest) and runs ONE flattened software pipeline over
+// (tile, k-step): the loads of step s+1 are issued right after the barrier that opens step s, so they fly during the
+// 32 MFMAs/wave of step s, also across tile boundaries - a tile's epilogue overlaps the next tile's first loads.
+// LDS-DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
+// address and again on the ds_read side (same involution on both).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                      const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                      half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles, int xmode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (32 KB A + 32 KB W) + 8 x 4 KB epilogue patches
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = K >> 5;
+    // Tile schedule for L2 locality: blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous
+    // tile range [x*T/8, (x+1)*T/8) (n fastest) and its resident blocks take tiles round-robin, so that at any time the
+    // blocks of one XCD hold ~32 CONSECUTIVE tiles: a handful of A row-panels x all W column-panels, swept through k in
+    // lockstep -> each k-slab is fetched into that XCD's L2 once and then hit by the other blocks that share it.
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
+    const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
+    const int tb = c0 + slot;
+    const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
+    const int steps = my_tiles * nk;
+    if (steps <= 0) return;
+    const int tstride = per_xcd;
+
+    // 64-byte LDS rows (32 k): 16-B chunk XOR ((row>>2)&3) keeps the ds_read_b128 fragment reads conflict-free.
+    // per-lane source offsets of the 2 row groups this wave stages per operand (rows wave*32 + p*16 + lane/4)
+    const int lrow = lane >> 2, pc = lane & 3;
+    int src_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int rowl = wave * 32 + p * 16 + lrow;
+        src_off[p] = rowl * K + ((pc ^ ((rowl >> 2) & 3)) << 3);
+    }
+    auto issue = [&](int tile, int kt, int slot) {
+        const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+        const half_t* ga = A + (size_t)bm * 256 * K + kt * 32;
+        const half_t* gw = W + (size_t)bn * 256 * K + kt * 32;
+        char* sa = smem + slot * 32768 + wave * 2048;
+        char* sw = sa + 16384;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const void*)(ga + src_off[p]), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gw + src_off[p]), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
+        }
+    };
+    auto off32 = [](int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
+
+    // flattened pipeline over (tile, 32-deep k sub-step): 4-slot ring, 3 sub-tiles (12 LDS-DMA per wave) in flight
+    int tile = (int)tb, kt = 0;          // sub-step being computed
+    int ntile = tile, nkt = 0;           // sub-step being loaded
+#pragma unroll
+    for (int pre = 0; pre < 3; ++pre) {
+        if (pre < steps) issue(ntile, nkt, pre);
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+    }
+    int store_age = 4;                   // iterations since the last epilogue issued its 16 stores
+    half8 rpre[4];                       // residual rows of the next epilogue block, prefetched under the MFMAs
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
+    for (int s = 0; s < steps; ++s) {
+        // slot s must have landed: everything younger (2 sub-tiles = 8 DMAs, + 16 epilogue stores if recent) may fly
+        if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (store_age < 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        ++store_age;
+        __builtin_amdgcn_s_barrier();    // slot s visible to all waves; slot (s+3)&3 == (s-1)&3 is free again
+        asm volatile("" ::: "memory");
+        if (s + 3 < steps && !((xmode & 1) && s >= 2)) issue(ntile, nkt, (s + 3) & 3);
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+        if (HAS_RES && kt == nk - 2) {     // residual rows of epilogue block i=0: two sub-steps of MFMAs hide the latency
+            const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
+        }
+        const char* la = smem + (s & 3) * 32768;
+        const char* lw = la + 16384;
+        half8 fw[2][2], fa[2][4];
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[k16][j] = *(const half8*)(lw + off32(wn * 64 + j * 32 + r, 2 * k16 + hh));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[k16][i] = *(const half8*)(la + off32(wm * 128 + i * 32 + r, 2 * k16 + hh));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[k16][j], fa[k16][i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (++kt == nk) {
+            // epilogue of this tile (the next tile's first loads are already in flight).  The accumulators are
+            // transposed through a per-wave LDS patch [32 m][64 n] fp16 (128-B rows, 16-B chunks XOR (row&7)) so that
+            // every global store instruction writes 8 full 128-byte row segments instead of 32 16-byte pieces.
+            const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+            char* ep = smem + 131072 + wave * 4096;
+            const int nb0 = bn * 256 + wn * 64;
+            f32x4 bq[2][4];
+            if (HAS_BIAS) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *(const float4*)(bias + nb0 + j * 32 + 8 * g + 4 * hh);
+                        bq[j][g][0] = b4.x; bq[j][g][1] = b4.y; bq[j][g][2] = b4.z; bq[j][g][3] = b4.w;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        half4 o;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            float v = acc[j][i][4 * g + q4];
+                            if (HAS_BIAS) v += bq[j][g][q4];
+                            o[q4] = (half_t)act_apply(v, ACT);
+                            acc[j][i][4 * g + q4] = 0.f;
+                        }
+                        *(half4*)(ep + r * 128 + (((j * 4 + g) ^ (r & 7)) << 4) + hh * 8) = o;
+                    }
+                }
+                half8 rcur[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
+                if (HAS_RES && i < 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + (i + 1) * 32 + p * 8 + (lane >> 3)) * N + nb0 + (lane & 7) * 8);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int rr = p * 8 + (lane >> 3), cc = lane & 7;
+                    half8 h = *(const half8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    const size_t off = ((size_t)bm * 256 + wm * 128 + i * 32 + rr) * N + nb0 + cc * 8;
+                    if (HAS_RES) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) h[q] = (half_t)((float)h[q] + (float)rcur[p][q]);
+                    }
+                    if (!(xmode & 2)) *(half8*)(C + off) = h;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            kt = 0;
+            tile += tstride;
+            store_age = 0;
+        }
+    }
+}
+
+template <int ACT, bool B, bool RR>
+static int launch256(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                     hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        SCD_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        attr = true;
+    }
+    const int tiles_n = N / 256, total = (M / 256) * tiles_n;
+    const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
+    static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    gemm256_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode);
+    return SCD_OK;
+}
+template <int ACT>
+static int launch256_act(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                         hipStream_t st) {
+    if (bias && R) return launch256<ACT, true, true>(A, W, bias, R, C, M, N, K, st);
+    if (bias) return launch256<ACT, true, false>(A, W, bias, R, C, M, N, K, st);
+    if (R) return launch256<ACT, false, true>(A, W, bias, R, C, M, N, K, st);
+    return launch256<ACT, false, false>(A, W, bias, R, C, M, N, K, st);
+}
+
 template <int ACT>
 static void launch_act(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                        hipStream_t st) {
@@ -143,6 +344,17 @@ int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const h
     SCD_REQUIRE(M > 0 && M % 128 == 0 && N > 0 && N % 128 == 0 && K > 0 && K % 64 == 0 && M < (1ll << 31),
                 "gemm: shape m=%lld n=%d k=%d must be multiples of 128/128/64", (long long)M, N, K);
     SCD_REQUIRE(C != (half_t*)A, "gemm: C must not alias A");
+    static const bool force128 = getenv("SCD_GEMM128") != nullptr;
+    if (M % 256 == 0 && N % 256 == 0 && !force128) {
+        int rc;
+        if (act == SCD_ACT_NONE) rc = launch256_act<SCD_ACT_NONE>(A, W, bias, R, C, (int)M, N, K, st);
+        else if (act == SCD_ACT_QUICKGELU) rc = launch256_act<SCD_ACT_QUICKGELU>(A, W, bias, R, C, (int)M, N, K, st);
+        else if (act == SCD_ACT_GELU) rc = launch256_act<SCD_ACT_GELU>(A, W, bias, R, C, (int)M, N, K, st);
+        else SCD_REQUIRE(false, "gemm: bad activation %d", act);
+        if (rc) return rc;
+        SCD_LAUNCH_CHECK();
+        return SCD_OK;
+    }
     if (act == SCD_ACT_NONE) launch_act<SCD_ACT_NONE>(A, W, bias, R, C, (int)M, N, K, st);
     else if (act == SCD_ACT_QUICKGELU) launch_act<SCD_ACT_QUICKGELU>(A, W, bias, R, C, (int)M, N, K, st);
     else if (act == SCD_ACT_GELU) launch_act<SCD_ACT_GELU>(A, W, bias, R, C, (int)M, N, K, st);

@@ -27,20 +27,22 @@ def dev(x):
 
 
 # ----------------------------------------------------------------------------------------------- GEMM
-def test_gemm_identity_asymmetric(ops):
-    # A = I (padded), asymmetric integer W: catches any row/col or lane-map swap exactly
-    m, n, k = 128, 256, 128
+@pytest.mark.parametrize("m,n,k", [(128, 256, 128), (256, 512, 256), (512, 256, 512)])
+def test_gemm_identity_asymmetric(ops, m, n, k):
+    # A = I (padded), asymmetric integer W: catches any row/col or lane-map swap exactly (128- and 256-tile kernels)
     a = torch.zeros(m, k)
-    a[torch.arange(m), torch.arange(m)] = 1.0
+    idx = torch.arange(min(m, k))
+    a[idx, idx] = 1.0
     w = (torch.arange(n).view(n, 1) * 3 + torch.arange(k).view(1, k) * 7) % 61 - 30.0
     c = ops.gemm_f16(a.half().cuda(), w.half().cuda())
     assert torch.equal(c.float().cpu(), (a @ w.t()))
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 768), (384, 768, 3072), (25216, 2304, 768)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 768), (384, 768, 3072), (25216, 2304, 768), (256, 256, 64),
+                                   (512, 768, 768), (1024, 2304, 3072), (50432, 768, 768)])
 @pytest.mark.parametrize("variant", ["plain", "bias_qgelu", "bias_res", "gelu"])
 def test_gemm_matches_fp32(ops, m, n, k, variant):
-    if m > 1000 and variant != "bias_res":
+    if m > 10000 and variant != "bias_res":
         pytest.skip("big shape once")
     g = torch.Generator().manual_seed(m + n + k)
     a = (torch.randn(m, k, generator=g) * 0.5).half().cuda()
@@ -397,3 +399,21 @@ def test_full_size_estep_mstep_properties(ops):
     c2, shift = ops.kmeans_finalize(sums, counts, c)
     lab2 = data.estep(c2)
     assert (lab2 == lab).float().mean().item() > 0.999
+
+
+# ----------------------------------------------------------------------------------------------- drop-in entry points
+def test_main_unsup_and_ptsup_synthetic(ops, monkeypatch):
+    import importlib
+    import sys
+    monkeypatch.setattr(sys, "argv", ["main_unsup.py", "--synthetic", "true", "--synthetic_images", "1536", "--synthetic_vocab", "600",
+                                      "--n_cluster", "8", "--cluster", "SSKM", "--topk", "3", "--num_common_vote", "10",
+                                      "--num_common_linear", "2"])
+    mu = importlib.import_module("main_unsup")
+    cand, u_preds = mu.main()
+    assert len(cand) == 8 and set(int(c.split("_")[1]) for c in cand) == set(range(8))      # the planted names are found
+    monkeypatch.setattr(sys, "argv", ["main_ptsup.py", "--synthetic", "true", "--synthetic_images", "1536", "--synthetic_vocab", "600",
+                                      "--n_cluster", "8", "--cluster", "ConSSKM", "--cluster_size_min", "50", "--cluster_size_max", "400",
+                                      "--topk", "5", "--num_common_vote", "10", "--num_common_linear", "2"])
+    mp_ = importlib.import_module("main_ptsup")
+    cand, u_preds = mp_.main()
+    assert set(int(c.split("_")[1]) for c in cand) == set(range(8))
