@@ -94,7 +94,7 @@ def cpu_baseline(seed=0):
 
 
 def dominant_kernel_roofline(model, batch):
-    """fc1 GEMM of the ViT blocks (gemm_f16_kernel<QuickGELU,bias,no-residual>): [B*197,768] x [3072,768]^T.
+    """fc1 GEMM of the ViT blocks (gemm256_kernel<QuickGELU,bias,no-residual>): [B*197,768] x [3072,768]^T.
     Timed with HIP events on the launch stream; algorithmic FLOPs = 2*M*N*K per launch."""
     from scd_amd import ops
     enc = model.visual.enc
@@ -116,7 +116,7 @@ def dominant_kernel_roofline(model, batch):
     tf = 2.0 * m * n * k / sec / 1e12
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_f16_kernel<QuickGELU,bias> fc1 m=%d n=%d k=%d" % (m, n, k), "avg_launch_us": round(sec * 1e6, 1)}
+            "kernel": "gemm256_kernel<QuickGELU,bias,no-residual> (ViT fc1) m=%d n=%d k=%d" % (m, n, k), "avg_launch_us": round(sec * 1e6, 1)}
 
 
 def main():

@@ -199,17 +199,21 @@ __global__ void __launch_bounds__(256) emit_kernel(const half_t* __restrict__ in
 }
 
 // ------------------------------------------------------------------------------------------------ attention
-// One block (4 waves) per (image, head); head_dim = 64.  K rows and V^T live in LDS; a wave owns 32-query blocks.
-// S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows, B = Q rows): lane = query, registers = keys, so the softmax
-// reductions are in-lane plus one exchange between lanes l and l+32; the exponentiated S^T registers are then the
-// B operand of O^T = V^T P^T directly (k order of the accumulator layout: key = 16s + 8(j>>2) + 4h + (j&3)).
+// One block (4 waves) per (image, head); head_dim = 64.  K (XOR-swizzled 128-B rows) and V (row-major, 192-B rows)
+// live in LDS; a wave owns 32-query blocks.  S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows, B = Q rows):
+// lane = query, registers = keys, so the softmax reductions are in-lane plus one exchange between lanes l and l+32;
+// the exponentiated S^T registers are then directly the B operand of O^T = V^T P^T (k order of the accumulator
+// layout: key = 16s + 8(j>>2) + 4h + (j&3)), and the matching V^T A-fragments come from the hardware transposing
+// read ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group), so V is staged with plain 16-byte row copies.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
 template <int NB>   // NB = ceil(T/32): 7 for T=197, 3 for T=77
-__global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width,
-                                                        int heads, int causal) {
+__global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width,
+                                                           int heads, int causal) {
     constexpr int TP = NB * 32;
-    constexpr int VSTRIDE = TP + 4;                 // halves; 2*(TP+4) bytes per V^T row keeps ds_read_b64 conflict-free
+    constexpr int VS = 192;                          // V row stride in bytes: 4 rows x 64 B of a tr-read tile the 64 banks
     __shared__ __attribute__((aligned(16))) char kl[TP * 128];
-    __shared__ __attribute__((aligned(16))) half_t vt[64 * VSTRIDE];
+    __shared__ __attribute__((aligned(16))) char vl[TP * VS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int img = blockIdx.x / heads, head = blockIdx.x % heads;
@@ -219,22 +223,21 @@ __global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict
     const half_t* kbase = qbase + width;
     const half_t* vbase = qbase + 2 * width;
 
-    // stage K (swizzled 128-B rows) and V^T; rows >= T are zero
     for (int i = tid; i < TP * 8; i += 256) {
         const int row = i >> 3, ch = i & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0);
-        half8 vv;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) vv[q] = (half_t)0.f;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (row < T) {
             kv = *(const uint4*)(kbase + (size_t)row * ld + 8 * ch);
-            vv = *(const half8*)(vbase + (size_t)row * ld + 8 * ch);
+            vv = *(const uint4*)(vbase + (size_t)row * ld + 8 * ch);
         }
         *(uint4*)(kl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) vt[(8 * ch + q) * VSTRIDE + row] = vv[q];
+        *(uint4*)(vl + row * VS + ch * 16) = vv;
     }
     __syncthreads();
+
+    // transposing-read address of this lane inside a (4 keys x 16 d) tile: group g = lane>>4 selects d half and key half
+    const int L = lane & 15;
+    const int tr_off = (4 * hh + (L >> 2)) * VS + (16 * ((lane >> 4) & 1) + 4 * (L & 3)) * 2;
 
     for (int qb = wave; qb < NB; qb += 4) {
         const int query = qb * 32 + r;
@@ -254,7 +257,6 @@ __global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
             }
         }
-        // scale, mask, softmax over keys (registers x key blocks x the partner half-lane)
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
@@ -277,8 +279,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict
                 sum += p;
             }
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+        const float inv = __builtin_amdgcn_rcpf(sum);
         f32x16 oacc[2];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -293,12 +294,13 @@ __global__ void __launch_bounds__(256) attention_kernel(const half_t* __restrict
                 for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const half_t* vrow = vt + (db * 32 + r) * VSTRIDE + kb * 32 + 16 * s + 4 * hh;
-                    const half4 lo = *(const half4*)(vrow);
-                    const half4 hi = *(const half4*)(vrow + 8);
+                    const char* base = vl + (kb * 32 + 16 * s) * VS + db * 64 + tr_off;
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 8 * VS));
+                    const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
                     half8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    vf[0] = l4[0]; vf[1] = l4[1]; vf[2] = l4[2]; vf[3] = l4[3];
+                    vf[4] = h4[0]; vf[5] = h4[1]; vf[6] = h4[2]; vf[7] = h4[3];
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
                 }
             }
