@@ -223,15 +223,25 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
     const half_t* kbase = qbase + width;
     const half_t* vbase = qbase + 2 * width;
 
-    for (int i = tid; i < TP * 8; i += 256) {
-        const int row = i >> 3, ch = i & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (row < T) {
-            kv = *(const uint4*)(kbase + (size_t)row * ld + 8 * ch);
-            vv = *(const uint4*)(vbase + (size_t)row * ld + 8 * ch);
+    // stage K and V: all 2*NB 16-byte loads of a thread are issued before the first LDS write (one memory round trip)
+    {
+        uint4 kv[NB], vv[NB];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int i = it * 256 + tid, row = i >> 3, ch = i & 7;
+            kv[it] = make_uint4(0, 0, 0, 0);
+            vv[it] = make_uint4(0, 0, 0, 0);
+            if (row < T) {
+                kv[it] = *(const uint4*)(kbase + (size_t)row * ld + 8 * ch);
+                vv[it] = *(const uint4*)(vbase + (size_t)row * ld + 8 * ch);
+            }
         }
-        *(uint4*)(kl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
-        *(uint4*)(vl + row * VS + ch * 16) = vv;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int i = it * 256 + tid, row = i >> 3, ch = i & 7;
+            *(uint4*)(kl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv[it];
+            *(uint4*)(vl + row * VS + ch * 16) = vv[it];
+        }
     }
     __syncthreads();
 
@@ -257,24 +267,30 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
             }
         }
+        // softmax over keys on the raw scores: only the last key block can hold padded keys; the 1/sqrt(64) scale is
+        // folded into the exp2 argument: p = 2^((s - max) * 0.125 * log2 e)
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                float v = sacc[kb][i] * 0.125f;
-                if (key >= T || (causal && key > query)) v = -INFINITY;
-                sacc[kb][i] = v;
+                float v = sacc[kb][i];
+                if (kb == NB - 1 || causal) {
+                    const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (key >= T || (causal && key > query)) v = -INFINITY;
+                    sacc[kb][i] = v;
+                }
                 mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float cs = 0.125f * 1.4426950408889634f;
+        const float mxs = mx * cs;
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = __expf(sacc[kb][i] - mx);
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], cs, -mxs));
                 sacc[kb][i] = p;
                 sum += p;
             }

@@ -207,40 +207,58 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
+
+    // Fragment registers: F0 feeds the first 8 MFMAs of a sub-step (k16 group 0), F1 the second 8 (group 1).  The LDS
+    // reads of a group are issued one MFMA group ahead, and the wait+barrier that publishes slot s+1 sits in the MIDDLE
+    // of sub-step s, so a staged slot is first read half a sub-step after the barrier that retired its DMAs.
+    half8 f0w[2], f0a[4], f1w[2], f1a[4];
+    const int rw0 = wn * 64 + r, ra0 = wm * 128 + r;
+    auto rd = [&](const char* slot, int k16, half8 (&fw)[2], half8 (&fa)[4]) {
+        const char* la = slot;
+        const char* lw = slot + 16384;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[j] = *(const half8*)(lw + off32(rw0 + j * 32, 2 * k16 + hh));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *(const half8*)(la + off32(ra0 + i * 32, 2 * k16 + hh));
+    };
+    // slot 0 must be visible before the first fragment reads
+    if (steps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rd(smem, 0, f0w, f0a);
     for (int s = 0; s < steps; ++s) {
-        // slot s must have landed: everything younger (2 sub-tiles = 8 DMAs, + 16 epilogue stores if recent) may fly
-        if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (store_age < 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        ++store_age;
-        __builtin_amdgcn_s_barrier();    // slot s visible to all waves; slot (s+3)&3 == (s-1)&3 is free again
-        asm volatile("" ::: "memory");
-        if (s + 3 < steps && !((xmode & 1) && s >= 2)) issue(ntile, nkt, (s + 3) & 3);
-        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+        const char* cur = smem + (s & 3) * 32768;
         if (HAS_RES && kt == nk - 2) {     // residual rows of epilogue block i=0: two sub-steps of MFMAs hide the latency
             const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
         }
-        const char* la = smem + (s & 3) * 32768;
-        const char* lw = la + 16384;
-        half8 fw[2][2], fa[2][4];
-#pragma unroll
-        for (int k16 = 0; k16 < 2; ++k16) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fw[k16][j] = *(const half8*)(lw + off32(wn * 64 + j * 32 + r, 2 * k16 + hh));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[k16][i] = *(const half8*)(la + off32(wm * 128 + i * 32 + r, 2 * k16 + hh));
-        }
+        rd(cur, 1, f1w, f1a);                                  // group 1 of this sub-step, overlaps the MFMAs below
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int k16 = 0; k16 < 2; ++k16)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0w[j], f0a[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // publish slot s+1: everything younger than its DMAs (1 sub-tile = 4 DMAs, + 16 epilogue stores if recent) may fly
+        if (s + 1 < steps) {
+            if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        ++store_age;
+        __builtin_amdgcn_s_barrier();    // slot s+1 visible to all waves; slot (s+3)&3 == (s-1)&3 is free again
+        asm volatile("" ::: "memory");
+        if (s + 3 < steps && !((xmode & 1) && s >= 2)) issue(ntile, nkt, (s + 3) & 3);
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+        if (s + 1 < steps) rd(smem + ((s + 1) & 3) * 32768, 0, f0w, f0a);     // group 0 of the next sub-step
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[k16][j], fa[k16][i], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1w[j], f1a[i], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         if (++kt == nk) {
             // epilogue of this tile (the next tile's first loads are already in flight).  The accumulators are
