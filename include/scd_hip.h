@@ -132,6 +132,10 @@ int scd_encoder_create(scd_handle h, const scd_encoder_desc* desc, const void* c
                        scd_encoder** out);
 int scd_encoder_destroy(scd_encoder* e);
 size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch);
+/* Measurement aid: while enabled, every fc1 GEMM launch of the encoder (its dominant kernel) is bracketed by HIP events on
+ * the launch stream.  Each call returns and clears what was collected so far: total milliseconds, launches, algorithmic
+ * FLOPs (2*M*N*K per launch); it synchronises on the recorded events. */
+int scd_encoder_timing(scd_encoder* e, int enable, double* ms_out, int* launches_out, double* flop_out);
 /* pixels [B,3,H,W] (dtype f32/f16) -> out fp16 [B,out] (L2-normalised when normalize != 0) */
 int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const void* pixels, int dtype, int batch, void* out,
                          int normalize, void* ws, size_t ws_bytes, void* stream);

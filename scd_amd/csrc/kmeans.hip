@@ -110,23 +110,25 @@ extern "C" int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d
 }
 
 // ------------------------------------------------------------------------------------------------
-// E-step workspace:  [0,64) EHdr | cn float[Kp] | ch half[Kp*Dp] | flag list int32[n]
+// E-step workspace:  [0,64) EHdr | cn float[Kp] | ch half[Kp*Dp] | ct float[Dp*Kp] (centres transposed, exact)
+//                       | pair list int32[n] | pair candidates int32[n] | full list int32[n]
 struct EHdr {
     unsigned cmax_bits;   // max ||c'||
-    int flag_cnt;
-    int pad[14];
+    int flag_cnt;         // rows whose exact argmin is among two known candidates
+    int full_cnt;         // rows that need the exact distance to every centre
+    int pad[13];
 };
 static inline int kpad(int k) { return (k + 127) / 128 * 128; }
 
 extern "C" size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k) {
     size_t kp = kpad(k), dp = dpad(d);
-    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * (size_t)n) + 256;
+    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * kp * dp) + 3 * scd_align(4 * (size_t)n) + 256;
 }
 
 // one block per (padded) centre: c' = (c-mu)*scale -> fp16; cn = ||c'||^2 (float64 -> float32)
 __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
                                                            const PrepHdr* hdr, const double* mu, EHdr* eh, float* cn,
-                                                           half_t* ch) {
+                                                           half_t* ch, float* ct, int kp) {
     __shared__ double red[4];
     __shared__ int bad;
     const int c = blockIdx.x;
@@ -143,6 +145,7 @@ __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restri
         }
         ss += v * v;
         ch[(size_t)c * dp + j] = (half_t)(float)v;
+        ct[(size_t)j * kp + c] = (c < k && j < d) ? C[(size_t)c * d + j] : NAN;     // untouched float32 values
     }
     ss = wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
@@ -171,8 +174,8 @@ __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restri
 // in-lane; lanes r and r+32 are merged once at the end.
 __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
                                                          const half_t* __restrict__ ch, const float* __restrict__ cn,
-                                                         EHdr* eh, int* flag_list, long long n, int dp, int kp,
-                                                         int32_t* __restrict__ labels) {
+                                                         EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
+                                                         long long n, int dp, int kp, int32_t* __restrict__ labels) {
     __shared__ __attribute__((aligned(16))) char lds[128 * 256];
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -181,8 +184,9 @@ __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restric
     const long long prow = point < n ? point : n - 1;
     const half_t* xrow = xh + prow * dp + 8 * hh;
 
-    float best = INFINITY, second = INFINITY;
-    int bidx = 0;
+    // running three smallest scores of this lane (b0 <= b1 <= b2) and the centres of the first two
+    float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+    int i0 = 0, i1 = 0;
 
     for (int kc = 0; kc < kp; kc += 128) {
         f32x16 acc[4];
@@ -220,28 +224,39 @@ __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restric
             for (int i = 0; i < 16; ++i) {
                 const int centre = kc + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 const float s = cn[centre] - 2.0f * acc[cb][i];
-                if (s < best) {
-                    second = best;
-                    best = s;
-                    bidx = centre;
-                } else if (s < second) {
-                    second = s;
+                if (s < b0) {
+                    b2 = b1; b1 = b0; i1 = i0; b0 = s; i0 = centre;
+                } else if (s < b1) {
+                    b2 = b1; b1 = s; i1 = centre;
+                } else if (s < b2) {
+                    b2 = s;
                 }
             }
         }
     }
-    // merge the two half-wave lanes that share a point
-    const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
-    const int oi = __shfl_xor(bidx, 32, 64);
-    float mb, ms;
-    int mi;
-    if (ob < best || (ob == best && oi < bidx)) {
-        mb = ob; mi = oi; ms = fminf(best, os);
-    } else {
-        mb = best; mi = bidx; ms = fminf(second, ob);
+    // merge the two half-wave lanes that share a point: three smallest of the six, order (value, centre)
+    const float o0 = __shfl_xor(b0, 32, 64), o1 = __shfl_xor(b1, 32, 64), o2 = __shfl_xor(b2, 32, 64);
+    const int p0 = __shfl_xor(i0, 32, 64), p1 = __shfl_xor(i1, 32, 64);
+    float m0, m1, m2;
+    int j0, j1;
+    {
+        // candidates in ascending order within each list; pick three by repeated front comparison
+        float av[3] = {b0, b1, b2}, ov[3] = {o0, o1, o2};
+        int ai[3] = {i0, i1, 0x7fffffff}, oi[3] = {p0, p1, 0x7fffffff};
+        int a = 0, o = 0;
+        float mv[3];
+        int mi[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const bool take_a = av[a > 2 ? 2 : a] < ov[o > 2 ? 2 : o] ||
+                                (av[a > 2 ? 2 : a] == ov[o > 2 ? 2 : o] && ai[a > 2 ? 2 : a] <= oi[o > 2 ? 2 : o]);
+            if (take_a) { mv[t] = av[a > 2 ? 2 : a]; mi[t] = ai[a > 2 ? 2 : a]; ++a; }
+            else { mv[t] = ov[o > 2 ? 2 : o]; mi[t] = oi[o > 2 ? 2 : o]; ++o; }
+        }
+        m0 = mv[0]; m1 = mv[1]; m2 = mv[2]; j0 = mi[0]; j1 = mi[1];
     }
     if (hh == 0 && point < n) {
-        labels[point] = mi;
+        labels[point] = j0;
         const float cmax = __uint_as_float(eh->cmax_bits);
         const float sq = sqrtf((float)dp);
         // |s~ - s| <= A*||x'|| + B : fp16 rounding of both operands (2^-10), fp32 accumulation (dp*2^-24),
@@ -249,25 +264,41 @@ __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restric
         const float A = 1.5f * (2.02f * (9.765625e-4f + dp * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq);
         const float B = 1.5f * (6.0e-8f * sq * cmax + 2.4e-7f * cmax * cmax);
         const float E = A * xnorm[point] + B;
-        if (!(ms - mb > 2.0f * E)) {       // also catches NaN
-            const int pos = atomicAdd(&eh->flag_cnt, 1);
-            flag_list[pos] = (int)point;
+        if (!(m1 - m0 > 2.0f * E)) {       // also catches NaN
+            // the true argmin is among the centres whose filtered score is within 2E of the best: if the third
+            // smallest is already outside, only {j0, j1} need the exact distance; otherwise all K do.
+            const bool pair_only = (m2 - m0 > 2.0f * E) && j1 != 0x7fffffff;
+            if (pair_only) {
+                const int pos = atomicAdd(&eh->flag_cnt, 1);
+                flag_list[pos] = (int)point;
+                flag_cand[pos] = (j0 & 0xffff) | (j1 << 16);
+            } else {
+                full_list[atomicAdd(&eh->full_cnt, 1)] = (int)point;
+            }
         }
     }
 }
 
 // exact re-evaluation of flagged rows: one wave per row, float64 difference form over all K centres
 __global__ void __launch_bounds__(64) estep_refine_kernel(const float* __restrict__ X, const float* __restrict__ C,
-                                                          const EHdr* eh, const int* flag_list, int d, int k,
-                                                          int32_t* labels) {
+                                                          const EHdr* eh, const int* flag_list, const int* flag_cand, int d,
+                                                          int k, int32_t* labels) {
     const int lane = threadIdx.x;
     const int cnt = eh->flag_cnt;
     for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
         const long long row = flag_list[f];
+        const int cand = flag_cand[f];
         const float* x = X + row * d;
         double best = INFINITY;
         int bi = 0;
-        for (int c = 0; c < k; ++c) {
+        const int nc = cand < 0 ? k : 2;
+        for (int t = 0; t < nc; ++t) {
+            int c = t;
+            if (cand >= 0) {                       // two candidates, visited in ascending centre order
+                const int ca = cand & 0xffff, cb = cand >> 16;
+                const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+                c = t == 0 ? lo : hi;
+            }
             const float* cc = C + (size_t)c * d;
             double s = 0.0;
             for (int j = lane; j < d; j += 64) {
@@ -284,10 +315,63 @@ __global__ void __launch_bounds__(64) estep_refine_kernel(const float* __restric
     }
 }
 
+// full-mode refine: one block (2 waves) per row; lane t owns centre t of a 128-centre chunk and walks the TRANSPOSED centre
+// matrix ct[j][t] (coalesced across lanes) against the row held as doubles in LDS.  Exact float64 difference form.
+__global__ void __launch_bounds__(128) estep_refine_full_kernel(const float* __restrict__ X, const float* __restrict__ ct,
+                                                                const EHdr* eh, const int* full_list, int d, int k, int kp,
+                                                                int32_t* labels) {
+    extern __shared__ double xs[];            // d doubles, then 4 doubles of reduction scratch
+    __shared__ double rv[2];
+    __shared__ int ri[2];
+    const int cnt = eh->full_cnt;
+    for (int f = blockIdx.x; f < cnt; f += gridDim.x) {
+        const long long row = full_list[f];
+        __syncthreads();
+        for (int j = threadIdx.x; j < d; j += 128) xs[j] = (double)X[row * d + j];
+        __syncthreads();
+        double best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int c0 = 0; c0 < k; c0 += 128) {
+            const int c = c0 + threadIdx.x;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const float* col = ct + c;
+            int j = 0;
+            for (; j + 4 <= d; j += 4) {
+                const double d0 = xs[j] - (double)col[(size_t)j * kp];
+                const double d1 = xs[j + 1] - (double)col[(size_t)(j + 1) * kp];
+                const double d2 = xs[j + 2] - (double)col[(size_t)(j + 2) * kp];
+                const double d3 = xs[j + 3] - (double)col[(size_t)(j + 3) * kp];
+                a0 = fma(d0, d0, a0); a1 = fma(d1, d1, a1); a2 = fma(d2, d2, a2); a3 = fma(d3, d3, a3);
+            }
+            for (; j < d; ++j) {
+                const double d0 = xs[j] - (double)col[(size_t)j * kp];
+                a0 = fma(d0, d0, a0);
+            }
+            const double s = (a0 + a1) + (a2 + a3);
+            if (c < k && s < best) { best = s; bi = c; }      // NaN never wins
+        }
+        // (value, index) minimum over the 128 lanes
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int w = (rv[1] < rv[0] || (rv[1] == rv[0] && ri[1] < ri[0])) ? 1 : 0;
+            labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
+        }
+    }
+}
+
+__global__ void refine_count_kernel(const EHdr* eh, int32_t* out) { *out = eh->flag_cnt + eh->full_cnt; }
+
 extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                                 int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && X && prep && C && labels_out && ws, "scd_kmeans_estep: null argument");
-    SCD_REQUIRE(n > 0 && d > 0 && k > 0 && n < (1ll << 31), "scd_kmeans_estep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    SCD_REQUIRE(n > 0 && d > 0 && k > 0 && k < 32768 && n < (1ll << 31), "scd_kmeans_estep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     SCD_REQUIRE(ws_bytes >= scd_kmeans_estep_ws_bytes(n, d, k), "scd_kmeans_estep: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     const int dp = dpad(d), kp = kpad(k);
@@ -295,17 +379,21 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     EHdr* eh = (EHdr*)w;
     float* cn = (float*)(w + 64);
     half_t* ch = (half_t*)(w + 64 + scd_align(4 * (size_t)kp));
-    int* flags = (int*)((char*)ch + scd_align(2 * (size_t)kp * dp));
+    float* ct = (float*)((char*)ch + scd_align(2 * (size_t)kp * dp));
+    int* flags = (int*)((char*)ct + scd_align(4 * (size_t)kp * dp));
+    int* fcand = (int*)((char*)flags + scd_align(4 * (size_t)n));
+    int* fulls = (int*)((char*)fcand + scd_align(4 * (size_t)n));
     const char* p = (const char*)prep;
     const PrepHdr* ph = (const PrepHdr*)p;
     const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
     const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
     SCD_HIP(hipMemsetAsync(eh, 0, 64, st));
-    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch);
+    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp);
     estep_mfma_kernel<<<(unsigned)scd_cdiv(n, 128), 256, 0, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off),
-                                                                    ch, cn, eh, flags, n, dp, kp, labels_out);
-    estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, d, k, labels_out);
-    if (refine_rows_out) SCD_HIP(hipMemcpyAsync(refine_rows_out, &eh->flag_cnt, 4, hipMemcpyDeviceToDevice, st));
+                                                                    ch, cn, eh, flags, fcand, fulls, n, dp, kp, labels_out);
+    estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);
+    estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
+    if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
@@ -407,129 +495,7 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
     return SCD_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// M-step partial sums.  grid = (column slices, row chunks); a block owns SW columns of its row chunk and
-// accumulates per-cluster float64 sums in LDS (ds_add_f64), plus the inertia of (x - c_old[label]).
-struct MstepPlan { int sw, slices, chunks; size_t lds; };
-static MstepPlan mstep_plan(int64_t n, int d, int k) {
-    MstepPlan p;
-    p.sw = 64;
-    while (p.sw > 4 && (size_t)k * p.sw * 12 + 4 * (size_t)k + 64 > 150 * 1024) p.sw >>= 1;
-    p.slices = (d + p.sw - 1) / p.sw;
-    int want = (768 + p.slices - 1) / p.slices;
-    long long maxc = scd_cdiv(n, 64);
-    p.chunks = (int)(want < maxc ? want : maxc);
-    if (p.chunks < 1) p.chunks = 1;
-    p.lds = (size_t)k * p.sw * 12 + 4 * (size_t)k + 64;
-    return p;
-}
-extern "C" size_t scd_kmeans_mstep_ws_bytes(int64_t n, int d, int k) {
-    MstepPlan p = mstep_plan(n, d, k);
-    return scd_align((size_t)p.chunks * k * d * 8) + scd_align((size_t)p.chunks * p.slices * 16) + 256;
-}
-
-__global__ void __launch_bounds__(256) mstep_kernel(const float* __restrict__ X, const int32_t* __restrict__ labels,
-                                                    const float* __restrict__ Cold, long long n, int d, int k, int sw,
-                                                    long long split, double* part, double* ipart,
-                                                    unsigned long long* counts) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sums = (double*)smem;                       // [k][sw]
-    float* cold = (float*)(smem + (size_t)k * sw * 8);  // [k][sw]
-    int* cnt = (int*)(smem + (size_t)k * sw * 12);      // [k]
-    __shared__ double ired[8];
-    const int slice = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
-    const int col0 = slice * sw;
-    for (int i = threadIdx.x; i < k * sw; i += 256) {
-        sums[i] = 0.0;
-        const int c = i / sw, j = col0 + i % sw;
-        cold[i] = (Cold && j < d) ? Cold[(size_t)c * d + j] : 0.f;
-    }
-    for (int i = threadIdx.x; i < k; i += 256) cnt[i] = 0;
-    __syncthreads();
-    const long long rows_per = scd_cdiv_dev(n, nchunks);
-    const long long r0 = (long long)chunk * rows_per;
-    const long long r1 = (r0 + rows_per < n) ? r0 + rows_per : n;
-    const int lpr = sw / 4;                  // lanes per row (float4 each)
-    const int rpb = 256 / lpr;               // rows per block step
-    const int sub = threadIdx.x / lpr, q4 = (threadIdx.x % lpr) * 4;
-    double in0 = 0.0, in1 = 0.0;
-    for (long long r = r0 + sub; r < r1; r += rpb) {
-        const int l = labels[r];
-        if (l < 0 || l >= k) continue;
-        if (slice == 0 && q4 == 0) atomicAdd(&cnt[l], 1);
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = col0 + q4 + q;
-            if (j < d) {
-                const float xv = X[r * d + j];
-                const double df = (double)xv - (double)cold[l * sw + q4 + q];
-                acc = fma(df, df, acc);
-                atomicAdd(&sums[l * sw + q4 + q], (double)xv);
-            }
-        }
-        if (r < split) in0 += acc; else in1 += acc;
-    }
-    in0 = wave_sum_f64(in0);
-    in1 = wave_sum_f64(in1);
-    if ((threadIdx.x & 63) == 0) {
-        ired[(threadIdx.x >> 6) * 2] = in0;
-        ired[(threadIdx.x >> 6) * 2 + 1] = in1;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < k * sw; i += 256) {
-        const int c = i / sw, j = col0 + i % sw;
-        if (j < d) part[((size_t)chunk * k + c) * d + j] = sums[i];
-    }
-    if (threadIdx.x == 0) {
-        ipart[((size_t)chunk * gridDim.x + slice) * 2] = ired[0] + ired[2] + ired[4] + ired[6];
-        ipart[((size_t)chunk * gridDim.x + slice) * 2 + 1] = ired[1] + ired[3] + ired[5] + ired[7];
-    }
-    if (slice == 0)
-        for (int i = threadIdx.x; i < k; i += 256)
-            if (cnt[i]) atomicAdd(&counts[i], (unsigned long long)cnt[i]);
-}
-
-__global__ void __launch_bounds__(256) mstep_reduce_kernel(const double* part, const double* ipart, int chunks, int nip,
-                                                           long long kd, double* sums, double* inertia) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < kd) {
-        double s = 0.0;
-        for (int c = 0; c < chunks; ++c) s += part[(size_t)c * kd + i];
-        sums[i] = s;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 2 && inertia) {
-        double s = 0.0;
-        for (int c = 0; c < nip; ++c) s += ipart[(size_t)c * 2 + threadIdx.x];
-        inertia[threadIdx.x] = s;
-    }
-}
-
-extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d,
-                                int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
-                                size_t ws_bytes, void* stream_) {
-    SCD_REQUIRE(h && X && labels && sums && counts && ws, "scd_kmeans_mstep: null argument");
-    SCD_REQUIRE(n > 0 && d > 0 && k > 0, "scd_kmeans_mstep: bad shape");
-    SCD_REQUIRE(ws_bytes >= scd_kmeans_mstep_ws_bytes(n, d, k), "scd_kmeans_mstep: workspace too small");
-    MstepPlan p = mstep_plan(n, d, k);
-    SCD_REQUIRE(p.lds <= 160 * 1024 - 256, "scd_kmeans_mstep: k=%d too large for the LDS-privatised M-step", k);
-    hipStream_t st = (hipStream_t)stream_;
-    double* part = (double*)ws;
-    double* ipart = (double*)((char*)ws + scd_align((size_t)p.chunks * k * d * 8));
-    SCD_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)k, st));
-    static bool attr_set = false;
-    if (!attr_set) {
-        SCD_HIP(hipFuncSetAttribute((const void*)mstep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
-    mstep_kernel<<<dim3(p.slices, p.chunks), 256, p.lds, st>>>(X, labels, C_old, n, d, k, p.sw, split, part, ipart,
-                                                               (unsigned long long*)counts);
-    const long long kd = (long long)k * d;
-    mstep_reduce_kernel<<<(unsigned)scd_cdiv(kd, 256), 256, 0, st>>>(part, ipart, p.chunks, p.chunks * p.slices, kd, sums,
-                                                                    inertia);
-    SCD_LAUNCH_CHECK();
-    return SCD_OK;
-}
+// (M-step partial sums: see mstep.hip)
 
 // centres = sums / counts; shift = (sum_k ||c_k - c_old_k||)^2.  Single block, fixed reduction order.
 __global__ void __launch_bounds__(1024) finalize_kernel(const double* sums, const long long* counts, int k, int d,
@@ -617,54 +583,122 @@ extern "C" int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out,
     return SCD_OK;
 }
 
-extern "C" size_t scd_kpp_draw_ws_bytes(int64_t n) { (void)n; return 256; }
+// k-means++ draw, three short multi-block kernels over tiles of KPP_TILE elements (thread t owns 4 consecutive elements,
+// so within-tile prefix sums follow index order):
+//   kpp_tile_sum   bsum[b] = sum of d2 over tile b (float64)
+//   kpp_tile_prob  psum[b] = sum of prob = d2/float32(total) over tile b (float64); total = sum(bsum) or *total_in
+//   kpp_pick       prefix over psum (+ *prefix_in) locates the first tile whose running sum reaches r; that tile is
+//                  scanned in index order for the first i with float32(running) >= r.
+#define KPP_TILE 4096
+extern "C" size_t scd_kpp_draw_ws_bytes(int64_t n) { return scd_align(16 * (size_t)scd_cdiv(n, KPP_TILE) + 64) + 256; }
 
-// total_in / prefix_in (device doubles, nullable) make the draw shard-aware: prob = d2 / float(total), the running
-// cumulative starts at *prefix_in (sum of prob over the lower-ranked shards).  probsum_out (nullable) receives this
-// shard's float64 sum of prob.  idx_out may be NULL when only probsum_out is wanted.
-__global__ void __launch_bounds__(1024) kpp_draw_kernel(const float* __restrict__ d2, long long n, float r,
-                                                        const double* total_in, const double* prefix_in,
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(1024) kpp_tile_sum_kernel(const float* __restrict__ d2, long long n, double* bsum) {
+    __shared__ double sh[16];
+    const long long i0 = (long long)blockIdx.x * KPP_TILE + threadIdx.x * 4;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) s += (double)d2[i0 + q];
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s;
+}
+
+__device__ __forceinline__ float kpp_total(const double* bsum, int nb, const double* total_in) {
+    if (total_in) return (float)*total_in;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += bsum[b];      // fixed order
+    return (float)t;
+}
+
+__global__ void __launch_bounds__(1024) kpp_tile_prob_kernel(const float* __restrict__ d2, long long n, const double* bsum, int nb,
+                                                             const double* total_in, double* psum) {
+    __shared__ double sh[16];
+    const float totf = kpp_total(bsum, nb, total_in);
+    const long long i0 = (long long)blockIdx.x * KPP_TILE + threadIdx.x * 4;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) s += (double)__fdiv_rn(d2[i0 + q], totf);
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) psum[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(1024) kpp_pick_kernel(const float* __restrict__ d2, long long n, float r, const double* bsum,
+                                                        const double* psum, int nb, const double* total_in, const double* prefix_in,
                                                         long long* idx_out, double* probsum_out) {
     __shared__ double sh[32];
     __shared__ long long best;
-    const long long seg = scd_cdiv_dev(n, 1024);
-    const long long a = threadIdx.x * seg, b = (a + seg < n) ? a + seg : n;
-    if (threadIdx.x == 0) best = 0x7fffffffffffffffll;
-    double tot;
-    if (total_in) {
-        tot = *total_in;
-        __syncthreads();
-    } else {
-        double s = 0.0;
-        for (long long i = a; i < b; ++i) s += (double)d2[i];
-        block_scan_excl_1024(s, sh, &tot);
-    }
-    const float totf = (float)tot;
-    double ps = 0.0;
-    for (long long i = a; i < b; ++i) ps += (double)__fdiv_rn(d2[i], totf);
-    double ptot;
-    const double pre = block_scan_excl_1024(ps, sh, &ptot) + (prefix_in ? *prefix_in : 0.0);
-    if (threadIdx.x == 0 && probsum_out) *probsum_out = ptot;
-    if (!idx_out) return;
-    double run = pre;
-    long long found = 0x7fffffffffffffffll;
-    for (long long i = a; i < b; ++i) {
-        run += (double)__fdiv_rn(d2[i], totf);
-        if ((float)run >= r) {
-            found = i;
-            break;
+    __shared__ int owner;
+    __shared__ double owner_pre;
+    const float totf = kpp_total(bsum, nb, total_in);
+    if (threadIdx.x == 0) {
+        double run = prefix_in ? *prefix_in : 0.0;
+        int ow = -1;
+        double opre = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double nxt = run + psum[b];
+            if (ow < 0 && (float)nxt >= r) { ow = b; opre = run; }
+            run = nxt;
         }
+        owner = ow;
+        owner_pre = opre;
+        best = 0x7fffffffffffffffll;
+        if (probsum_out) *probsum_out = run - (prefix_in ? *prefix_in : 0.0);
     }
-    if (found != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&best, (unsigned long long)found);
     __syncthreads();
+    if (!idx_out) return;
+    if (owner < 0) {
+        if (threadIdx.x == 0) *idx_out = -1;
+        return;
+    }
+    // scan the owner tile (and, for the last-ulp case where association differs, the following tiles) in index order
+    double pre = owner_pre;
+    for (int b = owner; b < nb; ++b) {
+        const long long i0 = (long long)b * KPP_TILE + threadIdx.x * 4;
+        float pv[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pv[q] = (i0 + q < n) ? __fdiv_rn(d2[i0 + q], totf) : 0.f;
+            s += (double)pv[q];
+        }
+        double tot;
+        double run = pre + block_scan_excl_1024(s, sh, &tot);
+        long long found = 0x7fffffffffffffffll;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += (double)pv[q];
+            if (found == 0x7fffffffffffffffll && i0 + q < n && (float)run >= r) found = i0 + q;
+        }
+        if (found != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&best, (unsigned long long)found);
+        __syncthreads();
+        if (best != 0x7fffffffffffffffll) break;
+        pre += tot;
+    }
     if (threadIdx.x == 0) *idx_out = (best == 0x7fffffffffffffffll) ? -1 : best;
 }
 
 extern "C" int scd_kpp_draw(scd_handle h, const float* d2, int64_t n, float r, const double* total, const double* prefix,
                             int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream_) {
-    (void)ws; (void)ws_bytes;
-    SCD_REQUIRE(h && d2 && (idx_out || probsum_out) && n > 0, "scd_kpp_draw: bad arguments");
-    kpp_draw_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(d2, n, r, total, prefix, (long long*)idx_out, probsum_out);
+    SCD_REQUIRE(h && d2 && (idx_out || probsum_out) && n > 0 && ws, "scd_kpp_draw: bad arguments");
+    SCD_REQUIRE(ws_bytes >= scd_kpp_draw_ws_bytes(n), "scd_kpp_draw: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const int nb = (int)scd_cdiv(n, KPP_TILE);
+    double* bsum = (double*)ws;
+    double* psum = bsum + nb;
+    if (!total) kpp_tile_sum_kernel<<<nb, 1024, 0, st>>>(d2, n, bsum);
+    kpp_tile_prob_kernel<<<nb, 1024, 0, st>>>(d2, n, bsum, nb, total, psum);
+    kpp_pick_kernel<<<1, 1024, 0, st>>>(d2, n, r, bsum, psum, nb, total, prefix, (long long*)idx_out, probsum_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

@@ -1,0 +1,146 @@
+// K-Means M-step partial sums + inertia for gfx950 (sskm_constrained.py:118-128 under /root/reference):
+//   for idx in range(k): centers[idx] = cat_feats[labels == idx].mean(0);   inertia = sum ||x - c_old[label]||^2
+// Sort-then-segment instead of scatter: a stable radix sort of (label, row) keys (rocPRIM) turns the scatter into
+// contiguous runs; each wave then streams 64 sorted rows (whole 2-3 KB rows, coalesced), keeps its 4*D/256 columns per
+// lane in float64 REGISTERS while the label is unchanged, and flushes a run with float64 global atomics (about
+// N/64 + K flushes of D values).  Float64 accumulation makes the result independent of the flush order after the
+// single rounding to float32 in scd_kmeans_finalize.  No LDS, no partial slabs.
+#include "common.h"
+#include <string.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+extern "C" size_t scd_kmeans_mstep_ws_bytes(int64_t n, int d, int k) {
+    (void)d; (void)k;
+    return 2 * scd_align(8 * (size_t)n) + scd_align(24 * (size_t)n + (8u << 20)) + 256;
+}
+
+__global__ void __launch_bounds__(256) mstep_keys_kernel(const int32_t* __restrict__ labels, long long n, int k,
+                                                         unsigned long long* keys) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int l = labels[i];
+    const unsigned long long bucket = (l < 0 || l >= k) ? (unsigned long long)k : (unsigned long long)l;
+    keys[i] = (bucket << 32) | (unsigned long long)i;
+}
+
+// Lane owns columns lane, lane+64, ... (MAXG = ceil(d/64) <= 16): every load and every float64 atomic of a wave touches
+// 64 consecutive elements (256 B / 512 B contiguous).  ROWS sorted rows per wave.
+#define MSTEP_ROWS 32
+template <int MAXG>
+__global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restrict__ X, const unsigned long long* __restrict__ keys,
+                                                            const float* __restrict__ Cold, long long n, int d, int k,
+                                                            long long split, double* __restrict__ sums,
+                                                            unsigned long long* __restrict__ counts, double* __restrict__ inertia) {
+    const int lane = threadIdx.x & 63;
+    const long long s0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MSTEP_ROWS;
+    if (s0 >= n) return;
+    const long long s1 = s0 + MSTEP_ROWS < n ? s0 + MSTEP_ROWS : n;
+    double acc[MAXG];
+    float co[MAXG];
+    double in0 = 0.0, in1 = 0.0;
+    int cur = -1;
+    long long run = 0;
+    auto flush = [&]() {
+        if (cur >= 0 && cur < k) {
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                const int c = g * 64 + lane;
+                if (c < d) atomicAdd(&sums[(size_t)cur * d + c], acc[g]);
+            }
+            if (lane == 0) atomicAdd(&counts[cur], (unsigned long long)run);
+        }
+    };
+    // 4 rows per iteration: their keys and row slices are all loaded before the first one is consumed
+    for (long long sb = s0; sb < s1; sb += 4) {
+        unsigned long long key[4];
+        float xv[4][MAXG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = sb + u < s1 ? keys[sb + u] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // unconditional loads from clamped (always valid) addresses: a per-element "load or zero" branch would make
+            // the compiler wait for every load separately; out-of-range lanes are masked when the value is used
+            const bool live = (unsigned)(key[u] >> 32) < (unsigned)k;
+            const long long row = live ? (long long)(key[u] & 0xffffffffull) : 0;
+            const float* xr = X + row * d;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                const int c = g * 64 + lane;
+                xv[u][g] = xr[c < d ? c : d - 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = (int)(key[u] >> 32);
+            const long long row = (long long)(key[u] & 0xffffffffull);
+            if ((unsigned)l >= (unsigned)k) continue;        // sentinel bucket (invalid labels) / past the end
+            if (l != cur) {
+                flush();
+                cur = l;
+                run = 0;
+#pragma unroll
+                for (int g = 0; g < MAXG; ++g) {
+                    acc[g] = 0.0;
+                    const int c = g * 64 + lane;
+                    co[g] = (Cold && c < d) ? Cold[(size_t)l * d + c] : 0.f;
+                }
+            }
+            ++run;
+            double a = 0.0;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                if (g * 64 + lane < d) {
+                    acc[g] += (double)xv[u][g];
+                    const double df = (double)xv[u][g] - (double)co[g];
+                    a = fma(df, df, a);
+                }
+            }
+            if (row < split) in0 += a; else in1 += a;
+        }
+    }
+    flush();
+    if (inertia) {
+        in0 = wave_sum_f64(in0);
+        in1 = wave_sum_f64(in1);
+        if (lane == 0) {
+            if (in0 != 0.0) atomicAdd(&inertia[0], in0);
+            if (in1 != 0.0) atomicAdd(&inertia[1], in1);
+        }
+    }
+}
+
+extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d,
+                                int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
+                                size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(h && X && labels && sums && counts && ws, "scd_kmeans_mstep: null argument");
+    SCD_REQUIRE(n > 0 && d > 0 && d <= 1024 && k > 0 && n < (1ll << 32), "scd_kmeans_mstep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    SCD_REQUIRE(ws_bytes >= scd_kmeans_mstep_ws_bytes(n, d, k), "scd_kmeans_mstep: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    char* w = (char*)ws;
+    unsigned long long* k0 = (unsigned long long*)w; w += scd_align(8 * (size_t)n);
+    unsigned long long* k1 = (unsigned long long*)w; w += scd_align(8 * (size_t)n);
+    void* temp = w;
+    const size_t temp_avail = scd_align(24 * (size_t)n + (8u << 20));
+    SCD_HIP(hipMemsetAsync(sums, 0, 8 * (size_t)k * d, st));
+    SCD_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)k, st));
+    if (inertia) SCD_HIP(hipMemsetAsync(inertia, 0, 16, st));
+    mstep_keys_kernel<<<(unsigned)scd_cdiv(n, 256), 256, 0, st>>>(labels, n, k, k0);
+    int bits = 1;
+    while ((1ll << bits) <= k) ++bits;                       // buckets 0..k
+    size_t need = 0;
+    SCD_HIP(rocprim::radix_sort_keys(nullptr, need, k0, k1, (size_t)n, 32, 32 + bits, st));
+    SCD_REQUIRE(need <= temp_avail, "scd_kmeans_mstep: rocprim temp storage %zu > %zu", need, temp_avail);
+    SCD_HIP(rocprim::radix_sort_keys(temp, need, k0, k1, (size_t)n, 32, 32 + bits, st));
+    const unsigned grid = (unsigned)scd_cdiv(n, 4 * MSTEP_ROWS);
+#define MSTEP_LAUNCH(G) mstep_segment_kernel<G><<<grid, 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia)
+    if (d <= 64) MSTEP_LAUNCH(1);
+    else if (d <= 128) MSTEP_LAUNCH(2);
+    else if (d <= 256) MSTEP_LAUNCH(4);
+    else if (d <= 512) MSTEP_LAUNCH(8);
+    else if (d <= 768) MSTEP_LAUNCH(12);
+    else MSTEP_LAUNCH(16);
+#undef MSTEP_LAUNCH
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}

@@ -81,9 +81,9 @@ __global__ void __launch_bounds__(256, 1) sim_topk_kernel(const half_t* __restri
                     const int c16 = tid & 15;
                     long long vr = tile * 128 + row;
                     vr = vr < v ? vr : v - 1;
-                    uint4 val = make_uint4(0, 0, 0, 0);
-                    if (dc + 8 * c16 < d) val = *(const uint4*)(Wt + vr * d + dc + 8 * c16);
-                    *(uint4*)(lds + row * 256 + ((c16 ^ (row & 15)) << 4)) = val;
+                    const int col = dc + 8 * c16;
+                    const uint4 ld4 = *(const uint4*)(Wt + vr * d + (col < d ? col : 0));     // unconditional, masked below
+                    *(uint4*)(lds + row * 256 + ((c16 ^ (row & 15)) << 4)) = col < d ? ld4 : make_uint4(0, 0, 0, 0);
                 }
                 __syncthreads();
 #pragma unroll

@@ -164,9 +164,16 @@ def kpp_draw(d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
     _need_cuda(d2)
     idx = torch.empty(1, dtype=torch.int64, device=d2.device) if want_idx else None
     ps = torch.empty(1, dtype=torch.float64, device=d2.device) if want_probsum else None
+    nb = _L().scd_kpp_draw_ws_bytes(d2.numel())
+    ws = _kpp_ws.get((d2.device, nb))
+    if ws is None:
+        ws = _kpp_ws[(d2.device, nb)] = _ws(nb, d2.device)
     check(_L().scd_kpp_draw(handle(), ptr(d2), d2.numel(), float(np.float32(r)), ptr(total), ptr(prefix), ptr(idx), ptr(ps),
-                            None, 0, stream_ptr()))
+                            ptr(ws), nb, stream_ptr()))
     return idx, ps
+
+
+_kpp_ws = {}
 
 
 def sum_f32(x):
@@ -255,6 +262,12 @@ class Encoder:
                 _L().scd_encoder_destroy(self._enc)
         except Exception:
             pass
+
+    def timing(self, enable):
+        """Enable/disable HIP-event timing of the fc1 GEMM launches; returns (ms, launches, flop) collected so far."""
+        ms, n, fl = C.c_double(0), C.c_int(0), C.c_double(0)
+        check(_L().scd_encoder_timing(self._enc, 1 if enable else 0, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
 
     def _workspace(self, batch):
         nb = _L().scd_encoder_ws_bytes(self._enc, batch)

@@ -1,0 +1,40 @@
+"""Microbenchmark of the k-means kernels at BASELINE C2 size (N_u=95k, D=768, K=100), HIP events, clustered data."""
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scd_amd import ops
+from oracle import synth
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+if __name__ == "__main__":
+    n, d, k = 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, 100
+    noise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
+    x, y, cent = synth.clustered_features(n, d, k, seed=21, center_seed=22, noise=noise)
+    X = torch.from_numpy(x).cuda(); C = torch.from_numpy(cent).cuda()
+    C2 = X[torch.randperm(n, device="cuda")[:k]].clone()          # k-means++-like start: data points as centres
+    data = ops.KMeansData(X)
+    for name, cc in (("converged centres", C), ("data-point centres", C2)):
+        lab, ref = data.estep(cc, return_refined=True)
+        us = timeit(lambda: data.estep(cc))
+        dp = (d + 127) // 128 * 128
+        algo = n * dp * 2 + 4 * n + 128 * dp * 2
+        print("estep  [%s] %8.1f us  refined rows %6d (%.2f%%)  algorithmic %.1f MB -> %.0f GB/s" % (name, us, int(ref), 100.0 * int(ref) / n, algo / 1e6, algo / us / 1e3))
+    lab = data.estep(C)
+    us = timeit(lambda: ops.kmeans_mstep(X, lab, C, k, 0))
+    algo = n * d * 4 + 4 * n
+    print("mstep  %8.1f us  algorithmic %.1f MB -> %.0f GB/s" % (us, algo / 1e6, algo / us / 1e3))
+    d2 = data.rowdist(C, lab)
+    us = timeit(lambda: data.min_update(X[17], d2))
+    algo = n * d * 4 + 8 * n
+    print("minupd %8.1f us  algorithmic %.1f MB -> %.0f GB/s" % (us, algo / 1e6, algo / us / 1e3))
+    us = timeit(lambda: ops.kpp_draw(d2, 0.37))
+    print("draw   %8.1f us" % us)
+    sums, counts, _ = ops.kmeans_mstep(X, lab, C, k, 0)
+    us = timeit(lambda: ops.kmeans_finalize(sums, counts, C))
+    print("final  %8.1f us" % us)
