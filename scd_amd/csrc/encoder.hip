@@ -13,6 +13,10 @@
 struct scd_encoder {
     scd_encoder_desc d;
     std::vector<const void*> w;
+    // optional HIP-event timing of the dominant kernel (the fc1 GEMM of every block), see scd_encoder_timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double timed_flop = 0.0;
 };
 
 enum { W_PATCH = 0, W_PATCH_B = 1, W_CLS = 2, W_POS = 3, W_LNPRE_W = 4, W_LNPRE_B = 5, W_LNPOST_W = 6, W_LNPOST_B = 7,
@@ -397,6 +401,26 @@ extern "C" int scd_encoder_destroy(scd_encoder* e) {
     return SCD_OK;
 }
 
+extern "C" int scd_encoder_timing(scd_encoder* e, int enable, double* ms_out, int* launches_out, double* flop_out) {
+    SCD_REQUIRE(e, "scd_encoder_timing: null encoder");
+    double ms = 0.0;
+    for (auto& pr : e->ev) {
+        SCD_HIP(hipEventSynchronize(pr.second));
+        float t = 0.f;
+        SCD_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    if (ms_out) *ms_out = ms;
+    if (launches_out) *launches_out = (int)e->ev.size();
+    if (flop_out) *flop_out = e->timed_flop;
+    e->ev.clear();
+    e->timed_flop = 0.0;
+    e->timing = enable != 0;
+    return SCD_OK;
+}
+
 extern "C" size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch) {
     if (!e || batch <= 0) return 0;
     return carve(e->d, batch_pad(batch), nullptr).total;
@@ -421,8 +445,20 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t 
         if (rc) return rc;
         layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
                                                                        (const float*)lw[L_LN2_B], w.y);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (e->timing) {
+            SCD_HIP(hipEventCreate(&e0));
+            SCD_HIP(hipEventCreate(&e1));
+            SCD_HIP(hipEventRecord(e0, st));
+        }
         rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
         if (rc) return rc;
+        if (e->timing) {
+            SCD_HIP(hipEventRecord(e1, st));
+            scd_encoder* me = const_cast<scd_encoder*>(e);
+            me->ev.emplace_back(e0, e1);
+            me->timed_flop += 2.0 * (double)rows * d.mlp_dim * d.width;
+        }
         rc = scd_gemm_launch(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
                              SCD_ACT_NONE, st);
         if (rc) return rc;
