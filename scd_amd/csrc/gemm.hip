@@ -142,13 +142,25 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int ACT, bool HAS_BIAS, bool HAS_RES>
 __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                       const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                      half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles, int xmode) {
+                                                      half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles, int xmode, int ng) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (32 KB A + 32 KB W) + 8 x 4 KB epilogue patches
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
     const int nk = K >> 5;
+    // tile order: n-tiles are grouped (ng per group) and a group is swept over ALL m-tiles before the next one, so the
+    // group's W panels stay resident in the XCD's L2 while the activation panels stream through exactly once per group
+    const int tiles_m = total_tiles / tiles_n;
+    const int per_group = tiles_m * ng;
+    auto tile_mn = [&](int t, int& bm, int& bn) {
+        const int g = t / per_group;
+        const int local = t - g * per_group;
+        const int n0 = g * ng;
+        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;       // width of this (possibly last, narrower) group
+        bm = local / w;
+        bn = n0 + local - bm * w;
+    };
     // Tile schedule for L2 locality: blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous
     // tile range [x*T/8, (x+1)*T/8) (n fastest) and its resident blocks take tiles round-robin, so that at any time the
     // blocks of one XCD hold ~32 CONSECUTIVE tiles: a handful of A row-panels x all W column-panels, swept through k in
@@ -172,7 +184,8 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
         src_off[p] = rowl * K + ((pc ^ ((rowl >> 2) & 3)) << 3);
     }
     auto issue = [&](int tile, int kt, int slot) {
-        const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+        int bm, bn;
+        tile_mn(tile, bm, bn);
         const half_t* ga = A + (size_t)bm * 256 * K + kt * 32;
         const half_t* gw = W + (size_t)bn * 256 * K + kt * 32;
         char* sa = smem + slot * 32768 + wave * 2048;
@@ -230,7 +243,8 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
     for (int s = 0; s < steps; ++s) {
         const char* cur = smem + (s & 3) * 32768;
         if (HAS_RES && kt == nk - 2) {     // residual rows of epilogue block i=0: two sub-steps of MFMAs hide the latency
-            const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+            int bm, bn;
+            tile_mn(tile, bm, bn);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
                 rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
@@ -264,7 +278,8 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
             // epilogue of this tile (the next tile's first loads are already in flight).  The accumulators are
             // transposed through a per-wave LDS patch [32 m][64 n] fp16 (128-B rows, 16-B chunks XOR (row&7)) so that
             // every global store instruction writes 8 full 128-byte row segments instead of 32 16-byte pieces.
-            const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+            int bm, bn;
+            tile_mn(tile, bm, bn);
             char* ep = smem + 131072 + wave * 4096;
             const int nb0 = bn * 256 + wn * 64;
             f32x4 bq[2][4];
@@ -334,7 +349,24 @@ static int launch256(const half_t* A, const half_t* W, const float* bias, const 
     const int tiles_n = N / 256, total = (M / 256) * tiles_n;
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
     static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
-    gemm256_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode);
+    static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
+    // n-tiles per group: W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
+    // re-reads the activations once.  Estimate the beyond-L2 traffic of each candidate and keep the cheapest.
+    int ng = tiles_n;
+    {
+        const double a_bytes = 2.0 * M * (double)K, panel = 512.0 * K;
+        double best = 1e300;
+        for (int groups = 1; groups <= tiles_n; ++groups) {
+            const int cand = (tiles_n + groups - 1) / groups;
+            const double wg = cand * panel;
+            const double rounds = (double)total / 256.0;                      // tile rounds per resident block
+            const double w_traffic = wg <= 2.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
+            const double cost = groups * a_bytes + w_traffic;
+            if (cost < best) { best = cost; ng = cand; }
+        }
+        if (ng_env > 0) ng = ng_env < tiles_n ? ng_env : tiles_n;
+    }
+    gemm256_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
     return SCD_OK;
 }
 template <int ACT>
