@@ -111,12 +111,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    local_rank = local_rank % torch.cuda.device_count()     # (debug: several ranks may share a GPU with SCD_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("SCD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # nccl == RCCL on ROCm
         group = dist.group.WORLD
     dev = torch.device("cuda", local_rank)
 

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "gemm.h"
 #include <vector>
+#include <stdlib.h>
 
 struct scd_encoder {
     scd_encoder_desc d;
@@ -213,7 +214,7 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 template <int NB>   // NB = ceil(T/32): 7 for T=197, 3 for T=77
 __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width,
-                                                           int heads, int causal) {
+                                                           int heads, int causal, int xmode) {
     constexpr int TP = NB * 32;
     constexpr int VS = 192;                          // V row stride in bytes: 4 rows x 64 B of a tr-read tile the 64 banks
     __shared__ __attribute__((aligned(16))) char kl[TP * 128];
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
     const int tr_off = (4 * hh + (L >> 2)) * VS + (16 * ((lane >> 4) & 1) + 4 * (L & 3)) * 2;
 
     for (int qb = wave; qb < NB; qb += 4) {
+        if (xmode & 4) break;
         const int query = qb * 32 + r;
         const int qrow = query < T ? query : T - 1;
         half8 qf[4];
@@ -307,6 +309,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
             for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
+            if (xmode & 2) break;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 half8 pf;
@@ -426,6 +429,11 @@ extern "C" size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch) {
     return carve(e->d, batch_pad(batch), nullptr).total;
 }
 
+static int attn_xmode() {
+    static const int x = getenv("SCD_ATTN_X") ? atoi(getenv("SCD_ATTN_X")) : 0;   // timing ablations only
+    return x;
+}
+
 static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t st) {
     const scd_encoder_desc& d = e->d;
     const long long rows = (long long)bp * d.tokens;
@@ -438,8 +446,8 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t 
         int rc = scd_gemm_launch(w.y, (const half_t*)lw[L_QKV_W], (const float*)lw[L_QKV_B], nullptr, w.qkv, rows, 3 * d.width,
                                  d.width, SCD_ACT_NONE, st);
         if (rc) return rc;
-        if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal);
-        else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal);
+        if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
+        else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
                              SCD_ACT_NONE, st);
         if (rc) return rc;

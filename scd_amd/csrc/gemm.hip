@@ -130,71 +130,89 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const half_t* __restrict_
 
 
 // ------------------------------------------------------------------------------------------------
-// v2: persistent 256x256x64 kernel.  8 waves (2 m x 4 n), wave tile 128(m) x 64(n) = 4x2 MFMA tiles (128 accumulator
-// registers), LDS-DMA staging (global_load_lds, 16 B/lane) into a 2-stage ring of [A 256x64 | W 256x64] = 64 KB per stage.
-// A block owns a contiguous run of output tiles (n fastest) and runs ONE flattened software pipeline over
-// (tile, k-step): the loads of step s+1 are issued right after the barrier that opens step s, so they fly during the
-// 32 MFMAs/wave of step s, also across tile boundaries - a tile's epilogue overlaps the next tile's first loads.
-// LDS-DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
-// address and again on the ds_read side (same involution on both).
+// Persistent LDS-DMA kernel, block tile BM(m) x 256(n), k consumed in 32-deep sub-steps.
+//   BM = 256: 8 waves (2 m x 4 n), 4-slot ring (128 KB) + 8 x 4 KB epilogue patches: one block per CU.
+//   BM = 128: 4 waves (1 m x 4 n), 3-slot ring (72 KB)  + 4 x 2 KB epilogue patches: TWO independent blocks per CU, so one
+//             block's barrier waits / epilogue VALU overlap the other block's MFMAs (the two waves sharing a SIMD belong to
+//             different blocks and are not in lockstep).
+// Wave tile 128(m) x 64(n) = 4x2 v_mfma_f32_32x32x16_f16 tiles (128 accumulator registers).  Operands are staged with
+// global_load_lds (16 B/lane, LDS-DMA): LDS rows are 64 B (32 k) and the 16-B chunk index is XORed with (row>>2)&3 - on the
+// per-lane SOURCE address for the DMA (its LDS destination is linear) and again on the ds_read_b128 side - which keeps the
+// fragment reads bank-conflict-free.  A block walks its tiles as ONE flattened software pipeline over (tile, sub-step):
+// the DMAs of sub-step s+NSLOT-1 are issued after the barrier in the middle of sub-step s (which also publishes slot
+// s+1), waits are counted (s_waitcnt vmcnt(N)) so DMAs and the epilogue's stores stay in flight across barriers, and the
+// fragment reads of an MFMA group are issued one group ahead.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                      const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                      half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles, int xmode, int ng) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 x (32 KB A + 32 KB W) + 8 x 4 KB epilogue patches
+template <int BM, int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ void __launch_bounds__(BM * 2, 2) gemm_dma_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                          const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                          half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
+                                                          int xmode, int ng) {
+    constexpr int NW = BM / 32;                       // waves: 8 or 4
+    constexpr int NSLOT = BM == 256 ? 4 : 3;
+    constexpr int SLOT = BM * 64 + 16384;             // A sub-tile [BM][32] + W sub-tile [256][32], fp16
+    constexpr int WG = 256 / NW / 16;                 // W DMAs per wave per sub-step (2 or 4); A: always 2
+    constexpr int G = 2 + WG;                         // DMAs per wave per sub-step
+    constexpr int PATCH = BM == 256 ? 4096 : 2048;    // per-wave epilogue patch
+    constexpr int NST = BM == 256 ? 16 : 16;          // epilogue stores per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = BM == 256 ? wave >> 2 : 0, wn = wave & 3;
     const int nk = K >> 5;
     // tile order: n-tiles are grouped (ng per group) and a group is swept over ALL m-tiles before the next one, so the
-    // group's W panels stay resident in the XCD's L2 while the activation panels stream through exactly once per group
+    // group's W panels stay resident in the XCD's L2 while the activation panels stream through once per group
     const int tiles_m = total_tiles / tiles_n;
     const int per_group = tiles_m * ng;
     auto tile_mn = [&](int t, int& bm, int& bn) {
         const int g = t / per_group;
         const int local = t - g * per_group;
         const int n0 = g * ng;
-        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;       // width of this (possibly last, narrower) group
+        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;
         bm = local / w;
         bn = n0 + local - bm * w;
     };
-    // Tile schedule for L2 locality: blocks b and b+8 share an XCD (round-robin dispatch).  XCD x owns the contiguous
-    // tile range [x*T/8, (x+1)*T/8) (n fastest) and its resident blocks take tiles round-robin, so that at any time the
-    // blocks of one XCD hold ~32 CONSECUTIVE tiles: a handful of A row-panels x all W column-panels, swept through k in
-    // lockstep -> each k-slab is fetched into that XCD's L2 once and then hit by the other blocks that share it.
+    // blocks b and b+8 share an XCD (round-robin dispatch): XCD x owns the contiguous tile range [x*T/8, (x+1)*T/8) and
+    // its resident blocks take tiles round-robin, so at any time the blocks of one XCD hold consecutive tiles and sweep k
+    // together: a k-slab is fetched into that XCD's L2 once and then hit by the blocks that share it.
     const int nxcd = gridDim.x >= 8 ? 8 : 1;
-    const int xcd = blockIdx.x % nxcd, slot = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
+    const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
     const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
-    const int tb = c0 + slot;
+    const int tb = c0 + slot_id;
     const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
     const int steps = my_tiles * nk;
     if (steps <= 0) return;
     const int tstride = per_xcd;
 
-    // 64-byte LDS rows (32 k): 16-B chunk XOR ((row>>2)&3) keeps the ds_read_b128 fragment reads conflict-free.
-    // per-lane source offsets of the 2 row groups this wave stages per operand (rows wave*32 + p*16 + lane/4)
+    // per-lane source offsets: a DMA instruction covers 16 rows x 64 B; lane -> (row lane/4, physical chunk lane%4)
     const int lrow = lane >> 2, pc = lane & 3;
-    int src_off[2];
+    int a_off[2], w_off[WG];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int rowl = wave * 32 + p * 16 + lrow;
-        src_off[p] = rowl * K + ((pc ^ ((rowl >> 2) & 3)) << 3);
+        a_off[p] = rowl * K + ((pc ^ ((rowl >> 2) & 3)) << 3);
+    }
+#pragma unroll
+    for (int p = 0; p < WG; ++p) {
+        const int rowl = wave * (16 * WG) + p * 16 + lrow;
+        w_off[p] = rowl * K + ((pc ^ ((rowl >> 2) & 3)) << 3);
     }
     auto issue = [&](int tile, int kt, int slot) {
         int bm, bn;
         tile_mn(tile, bm, bn);
-        const half_t* ga = A + (size_t)bm * 256 * K + kt * 32;
+        if (xmode & 4) { bm = 0; bn = 0; }          // timing ablation: every block streams the same (L2-resident) panels
+        const half_t* ga = A + (size_t)bm * BM * K + kt * 32;
         const half_t* gw = W + (size_t)bn * 256 * K + kt * 32;
-        char* sa = smem + slot * 32768 + wave * 2048;
-        char* sw = sa + 16384;
+        char* sa = smem + slot * SLOT + wave * 2048;
+        char* sw = smem + slot * SLOT + BM * 64 + wave * (1024 * WG);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_global_load_lds((const void*)(ga + src_off[p]), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)(gw + src_off[p]), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
-        }
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((const void*)(ga + a_off[p]), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < WG; ++p)
+            __builtin_amdgcn_global_load_lds((const void*)(gw + w_off[p]), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
     };
     auto off32 = [](int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
 
@@ -206,48 +224,52 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[j][i][q] = 0.f;
 
-    // flattened pipeline over (tile, 32-deep k sub-step): 4-slot ring, 3 sub-tiles (12 LDS-DMA per wave) in flight
-    int tile = (int)tb, kt = 0;          // sub-step being computed
+    int tile = tb, kt = 0;               // sub-step being computed
     int ntile = tile, nkt = 0;           // sub-step being loaded
 #pragma unroll
-    for (int pre = 0; pre < 3; ++pre) {
+    for (int pre = 0; pre < NSLOT - 1; ++pre) {
         if (pre < steps) issue(ntile, nkt, pre);
         if (++nkt == nk) { nkt = 0; ntile += tstride; }
     }
-    int store_age = 4;                   // iterations since the last epilogue issued its 16 stores
+    int store_age = 8;                   // sub-steps since the last epilogue issued its NST stores
     half8 rpre[4];                       // residual rows of the next epilogue block, prefetched under the MFMAs
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
 
-    // Fragment registers: F0 feeds the first 8 MFMAs of a sub-step (k16 group 0), F1 the second 8 (group 1).  The LDS
-    // reads of a group are issued one MFMA group ahead, and the wait+barrier that publishes slot s+1 sits in the MIDDLE
-    // of sub-step s, so a staged slot is first read half a sub-step after the barrier that retired its DMAs.
+    // F0 feeds the first 8 MFMAs of a sub-step (k16 group 0), F1 the second 8 (group 1)
     half8 f0w[2], f0a[4], f1w[2], f1a[4];
     const int rw0 = wn * 64 + r, ra0 = wm * 128 + r;
     auto rd = [&](const char* slot, int k16, half8 (&fw)[2], half8 (&fa)[4]) {
         const char* la = slot;
-        const char* lw = slot + 16384;
+        const char* lw = slot + BM * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[j] = *(const half8*)(lw + off32(rw0 + j * 32, 2 * k16 + hh));
 #pragma unroll
         for (int i = 0; i < 4; ++i) fa[i] = *(const half8*)(la + off32(ra0 + i * 32, 2 * k16 + hh));
     };
-    // slot 0 must be visible before the first fragment reads
-    if (steps > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slot 0 must be visible before the first fragment reads: at most NSLOT-2 younger sub-tiles may still fly
+    if (steps >= NSLOT - 1) {
+        if (NSLOT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (WG == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     rd(smem, 0, f0w, f0a);
+    int cslot = 0;                       // ring slot of sub-step s
     for (int s = 0; s < steps; ++s) {
-        const char* cur = smem + (s & 3) * 32768;
+        const char* cur = smem + cslot * SLOT;
+        const int nslot = cslot + 1 == NSLOT ? 0 : cslot + 1;
         if (HAS_RES && kt == nk - 2) {     // residual rows of epilogue block i=0: two sub-steps of MFMAs hide the latency
             int bm, bn;
             tile_mn(tile, bm, bn);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
+                rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
         }
         rd(cur, 1, f1w, f1a);                                  // group 1 of this sub-step, overlaps the MFMAs below
         __builtin_amdgcn_s_setprio(1);
@@ -256,31 +278,43 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0w[j], f0a[i], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        // publish slot s+1: everything younger than its DMAs (1 sub-tile = 4 DMAs, + 16 epilogue stores if recent) may fly
+        // publish slot s+1.  In flight at this point (oldest first): DMAs(s+1) .. DMAs(s+NSLOT-2), and the epilogue's
+        // NST stores if they were issued after DMAs(s+1): everything younger than DMAs(s+1) may keep flying.
         if (s + 1 < steps) {
-            if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (s + NSLOT - 2 >= steps) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (NSLOT == 4) {
+                if (store_age < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // 4 + 16
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                if (store_age < 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // 0 + 16
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         ++store_age;
-        __builtin_amdgcn_s_barrier();    // slot s+1 visible to all waves; slot (s+3)&3 == (s-1)&3 is free again
+        __builtin_amdgcn_s_barrier();    // slot s+1 visible to all waves; the slot of sub-step s-1 is free again
         asm volatile("" ::: "memory");
-        if (s + 3 < steps && !((xmode & 1) && s >= 2)) issue(ntile, nkt, (s + 3) & 3);
+        if (s + NSLOT - 1 < steps && !((xmode & 1) && s >= 2)) {
+            int ls = cslot + NSLOT - 1;
+            if (ls >= NSLOT) ls -= NSLOT;
+            issue(ntile, nkt, ls);
+        }
         if (++nkt == nk) { nkt = 0; ntile += tstride; }
-        if (s + 1 < steps) rd(smem + ((s + 1) & 3) * 32768, 0, f0w, f0a);     // group 0 of the next sub-step
+        if (s + 1 < steps) rd(smem + nslot * SLOT, 0, f0w, f0a);     // group 0 of the next sub-step
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1w[j], f1a[i], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        cslot = nslot;
         if (++kt == nk) {
-            // epilogue of this tile (the next tile's first loads are already in flight).  The accumulators are
-            // transposed through a per-wave LDS patch [32 m][64 n] fp16 (128-B rows, 16-B chunks XOR (row&7)) so that
-            // every global store instruction writes 8 full 128-byte row segments instead of 32 16-byte pieces.
+            // epilogue of this tile (the next tile's first DMAs are already in flight).  The accumulators are transposed
+            // through a per-wave LDS patch so that global stores write whole row segments (128 B for BM=256, 64 B for
+            // BM=128) instead of 32 16-byte pieces; the residual is added after the transpose from prefetched rows.
             int bm, bn;
             tile_mn(tile, bm, bn);
-            char* ep = smem + 131072 + wave * 4096;
+            char* ep = smem + NSLOT * SLOT + wave * PATCH;
             const int nb0 = bn * 256 + wn * 64;
             f32x4 bq[2][4];
             if (HAS_BIAS) {
@@ -294,42 +328,76 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        half4 o;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            float v = acc[j][i][4 * g + q4];
-                            if (HAS_BIAS) v += bq[j][g][q4];
-                            o[q4] = (half_t)act_apply(v, ACT);
-                            acc[j][i][4 * g + q4] = 0.f;
-                        }
-                        *(half4*)(ep + r * 128 + (((j * 4 + g) ^ (r & 7)) << 4) + hh * 8) = o;
-                    }
-                }
                 half8 rcur[4];
 #pragma unroll
                 for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
                 if (HAS_RES && i < 3) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        rpre[p] = *(const half8*)(R + ((size_t)bm * 256 + wm * 128 + (i + 1) * 32 + p * 8 + (lane >> 3)) * N + nb0 + (lane & 7) * 8);
+                        rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (i + 1) * 32 + p * 8 + (lane >> 3)) * N + nb0 + (lane & 7) * 8);
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (BM == 256) {
+                    // patch [32 m][64 n] fp16, 128-B rows, 16-B chunk XOR (row&7)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int rr = p * 8 + (lane >> 3), cc = lane & 7;
-                    half8 h = *(const half8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
-                    const size_t off = ((size_t)bm * 256 + wm * 128 + i * 32 + rr) * N + nb0 + cc * 8;
-                    if (HAS_RES) {
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) h[q] = (half_t)((float)h[q] + (float)rcur[p][q]);
+                        for (int g = 0; g < 4; ++g) {
+                            half4 o;
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                float v = acc[j][i][4 * g + q4];
+                                if (HAS_BIAS) v += bq[j][g][q4];
+                                o[q4] = (half_t)act_apply(v, ACT);
+                                acc[j][i][4 * g + q4] = 0.f;
+                            }
+                            *(half4*)(ep + r * 128 + (((j * 4 + g) ^ (r & 7)) << 4) + hh * 8) = o;
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int rr = p * 8 + (lane >> 3), cc = lane & 7;
+                        half8 h = *(const half8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                        const size_t off = ((size_t)bm * BM + wm * 128 + i * 32 + rr) * N + nb0 + cc * 8;
+                        if (HAS_RES) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) h[q] = (half_t)((float)h[q] + (float)rcur[p][q]);
+                        }
+                        if (!(xmode & 2)) *(half8*)(C + off) = h;
                     }
-                    if (!(xmode & 2)) *(half8*)(C + off) = h;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    // 2 KB patch: one [32 m][32 n] MFMA tile at a time, 64-B rows, 16-B chunk XOR ((row>>1)&3)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            half4 o;
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                float v = acc[j][i][4 * g + q4];
+                                if (HAS_BIAS) v += bq[j][g][q4];
+                                o[q4] = (half_t)act_apply(v, ACT);
+                                acc[j][i][4 * g + q4] = 0.f;
+                            }
+                            *(half4*)(ep + r * 64 + ((g ^ ((r >> 1) & 3)) << 4) + hh * 8) = o;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const int rr = p * 16 + (lane >> 2), cc = lane & 3;
+                            half8 h = *(const half8*)(ep + rr * 64 + ((cc ^ ((rr >> 1) & 3)) << 4));
+                            const size_t off = ((size_t)bm * BM + i * 32 + rr) * N + nb0 + j * 32 + cc * 8;
+                            if (HAS_RES) {
+                                // rcur rows are laid out for the 128-B pattern (row p*8 + lane/8, chunk lane%8): re-read directly
+                                const half8 rres = *(const half8*)(R + off);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) h[q] = (half_t)((float)h[q] + (float)rres[q]);
+                            }
+                            if (!(xmode & 2)) *(half8*)(C + off) = h;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             kt = 0;
             tile += tstride;
@@ -338,16 +406,18 @@ __global__ void __launch_bounds__(512) gemm256_kernel(const half_t* __restrict__
     }
 }
 
-template <int ACT, bool B, bool RR>
-static int launch256(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
-                     hipStream_t st) {
+template <int BM, int ACT, bool B, bool RR>
+static int launch_dma(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                      hipStream_t st) {
+    constexpr int LDS = BM == 256 ? 4 * (256 * 64 + 16384) + 8 * 4096 : 3 * (128 * 64 + 16384) + 4 * 2048;   // 160 KB / 80 KB
     static bool attr = false;
     if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        SCD_HIP(hipFuncSetAttribute((const void*)gemm_dma_kernel<BM, ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int tiles_n = N / 256, total = (M / 256) * tiles_n;
-    const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
+    const int tiles_n = N / 256, total = (M / BM) * tiles_n;
+    const int resident = BM == 256 ? 256 : 512;
+    const int grid = total < resident ? (total >= 8 ? total / 8 * 8 : total) : resident;
     static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
     static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
     // n-tiles per group: W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
@@ -359,23 +429,30 @@ static int launch256(const half_t* A, const half_t* W, const float* bias, const 
         for (int groups = 1; groups <= tiles_n; ++groups) {
             const int cand = (tiles_n + groups - 1) / groups;
             const double wg = cand * panel;
-            const double rounds = (double)total / 256.0;                      // tile rounds per resident block
+            const double rounds = (double)total / resident;
             const double w_traffic = wg <= 2.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
             const double cost = groups * a_bytes + w_traffic;
             if (cost < best) { best = cost; ng = cand; }
         }
         if (ng_env > 0) ng = ng_env < tiles_n ? ng_env : tiles_n;
     }
-    gemm256_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+    gemm_dma_kernel<BM, ACT, B, RR><<<grid, BM * 2, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
     return SCD_OK;
 }
-template <int ACT>
-static int launch256_act(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
-                         hipStream_t st) {
-    if (bias && R) return launch256<ACT, true, true>(A, W, bias, R, C, M, N, K, st);
-    if (bias) return launch256<ACT, true, false>(A, W, bias, R, C, M, N, K, st);
-    if (R) return launch256<ACT, false, true>(A, W, bias, R, C, M, N, K, st);
-    return launch256<ACT, false, false>(A, W, bias, R, C, M, N, K, st);
+template <int BM, int ACT>
+static int launch_dma_act(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                          hipStream_t st) {
+    if (bias && R) return launch_dma<BM, ACT, true, true>(A, W, bias, R, C, M, N, K, st);
+    if (bias) return launch_dma<BM, ACT, true, false>(A, W, bias, R, C, M, N, K, st);
+    if (R) return launch_dma<BM, ACT, false, true>(A, W, bias, R, C, M, N, K, st);
+    return launch_dma<BM, ACT, false, false>(A, W, bias, R, C, M, N, K, st);
+}
+template <int BM>
+static int launch_dma_bm(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                         int act, hipStream_t st) {
+    if (act == SCD_ACT_NONE) return launch_dma_act<BM, SCD_ACT_NONE>(A, W, bias, R, C, M, N, K, st);
+    if (act == SCD_ACT_QUICKGELU) return launch_dma_act<BM, SCD_ACT_QUICKGELU>(A, W, bias, R, C, M, N, K, st);
+    return launch_dma_act<BM, SCD_ACT_GELU>(A, W, bias, R, C, M, N, K, st);
 }
 
 template <int ACT>
@@ -394,13 +471,13 @@ int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const h
     SCD_REQUIRE(M > 0 && M % 128 == 0 && N > 0 && N % 128 == 0 && K > 0 && K % 64 == 0 && M < (1ll << 31),
                 "gemm: shape m=%lld n=%d k=%d must be multiples of 128/128/64", (long long)M, N, K);
     SCD_REQUIRE(C != (half_t*)A, "gemm: C must not alias A");
-    static const bool force128 = getenv("SCD_GEMM128") != nullptr;
-    if (M % 256 == 0 && N % 256 == 0 && !force128) {
-        int rc;
-        if (act == SCD_ACT_NONE) rc = launch256_act<SCD_ACT_NONE>(A, W, bias, R, C, (int)M, N, K, st);
-        else if (act == SCD_ACT_QUICKGELU) rc = launch256_act<SCD_ACT_QUICKGELU>(A, W, bias, R, C, (int)M, N, K, st);
-        else if (act == SCD_ACT_GELU) rc = launch256_act<SCD_ACT_GELU>(A, W, bias, R, C, (int)M, N, K, st);
-        else SCD_REQUIRE(false, "gemm: bad activation %d", act);
+    SCD_REQUIRE(act == SCD_ACT_NONE || act == SCD_ACT_QUICKGELU || act == SCD_ACT_GELU, "gemm: bad activation %d", act);
+    static const int force = getenv("SCD_GEMM_TILE") ? atoi(getenv("SCD_GEMM_TILE")) : 0;    // 64 -> legacy 128x128 kernel
+    if (N % 256 == 0 && force != 64) {
+        int rc = -1;
+        // BM=256 (one 8-wave block per CU) measures a few % ahead of BM=128 (two 4-wave blocks per CU) on the ViT shapes
+        if (M % 256 == 0 && force != 128) rc = launch_dma_bm<256>(A, W, bias, R, C, (int)M, N, K, act, st);
+        else rc = launch_dma_bm<128>(A, W, bias, R, C, (int)M, N, K, act, st);
         if (rc) return rc;
         SCD_LAUNCH_CHECK();
         return SCD_OK;
