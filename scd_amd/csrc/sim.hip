@@ -27,20 +27,42 @@ __device__ __forceinline__ void topm_insert(float (&lv)[TOPM], int (&li)[TOPM], 
     }
 }
 
-// Block = 4 waves = 128 images; wave w keeps the B fragments (F rows, K <= 512) of its 32 images in
-// registers for the whole kernel and sweeps all vocabulary tiles of 128 names staged through LDS.
+// bf[dc*4 + k16] for a runtime d-chunk dc (0..7) and a compile-time k16: a switch over constants keeps the fragment
+// array in registers (a runtime-indexed array would be demoted to scratch)
+__device__ __forceinline__ half8 bf_sel(const half8 (&bf)[32], int dc, int k16) {
+    switch (dc) {
+        case 0: return bf[0 + k16];
+        case 1: return bf[4 + k16];
+        case 2: return bf[8 + k16];
+        case 3: return bf[12 + k16];
+        case 4: return bf[16 + k16];
+        case 5: return bf[20 + k16];
+        case 6: return bf[24 + k16];
+        default: return bf[28 + k16];
+    }
+}
+
+// Block = 8 waves = 256 images; wave w keeps the B fragments (F rows, K <= 512) of its 32 images in registers for the
+// whole kernel and sweeps the vocabulary in tiles of 128 names.  W^T tiles are streamed by LDS-DMA (global_load_lds,
+// 16 B/lane) in sub-tiles of [128 names][64 d] (128-B rows, 16-B chunk XOR (row>>1)&7 applied to the DMA source address
+// and to the ds_read side) through a 4-slot ring; one flattened software pipeline runs over (tile, d-chunk): the DMAs of
+// sub-step s+3 are issued after the mid-sub-step barrier that publishes slot s+1, waits are counted, fragment reads run
+// one MFMA group ahead (same schedule as gemm_dma_kernel).
 // v_mfma_f32_32x32x16_f16: A[row = name][k] from LDS, B[k][col = image] from registers,
-// D[row = (reg&3)+8(reg>>2)+4h][col = image]: every lane sees 16 logits of ONE image per 32-name block.
+// D[row = (reg&3)+8(reg>>2)+4h][col = image]: every lane sees 16 logits of ONE image per 32-name block, so the
+// running top-8 list, its threshold and the online-softmax statistics are lane-private registers.
+typedef __attribute__((address_space(3))) void* sim_lds_ptr_t;
+
 template <bool SOFTMAX>
-__global__ void __launch_bounds__(256, 1) sim_topk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
+__global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
                                                           long long n, int d, long long v, float scale,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                           float* __restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) char lds[128 * 256];
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 x 16 KB
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const long long img = (long long)blockIdx.x * 128 + wave * 32 + r;
+    const long long img = (long long)blockIdx.x * 256 + wave * 32 + r;
     const long long irow = img < n ? img : n - 1;
     const half_t* frow = F + irow * d + 8 * hh;
 
@@ -63,61 +85,116 @@ __global__ void __launch_bounds__(256, 1) sim_topk_kernel(const half_t* __restri
     }
     float sm_m = -INFINITY, sm_z = 0.f;
 
-    const long long ntiles = (v + 127) / 128;
-    for (long long tile = 0; tile < ntiles; ++tile) {
-        f32x16 acc[4];
+    const int nd = d >> 6;                                  // 64-deep sub-steps per tile
+    const int ntiles = (int)((v + 127) / 128);
+    const int steps = ntiles * nd;
+    // DMA source of this lane: wave w stages rows w*16 .. w*16+15 (2 instructions x 8 rows); lane -> (row lane/8, chunk lane%8)
+    int src_row[2], src_col[2];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+    for (int p = 0; p < 2; ++p) {
+        const int rowl = wave * 16 + p * 8 + (lane >> 3);
+        src_row[p] = rowl;
+        src_col[p] = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+    }
+    auto issue = [&](int tile, int dc, int slot) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+        for (int p = 0; p < 2; ++p) {
+            long long vr = (long long)tile * 128 + src_row[p];
+            vr = vr < v ? vr : v - 1;                        // padded names re-read the last row; masked in the epilogue
+            __builtin_amdgcn_global_load_lds((const void*)(Wt + vr * d + dc * 64 + src_col[p]),
+                                             (sim_lds_ptr_t)(smem + slot * 16384 + wave * 2048 + p * 1024), 16, 0, 0);
+        }
+    };
+    auto off128 = [](int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); };
+
+    f32x16 acc[4];
 #pragma unroll
-        for (int dcs = 0; dcs < 4; ++dcs) {
-            const int dc = dcs * 128;
-            if (dc < d) {
-                __syncthreads();
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    const int row = p * 16 + (tid >> 4);
-                    const int c16 = tid & 15;
-                    long long vr = tile * 128 + row;
-                    vr = vr < v ? vr : v - 1;
-                    const int col = dc + 8 * c16;
-                    const uint4 ld4 = *(const uint4*)(Wt + vr * d + (col < d ? col : 0));     // unconditional, masked below
-                    *(uint4*)(lds + row * 256 + ((c16 ^ (row & 15)) << 4)) = col < d ? ld4 : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+
+    int ntile = 0, ndc = 0;
+#pragma unroll
+    for (int pre = 0; pre < 3; ++pre) {
+        if (pre < steps) issue(ntile, ndc, pre);
+        if (++ndc == nd) { ndc = 0; ++ntile; }
+    }
+    if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    half8 fa[4], fb[4];                                     // two fragment sets, alternating between the four k16 groups
+    auto rd = [&](const char* slot, int k16, half8 (&f)[4]) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) f[cb] = *(const half8*)(slot + off128(cb * 32 + r, 2 * k16 + hh));
+    };
+    auto mm = [&](const half8 (&f)[4], const half8 b) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cb], b, acc[cb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    rd(smem, 0, fa);
+    int s = 0;                                              // flattened sub-step counter (ring slot = s & 3)
+    for (int tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int dcc = 0; dcc < 8; ++dcc) {                 // d-chunk index is a compile-time constant: bf[] stays in registers
+            if (dcc < nd) {
+                const char* cur = smem + (s & 3) * 16384;
+                rd(cur, 1, fb);
+                mm(fa, bf[dcc * 4 + 0]);
+                rd(cur, 2, fa);
+                mm(fb, bf[dcc * 4 + 1]);
+                if (s + 1 < steps) {
+                    if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 }
-                __syncthreads();
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        const int row = cb * 32 + r;
-                        const half8 a = *(const half8*)(lds + row * 256 + (((2 * s + hh) ^ (row & 15)) << 4));
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[dcs * 8 + s], acc[cb], 0, 0, 0);
-                    }
-                }
+                __builtin_amdgcn_s_barrier();               // slot s+1 visible; slot s-1 free
+                asm volatile("" ::: "memory");
+                if (s + 3 < steps) issue(ntile, ndc, (s + 3) & 3);
+                if (++ndc == nd) { ndc = 0; ++ntile; }
+                rd(cur, 3, fb);
+                mm(fa, bf[dcc * 4 + 2]);
+                if (s + 1 < steps) rd(smem + ((s + 1) & 3) * 16384, 0, fa);
+                mm(fb, bf[dcc * 4 + 3]);
+                ++s;
             }
         }
-        const long long vbase = tile * 128 + 4 * hh;
+        {
+            // tile epilogue on UNSCALED dot products (scale > 0 is applied when the lists are written): one max3 tree per
+            // 32-name block decides whether any of its 16 values can enter the list; only the last tile has padded names.
+            const long long vbase = (long long)tile * 128 + 4 * hh;
+            const bool last = tile == ntiles - 1;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            float bm = -INFINITY;
+            for (int cb = 0; cb < 4; ++cb) {
+                if (last) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long long vi = vbase + cb * 32 + (i & 3) + 8 * (i >> 2);
-                const float val = (vi < v) ? acc[cb][i] * scale : -INFINITY;
-                acc[cb][i] = val;
-                if (SOFTMAX) bm = fmaxf(bm, val);
-                if (val > lv[TOPM - 1]) topm_insert(lv, li, val, (int)vi);
-            }
-            if (SOFTMAX) {
-                if (bm > -INFINITY) {
-                    const float mn = fmaxf(sm_m, bm);
-                    float z = sm_z * __expf(sm_m - mn);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) z += __expf(acc[cb][i] - mn);
-                    sm_z = z;
-                    sm_m = mn;
+                    for (int i = 0; i < 16; ++i)
+                        if (vbase + cb * 32 + (i & 3) + 8 * (i >> 2) >= v) acc[cb][i] = -INFINITY;
                 }
+                float bm = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), acc[cb][2]);
+#pragma unroll
+                for (int i = 3; i < 15; i += 2) bm = fmaxf(fmaxf(bm, acc[cb][i]), acc[cb][i + 1]);
+                bm = fmaxf(bm, acc[cb][15]);
+                if (bm > lv[TOPM - 1]) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float val = acc[cb][i];
+                        if (val > lv[TOPM - 1]) topm_insert(lv, li, val, (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2)));
+                    }
+                }
+                if (SOFTMAX) {
+                    if (bm > -INFINITY) {
+                        const float mn = fmaxf(sm_m, bm);
+                        float z = sm_z * __expf((sm_m - mn) * scale);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) z += __expf((acc[cb][i] - mn) * scale);
+                        sm_z = z;
+                        sm_m = mn;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
             }
         }
     }
@@ -126,11 +203,11 @@ __global__ void __launch_bounds__(256, 1) sim_topk_kernel(const half_t* __restri
         int* ci = cand_idx + (img * 2 + hh) * TOPM;
 #pragma unroll
         for (int j = 0; j < TOPM; ++j) {
-            cv[j] = lv[j];
+            cv[j] = lv[j] * scale;
             ci[j] = li[j];
         }
         if (SOFTMAX) {
-            stats[(img * 2 + hh) * 2] = sm_m;
+            stats[(img * 2 + hh) * 2] = sm_m * scale;
             stats[(img * 2 + hh) * 2 + 1] = sm_z;
         }
     }
@@ -138,16 +215,21 @@ __global__ void __launch_bounds__(256, 1) sim_topk_kernel(const half_t* __restri
 
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
 __global__ void __launch_bounds__(256) wmax_kernel(const half_t* __restrict__ Wt, long long v, int d, unsigned* out_bits) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= v) return;
-    float s = 0.f;
-    for (int j = lane; j < d; j += 64) {
-        const float w = (float)Wt[row * d + j];
-        s = fmaf(w, w, s);
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float best = 0.f;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < v; row += (long long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int j = lane * 8; j < d; j += 512) {
+            const half8 w8 = *(const half8*)(Wt + row * d + j);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s = fmaf((float)w8[q], (float)w8[q], s);
+        }
+        best = fmaxf(best, wave_sum_f32(s));
     }
-    s = wave_sum_f32(s);
-    if (lane == 0) atomicMax(out_bits, __float_as_uint(s * 1.0001f));
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f));
 }
 
 struct SimHdr {
@@ -328,9 +410,10 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
                             size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && F && Wt && idx_out && val_out && ws, "scd_sim_topk: null argument");
     SCD_REQUIRE(n > 0 && v > 0 && n < (1ll << 31) && v < (1ll << 31), "scd_sim_topk: bad shape n=%lld v=%lld", (long long)n, (long long)v);
-    SCD_REQUIRE(d > 0 && d <= 512 && d % 16 == 0, "scd_sim_topk: d=%d must be a multiple of 16, <= 512", d);
+    SCD_REQUIRE(d > 0 && d <= 512 && d % 64 == 0, "scd_sim_topk: d=%d must be a multiple of 64, <= 512", d);
     SCD_REQUIRE(k >= 1 && k <= TOPM && k <= v, "scd_sim_topk: k=%d must be in [1,%d] and <= v", k, TOPM);
     SCD_REQUIRE(mode == SCD_SIM_RAW || mode == SCD_SIM_SOFTMAX, "scd_sim_topk: bad mode %d", mode);
+    SCD_REQUIRE(scale > 0.f, "scd_sim_topk: scale must be positive");
     SCD_REQUIRE(ws_bytes >= scd_sim_topk_ws_bytes(n, d, v, k), "scd_sim_topk: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     char* w = (char*)ws;
@@ -343,14 +426,20 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const half_t* f = (const half_t*)F;
     const half_t* wt = (const half_t*)Wt;
     SCD_HIP(hipMemsetAsync(hdr, 0, 64, st));
-    wmax_kernel<<<(unsigned)scd_cdiv(v, 4), 256, 0, st>>>(wt, v, d, &hdr->wmax2_bits);
-    const unsigned g1 = (unsigned)scd_cdiv(n, 128), g2 = (unsigned)scd_cdiv(n, 4);
+    wmax_kernel<<<256, 256, 0, st>>>(wt, v, d, &hdr->wmax2_bits);
+    const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
+    static bool attr = false;
+    if (!attr) {
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr = true;
+    }
     if (mode == SCD_SIM_SOFTMAX) {
-        sim_topk_kernel<true><<<g1, 256, 0, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        sim_topk_kernel<true><<<g1, 512, 65536, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else {
-        sim_topk_kernel<false><<<g1, 256, 0, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        sim_topk_kernel<false><<<g1, 512, 65536, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     }
