@@ -406,6 +406,484 @@ __global__ void __launch_bounds__(BM * 2, 2) gemm_dma_kernel(const half_t* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same block tile / ring / schedule as gemm_dma_kernel<256>, but on v_mfma_f32_16x16x32_f16 (the shape on which gfx950
+// sustains the higher clock under load): a 32-deep sub-step is ONE k-step of 8(m) x 4(n) 16x16 tiles = 32 MFMAs per wave.
+// Fragment (A or B operand): lane l reads row (l&15), 16-B chunk (l>>4) of a 64-B LDS row.  Chunk swizzle
+// pc = chunk ^ ((-(row>>2)) & 3): every ds_read_b128 lane group then touches 16 distinct 16-B slots.
+// MFMA group 0 = m-tiles 0-3, group 1 = m-tiles 4-7; the A fragments of group 1 are read while group 0 computes, and
+// the W + A(0-3) fragments of the next sub-step while group 1 computes.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
+                                                            const float* __restrict__ bias, const half_t* __restrict__ R,
+                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
+                                                            int xmode, int ng) {
+    constexpr int BM = 256, NSLOT = 4, SLOT = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, q16 = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nk = K >> 5;
+    const int tiles_m = total_tiles / tiles_n;
+    const int per_group = tiles_m * ng;
+    auto tile_mn = [&](int t, int& bm, int& bn) {
+        const int g = t / per_group;
+        const int local = t - g * per_group;
+        const int n0 = g * ng;
+        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;
+        bm = local / w;
+        bn = n0 + local - bm * w;
+    };
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
+    const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
+    const int tb = c0 + slot_id;
+    const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
+    const int steps = my_tiles * nk;
+    if (steps <= 0) return;
+    const int tstride = per_xcd;
+
+    auto swz = [](int row) { return (0 - (row >> 2)) & 3; };
+    const int lrow = lane >> 2, pc = lane & 3;
+    int a_off[2], w_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int rowl = wave * 32 + p * 16 + lrow;
+        a_off[p] = rowl * K + ((pc ^ swz(rowl)) << 3);
+        w_off[p] = a_off[p];
+    }
+    auto issue = [&](int tile, int kt, int slot) {
+        int bm, bn;
+        tile_mn(tile, bm, bn);
+        if (xmode & 4) { bm = 0; bn = 0; }
+        const half_t* ga = A + (size_t)bm * BM * K + kt * 32;
+        const half_t* gw = W + (size_t)bn * 256 * K + kt * 32;
+        char* sa = smem + slot * SLOT + wave * 2048;
+        char* sw = sa + 16384;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const void*)(ga + a_off[p]), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(gw + w_off[p]), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
+        }
+    };
+    // fragment byte offsets inside a sub-tile: rows (base + 16*t + c16), chunk q16
+    int offw[4], offa[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = wn * 64 + t * 16 + c16;
+        offw[t] = 16384 + row * 64 + ((q16 ^ swz(row)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = wm * 128 + t * 16 + c16;
+        offa[t] = row * 64 + ((q16 ^ swz(row)) << 4);
+    }
+
+    f32x4v acc[4][8];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[tn][tm][q] = 0.f;
+
+    int tile = tb, kt = 0, ntile = tb, nkt = 0;
+#pragma unroll
+    for (int pre = 0; pre < NSLOT - 1; ++pre) {
+        if (pre < steps) issue(ntile, nkt, pre);
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+    }
+    int store_age = 8;
+    half8 rpre[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
+
+    half8 fw[4], fa_lo[4], fa_hi[4], fwn[4];
+    if (steps >= NSLOT - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        fw[t] = *(const half8*)(smem + offw[t]);
+        fa_lo[t] = *(const half8*)(smem + offa[t]);
+    }
+    int cslot = 0;
+    for (int s = 0; s < steps; ++s) {
+        const char* cur = smem + cslot * SLOT;
+        const int nslot = cslot + 1 == NSLOT ? 0 : cslot + 1;
+        if (HAS_RES && kt == nk - 2) {
+            int bm, bn;
+            tile_mn(tile, bm, bn);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fa_hi[t] = *(const half8*)(cur + offa[4 + t]);          // m-tiles 4-7 of this sub-step
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa_lo[tm], acc[tn][tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (s + 1 < steps) {
+            if (s + NSLOT - 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        ++store_age;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NSLOT - 1 < steps && !((xmode & 1) && s >= 2)) {
+            int ls = cslot + NSLOT - 1;
+            if (ls >= NSLOT) ls -= NSLOT;
+            issue(ntile, nkt, ls);
+        }
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+        if (s + 1 < steps) {
+            const char* nx = smem + nslot * SLOT;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fwn[t] = *(const half8*)(nx + offw[t]);
+                fa_lo[t] = *(const half8*)(nx + offa[t]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+                acc[tn][4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa_hi[tm], acc[tn][4 + tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fw[t] = fwn[t];
+        cslot = nslot;
+        if (++kt == nk) {
+            // epilogue: D tile (tn, tm): lane (c16 = m column, q16) holds n = tn*16 + q16*4 + 0..3.  Per 32-row m block
+            // (two m-tiles) the values go through a per-wave LDS patch [32 m][64 n] fp16 (128-B rows, chunk XOR row&7)
+            // and leave as whole 128-byte row segments.
+            int bm, bn;
+            tile_mn(tile, bm, bn);
+            char* ep = smem + NSLOT * SLOT + wave * 4096;
+            const int nb0 = bn * 256 + wn * 64;
+            f32x4v bq[4];
+            if (HAS_BIAS) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);
+                    bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                half8 rcur[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
+                if (HAS_RES && i < 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (i + 1) * 32 + p * 8 + (lane >> 3)) * N + nb0 + (lane & 7) * 8);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = h * 16 + c16;
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        half4 o;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            float v = acc[tn][2 * i + h][q4];
+                            if (HAS_BIAS) v += bq[tn][q4];
+                            o[q4] = (half_t)act_apply(v, ACT);
+                            acc[tn][2 * i + h][q4] = 0.f;
+                        }
+                        *(half4*)(ep + row * 128 + (((tn * 2 + (q16 >> 1)) ^ (row & 7)) << 4) + (q16 & 1) * 8) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int rr = p * 8 + (lane >> 3), cc = lane & 7;
+                    half8 hv = *(const half8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
+                    const size_t off = ((size_t)bm * BM + wm * 128 + i * 32 + rr) * N + nb0 + cc * 8;
+                    if (HAS_RES) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)((float)hv[q] + (float)rcur[p][q]);
+                    }
+                    if (!(xmode & 2)) *(half8*)(C + off) = hv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            kt = 0;
+            tile += tstride;
+            store_age = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Four-wave variant: the same 256x256 block tile, ring and schedule, but each wave owns a 128(m) x 128(n) sub-tile, one wave
+// per SIMD, the 256 accumulator registers in AGPRs.  LDS reads drop to 16 fragments per 64 MFMAs (8-wave kernel: 12 per
+// 32), which matters because LDS bandwidth (ring fills + fragment reads) is what bounds the 8-wave kernel.
+template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
+               const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
+               int xmode, int ng) {
+    constexpr int BM = 256, BN = 32 * NT, NSLOT = 4, SLOT = 16384 + BN * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, q16 = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = K >> 5;
+    const int tiles_m = total_tiles / tiles_n;
+    const int per_group = tiles_m * ng;
+    auto tile_mn = [&](int t, int& bm, int& bn) {
+        const int g = t / per_group;
+        const int local = t - g * per_group;
+        const int n0 = g * ng;
+        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;
+        bm = local / w;
+        bn = n0 + local - bm * w;
+    };
+    const int nxcd = gridDim.x >= 8 ? 8 : 1;
+    const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
+    const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
+    const int tb = c0 + slot_id;
+    const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
+    const int steps = my_tiles * nk;
+    if (steps <= 0) return;
+    const int tstride = per_xcd;
+
+    auto swz = [](int row) { return (0 - (row >> 2)) & 3; };
+    const int lrow = lane >> 2, pc = lane & 3;
+    const int rowl0 = wave * 64 + lrow;
+    const int g_off0 = rowl0 * K + ((pc ^ swz(rowl0)) << 3);
+    const int roww0 = wave * (BN / 4) + lrow;
+    const int g_offw = roww0 * K + ((pc ^ swz(roww0)) << 3);
+    const int k16 = 16 * K;
+    auto issue = [&](int tile, int kt, int slot) {
+        int bm, bn;
+        tile_mn(tile, bm, bn);
+        if (xmode & 4) { bm = 0; bn = 0; }
+        const half_t* ga = A + (size_t)bm * BM * K + kt * 32 + g_off0;
+        const half_t* gw = W + (size_t)bn * BN * K + kt * 32 + g_offw;
+        char* sa = smem + slot * SLOT + wave * 4096;
+        char* sw = smem + slot * SLOT + 16384 + wave * (BN * 16);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((const void*)(ga + p * k16), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < NT / 2; ++p) __builtin_amdgcn_global_load_lds((const void*)(gw + p * k16), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
+    };
+    const int rw = wn * (NT * 16) + c16, ra = wm * 128 + c16;
+    const int offw0 = 16384 + rw * 64 + ((q16 ^ swz(rw)) << 4);   // tile t: + t * 1024 (the swizzle term does not change)
+    const int offa0 = ra * 64 + ((q16 ^ swz(ra)) << 4);
+
+    int tile = tb, ntile = tb, nkt = 0;
+#pragma unroll
+    for (int pre = 0; pre < NSLOT - 1; ++pre) {
+        if (pre < steps) issue(ntile, nkt, pre);
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+    }
+    int store_age = 8;
+    half8 rpre[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
+
+    half8 fwA[NT], fwB[NT], a01[2], a23[2], a45[2], a67[2];
+    // The hot loop is hand-scheduled: MFMAs, fragment reads and their waits are inline asm.
+    //  * MFMAs with the accumulators pinned to AGPRs ("a" constraints) - left to itself hipcc keeps copying the 256 accumulator
+    //    registers between AGPRs and VGPRs around every group.  Z = 1 is the first sub-step of a tile: C = 0, so the
+    //    accumulators are never zeroed.  No compiler hazard NOPs exist after an asm MFMA: s_nop before the epilogue reads them
+    //    back (explicit v_accvgpr_read).
+    //  * ds_read_b128 + counted lgkmcnt: for asm operands hipcc only ever emits lgkmcnt(0), which would serialise the
+    //    read-ahead.  lgkmcnt retires in order, so "all but the newest N" is exact.
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define W4_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
+    if (steps >= NSLOT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + NT / 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const unsigned aw = sbase + offw0, aa = sbase + offa0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) W4_RD(fwA[t], aw, t * 1024);
+        W4_RD(a01[0], aa, 0);
+        W4_RD(a01[1], aa, 1024);
+    }
+    int cslot = 0, s = 0;
+#define W4_GROUP(FW, FA, TM0, Z)                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int tn = 0; tn < NT; ++tn) {              \
+        if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][(TM0) + j]) : "v"(FW[tn]), "v"(FA[j]));   \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][(TM0) + j]) : "v"(FW[tn]), "v"(FA[j]));    \
+    }
+    // one 32-deep sub-step: 4 MFMA groups of 2 m-tiles x NT n-tiles; the A fragments of the next group are read while the
+    // current one computes, the ring wait + barrier + refill sit between groups 1 and 2, and the W / first A fragments of
+    // the NEXT sub-step (FWN) are read under group 3.  On entry FWC and a01 are in flight (NT + 2 reads).
+#define W4_SUBSTEP(FWC, FWN, Z)                                                                                   \
+    {                                                                                                            \
+        const unsigned cur = sbase + cslot * SLOT + offa0;                                                       \
+        const int nslot = cslot + 1 == NSLOT ? 0 : cslot + 1;                                                    \
+        W4_RD(a23[0], cur, 2 * 1024);                                                                            \
+        W4_RD(a23[1], cur, 3 * 1024);                                                                            \
+        W4_LGKM(2);                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        W4_GROUP(FWC, a01, 0, Z)                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        W4_RD(a45[0], cur, 4 * 1024);                                                                            \
+        W4_RD(a45[1], cur, 5 * 1024);                                                                            \
+        W4_LGKM(2);                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        W4_GROUP(FWC, a23, 2, Z)                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        if (s + 1 < steps) {                                                                                     \
+            if (s + NSLOT - 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         \
+            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(36 + NT / 2) : "memory");           \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NT / 2) : "memory");                               \
+        }                                                                                                        \
+        ++store_age;                                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                            \
+        asm volatile("" ::: "memory");                                                                           \
+        if (s + NSLOT - 1 < steps && !((xmode & 1) && s >= 2)) {                                                 \
+            int ls = cslot + NSLOT - 1;                                                                          \
+            if (ls >= NSLOT) ls -= NSLOT;                                                                        \
+            issue(ntile, nkt, ls);                                                                               \
+        }                                                                                                        \
+        if (++nkt == nk) { nkt = 0; ntile += tstride; }                                                          \
+        W4_RD(a67[0], cur, 6 * 1024);                                                                            \
+        W4_RD(a67[1], cur, 7 * 1024);                                                                            \
+        W4_LGKM(2);                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        W4_GROUP(FWC, a45, 4, Z)                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        {                                                                                                        \
+            const unsigned nw = sbase + nslot * SLOT + offw0; /* past the last step: a stale slot, values unused */ \
+            const unsigned na = sbase + nslot * SLOT + offa0;                                                    \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) W4_RD(FWN[t], nw, t * 1024);                          \
+            W4_RD(a01[0], na, 0);                                                                                \
+            W4_RD(a01[1], na, 1024);                                                                             \
+        }                                                                                                        \
+        W4_LGKM(NT + 2);                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        W4_GROUP(FWC, a67, 6, Z)                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        cslot = nslot;                                                                                           \
+        ++s;                                                                                                     \
+    }
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int bm, bn;
+        tile_mn(tile, bm, bn);
+        const int nb0 = bn * BN + wn * (NT * 16);
+        const int c16r = (NT < 8 && c16 >= NT * 2) ? 0 : c16;   // lanes past the tile's 32*NT columns only shadow lane 0's loads
+        f32x4v acc[NT][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
+        f32x4v bq[NT];
+        // bias and the first residual rows are fetched one sub-step before the tile ends: a plain load issued in the epilogue
+        // would sit behind the ring refills in the (in-order) vmcnt queue and stall on them.
+#define W4_PRE()                                                                                                 \
+    {                                                                                                            \
+        if (HAS_RES) {                                                                                           \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) rpre[p] =                                              \
+                *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 4 + q16) * N + nb0 + c16r * 8);            \
+        }                                                                                                        \
+        if (HAS_BIAS) {                                                                                          \
+            _Pragma("unroll") for (int tn = 0; tn < NT; ++tn) {                                                  \
+                const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);                              \
+                bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;                          \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+        W4_SUBSTEP(fwA, fwB, 1)
+        if (nk == 2) W4_PRE()
+        W4_SUBSTEP(fwB, fwA, 0)
+        for (int kt = 2; kt < nk; kt += 2) {
+            W4_SUBSTEP(fwA, fwB, 0)
+            if (kt == nk - 2) W4_PRE()
+            W4_SUBSTEP(fwB, fwA, 0)
+        }
+#undef W4_PRE
+        W4_LGKM(0);                                            // next tile's first fragments (read under the last group)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read
+        {
+            // epilogue, one 16-row m-tile at a time through a per-wave LDS patch [16 m][128 n] fp16 (256-B rows, chunk XOR row):
+            // lane (c16 = m, q16) holds n = tn*16 + q16*4 + 0..3; rows leave as whole 256-byte segments.
+            char* ep = smem + NSLOT * SLOT + wave * 4096;
+#pragma unroll
+            for (int tm = 0; tm < 8; ++tm) {
+                half8 rcur[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
+                if (HAS_RES && tm < 7) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + 1) * 16 + p * 4 + q16) * N + nb0 + c16r * 8);
+                }
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) {
+                    half4 o;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float v;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[tn][tm][q4]));
+                        if (HAS_BIAS) v += bq[tn][q4];
+                        o[q4] = (half_t)act_apply(v, ACT);
+                    }
+                    *(half4*)(ep + c16 * 256 + (((tn * 2 + (q16 >> 1)) ^ c16) << 4) + (q16 & 1) * 8) = o;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int rr = p * 4 + q16;
+                    if (NT < 8 && c16 >= NT * 2) continue;
+                    half8 hv = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
+                    const size_t off = ((size_t)bm * BM + wm * 128 + tm * 16 + rr) * N + nb0 + c16 * 8;
+                    if (HAS_RES) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)((float)hv[q] + (float)rcur[p][q]);
+                    }
+                    if (!(xmode & 2)) *(half8*)(C + off) = hv;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            tile += tstride;
+            store_age = 0;
+        }
+    }
+#undef W4_SUBSTEP
+#undef W4_GROUP
+#undef W4_RD
+#undef W4_LGKM
+}
+
+template <int NT, int ACT, bool B, bool RR>
+static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K, hipStream_t st) {
+    constexpr int BN = 32 * NT, LDS = 4 * (16384 + BN * 64) + 16384;
+    if (M % 256 || N % BN || K % 64) return SCD_EINVAL;
+    static bool attr = false;
+    if (!attr) {
+        SCD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<NT, ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int tiles_m = M / 256, tiles_n = N / BN, total = tiles_m * tiles_n;
+    static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
+    int ng = ng_env > 0 ? ng_env : tiles_n;
+    if (ng > tiles_n) ng = tiles_n;
+    const int grid = total < 256 ? total : 256;
+    gemm_w4_kernel<NT, ACT, B, RR><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+    return SCD_OK;
+}
+
 template <int BM, int ACT, bool B, bool RR>
 static int launch_dma(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                       hipStream_t st) {
@@ -435,6 +913,21 @@ static int launch_dma(const half_t* A, const half_t* W, const float* bias, const
             if (cost < best) { best = cost; ng = cand; }
         }
         if (ng_env > 0) ng = ng_env < tiles_n ? ng_env : tiles_n;
+    }
+    static const int mfma_sel = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) : 16;
+    const bool mfma16 = mfma_sel == 16;
+    if (BM == 256 && (mfma_sel == 4 || mfma_sel == 6)) {
+        if (mfma_sel == 6) return launch_w4<6, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
+        return launch_w4<8, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
+    }
+    if (BM == 256 && mfma16) {
+        static bool attr16 = false;
+        if (!attr16) {
+            SCD_HIP(hipFuncSetAttribute((const void*)gemm_dma16_kernel<ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+            attr16 = true;
+        }
+        gemm_dma16_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+        return SCD_OK;
     }
     gemm_dma_kernel<BM, ACT, B, RR><<<grid, BM * 2, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
     return SCD_OK;
