@@ -629,207 +629,263 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Four-wave variant: the same 256x256 block tile, ring and schedule, but each wave owns a 128(m) x 128(n) sub-tile, one wave
-// per SIMD, the 256 accumulator registers in AGPRs.  LDS reads drop to 16 fragments per 64 MFMAs (8-wave kernel: 12 per
-// 32), which matters because LDS bandwidth (ring fills + fragment reads) is what bounds the 8-wave kernel.
+// Four-wave kernel: 256x256 block tile, one wave per SIMD, each wave a 128(m) x 128(n) sub-tile whose 256 accumulator
+// registers live in AGPRs; K advances in 64-deep chunks through two 64 KB LDS slots.
+//
+// Why 64-deep: a ring fill of 64-byte row segments moves half the bytes per L1 request - measured with
+// tools/micro/dma_fill_bench.hip: 66 GB/s per CU against 129 GB/s per CU for 128-byte (whole-line) segments out of L2 -
+// and at 128 FLOP per L2 byte that fill rate, not the MFMA pipe, bounded the 32-deep kernels above.
+//
+// LDS slot (c & 1): A part 256 rows x 128 B, W part 256 rows x 128 B; the 16-byte chunk lc of row r sits at physical chunk
+// lc ^ ((r >> 1) & 7), which keeps both the DMA image (8 rows x 128 B per instruction, the swizzle applied to the per-lane
+// source address) and the fragment ds_read_b128 (lane = row l&15, chunk (l>>4) + 4*khalf) conflict-free.
+//
+// Schedule of chunk c (two 32-deep sub-steps, 64 MFMAs per wave each, in 4 groups of 2 m-tiles x 8 n-tiles):
+//   even: A fragments stream one group ahead; under the last group the W fragments and the first two A pairs of the odd
+//         sub-step are read.
+//   odd:  the remaining A pairs are read up front, so by the middle of the sub-step every read of chunk c has completed:
+//         there - one barrier per chunk - the wave waits for chunk c+1 (issued two sub-steps earlier), and refills this
+//         slot with chunk c+2; under the last group it reads the first fragments of chunk c+1.
+// The hot loop is hand-scheduled in inline asm: MFMAs with AGPR accumulators ("a" constraints; left alone hipcc shuffles
+// the accumulators between AGPRs and VGPRs around every group), C = 0 on a tile's first sub-step instead of zeroing,
+// ds_read_b128 with counted lgkmcnt (for asm operands hipcc only emits lgkmcnt(0)); s_nop covers the MFMA -> v_accvgpr_read
+// hazard the compiler cannot see.
+__device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
+
 template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
                int xmode, int ng) {
-    constexpr int BM = 256, BN = 32 * NT, NSLOT = 4, SLOT = 16384 + BN * 64;
+    static_assert(NT == 8, "wave tile is 128 x 128");
+    constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, q16 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nk = K >> 5;
+    const int nkc = K >> 6;                       // 64-deep chunks per tile
     const int tiles_m = total_tiles / tiles_n;
     const int per_group = tiles_m * ng;
-    auto tile_mn = [&](int t, int& bm, int& bn) {
+    // Tile order: n-groups of ng tile columns, row-major inside a group (see choose_ng).  A block walks its tiles with a
+    // stride, so (bm, bn) is carried incrementally - the integer divisions of the closed form, executed by a lone wave per
+    // SIMD between two MFMA blocks, cost several hundred idle matrix-pipe cycles per chunk.
+    struct TileIt { int t, bm, bnl, n0, w, q, r; };
+    auto it_init = [&](TileIt& it, int t) {
+        it.t = t;
         const int g = t / per_group;
         const int local = t - g * per_group;
-        const int n0 = g * ng;
-        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;
-        bm = local / w;
-        bn = n0 + local - bm * w;
+        it.n0 = g * ng;
+        it.w = tiles_n - it.n0 < ng ? tiles_n - it.n0 : ng;
+        it.bm = local / it.w;
+        it.bnl = local - it.bm * it.w;
     };
     const int nxcd = gridDim.x >= 8 ? 8 : 1;
     const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
     const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
     const int tb = c0 + slot_id;
     const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
-    const int steps = my_tiles * nk;
-    if (steps <= 0) return;
+    const int chunks = my_tiles * nkc;
+    if (chunks <= 0) return;
     const int tstride = per_xcd;
-
-    auto swz = [](int row) { return (0 - (row >> 2)) & 3; };
-    const int lrow = lane >> 2, pc = lane & 3;
-    const int rowl0 = wave * 64 + lrow;
-    const int g_off0 = rowl0 * K + ((pc ^ swz(rowl0)) << 3);
-    const int roww0 = wave * (BN / 4) + lrow;
-    const int g_offw = roww0 * K + ((pc ^ swz(roww0)) << 3);
-    const int k16 = 16 * K;
-    auto issue = [&](int tile, int kt, int slot) {
-        int bm, bn;
-        tile_mn(tile, bm, bn);
-        if (xmode & 4) { bm = 0; bn = 0; }
-        const half_t* ga = A + (size_t)bm * BM * K + kt * 32 + g_off0;
-        const half_t* gw = W + (size_t)bn * BN * K + kt * 32 + g_offw;
-        char* sa = smem + slot * SLOT + wave * 4096;
-        char* sw = smem + slot * SLOT + 16384 + wave * (BN * 16);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) __builtin_amdgcn_global_load_lds((const void*)(ga + p * k16), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < NT / 2; ++p) __builtin_amdgcn_global_load_lds((const void*)(gw + p * k16), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
+    auto it_step = [&](TileIt& it) {       // t += tstride
+        it.t += tstride;
+        it.bnl += it.r;
+        it.bm += it.q;
+        if (it.bnl >= it.w) { it.bnl -= it.w; ++it.bm; }
+        if (it.bm >= tiles_m) {            // crossed into the next n-group (rare): closed form
+            it_init(it, it.t);
+            it.q = tstride / it.w;
+            it.r = tstride - it.q * it.w;
+        }
     };
-    const int rw = wn * (NT * 16) + c16, ra = wm * 128 + c16;
-    const int offw0 = 16384 + rw * 64 + ((q16 ^ swz(rw)) << 4);   // tile t: + t * 1024 (the swizzle term does not change)
-    const int offa0 = ra * 64 + ((q16 ^ swz(ra)) << 4);
-
-    int tile = tb, ntile = tb, nkt = 0;
-#pragma unroll
-    for (int pre = 0; pre < NSLOT - 1; ++pre) {
-        if (pre < steps) issue(ntile, nkt, pre);
-        if (++nkt == nk) { nkt = 0; ntile += tstride; }
+    if (xmode >> 8) {   // experiment: phase-shift the blocks of an XCD so that their epilogues do not coincide
+        const long long target = wall_clock64() + (long long)(slot_id & 7) * (xmode >> 8);
+        while (wall_clock64() < target) __builtin_amdgcn_s_sleep(32);
     }
-    int store_age = 8;
-    half8 rpre[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
 
-    half8 fwA[NT], fwB[NT], a01[2], a23[2], a45[2], a67[2];
-    // The hot loop is hand-scheduled: MFMAs, fragment reads and their waits are inline asm.
-    //  * MFMAs with the accumulators pinned to AGPRs ("a" constraints) - left to itself hipcc keeps copying the 256 accumulator
-    //    registers between AGPRs and VGPRs around every group.  Z = 1 is the first sub-step of a tile: C = 0, so the
-    //    accumulators are never zeroed.  No compiler hazard NOPs exist after an asm MFMA: s_nop before the epilogue reads them
-    //    back (explicit v_accvgpr_read).
-    //  * ds_read_b128 + counted lgkmcnt: for asm operands hipcc only ever emits lgkmcnt(0), which would serialise the
-    //    read-ahead.  lgkmcnt retires in order, so "all but the newest N" is exact.
+    // DMA: instruction p of a wave covers rows wave*64 + p*8 + (lane>>3), lane&7 = physical chunk
+    const int drow = lane >> 3, dpc = lane & 7;
+    int g_off[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int rowl = wave * 64 + par * 8 + drow;
+        g_off[par] = rowl * K + ((dpc ^ ((rowl >> 1) & 7)) << 3);
+    }
+    const int k16 = 16 * K;
+    const half_t *ga = A, *gw = W;      // panel pointers of the chunk being issued
+    auto chunk_ptrs = [&](const TileIt& it, int kc) {
+        int bm = it.bm, bn = it.n0 + it.bnl;
+        if (xmode & 4) { bm = 0; bn = 0; }
+        ga = A + (size_t)bm * BM * K + kc * 64;
+        gw = W + (size_t)bn * BN * K + kc * 64;
+    };
+    // one ring-fill instruction (p = 0..7 of the A part or of the W part): scalar panel base + per-lane byte offset, so it
+    // costs the wave no VALU work between the MFMAs it is interleaved with.  M0 carries the LDS destination.
     const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned dma_lds = sbase + wave * 8192;
+    const unsigned voff0 = (unsigned)g_off[0] * 2, voff1 = (unsigned)g_off[1] * 2;
+#define W4_DMA(BASE, P, LDSOFF)                                                                                  \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                                \
+                 ::"s"(dma_lds + (LDSOFF) + (P) * 1024), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16) : "memory")
+    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, slot * SLOT); };
+    auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, slot * SLOT + WPART); };
+    auto issue = [&](const TileIt& it, int kc, int slot) {
+        chunk_ptrs(it, kc);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) issue_a(p, slot);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) issue_w(p, slot);
+    };
+    // fragment addresses: tile t adds t * 2048; k-half j uses chunk (q16 + 4j) ^ sw
+    const int fsw = (c16 >> 1) & 7;
+    const unsigned fa0 = sbase + (wm * 128 + c16) * 128 + ((q16 ^ fsw) << 4);
+    const unsigned fa1 = sbase + (wm * 128 + c16) * 128 + (((q16 + 4) ^ fsw) << 4);
+    const unsigned fw0 = sbase + WPART + (wn * 128 + c16) * 128 + ((q16 ^ fsw) << 4);
+    const unsigned fw1 = sbase + WPART + (wn * 128 + c16) * 128 + (((q16 + 4) ^ fsw) << 4);
+
+    // prologue: chunk 0 whole, chunk 1's A part (its W part is issued under the first even sub-step, see W4_H_EVEN)
+    TileIt cit, nit;                      // tile being computed / tile whose chunks are being issued
+    it_init(cit, tb);
+    cit.q = tstride / cit.w;
+    cit.r = tstride - cit.q * cit.w;
+    nit = cit;
+    int nkt = 0, ntiles = 0;              // ntiles: tiles completely issued
+    auto issue_advance = [&]() {
+        if (++nkt == nkc) {
+            nkt = 0;
+            if (++ntiles < my_tiles) it_step(nit);
+        }
+    };
+    issue(nit, nkt, 0);
+    issue_advance();
+    if (chunks > 1) chunk_ptrs(nit, nkt); else chunk_ptrs(cit, 0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) issue_a(p, 1);
+    issue_advance();
+    half8 rq[3][4];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rq[e][p][q] = (half_t)0.f;
+
+    half8 fwA[8], fwB[8], faA[8], faB[8];   // W / A fragments of the even (A) and odd (B) sub-step
 #define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W4_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
-    if (steps >= NSLOT - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + NT / 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
-        const unsigned aw = sbase + offw0, aa = sbase + offa0;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) W4_RD(fwA[t], aw, t * 1024);
-        W4_RD(a01[0], aa, 0);
-        W4_RD(a01[1], aa, 1024);
+    for (int t = 0; t < 8; ++t) {
+        W4_RD(fwA[t], fw0, t * 2048);
+        W4_RD(faA[t], fa0, t * 2048);
     }
-    int cslot = 0, s = 0;
-#define W4_GROUP(FW, FA, TM0, Z)                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int tn = 0; tn < NT; ++tn) {              \
-        if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][(TM0) + j]) : "v"(FW[tn]), "v"(FA[j]));   \
-        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][(TM0) + j]) : "v"(FW[tn]), "v"(FA[j]));    \
-    }
-    // one 32-deep sub-step: 4 MFMA groups of 2 m-tiles x NT n-tiles; the A fragments of the next group are read while the
-    // current one computes, the ring wait + barrier + refill sit between groups 1 and 2, and the W / first A fragments of
-    // the NEXT sub-step (FWN) are read under group 3.  On entry FWC and a01 are in flight (NT + 2 reads).
-#define W4_SUBSTEP(FWC, FWN, Z)                                                                                   \
+    int cslot = 0, g = 0;   // g: chunk counter over all of this block's tiles
+    // one 32-deep sub-step: 64 MFMAs (8 m-tiles x 8 n-tiles); HOOK(i) runs after MFMA i = 0..63.  Everything else the wave
+    // has to issue - the fragment reads of the NEXT sub-step and the ring refill - is spread between the MFMAs through the
+    // hook: issued back to back they hold up the wave's in-order instruction stream, and with it the matrix pipe, for as
+    // long as the LDS / texture queues take to accept them.
+#define W4_SUB(FW, FA, Z, HOOK)                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int tm = 0; tm < 8; ++tm) _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {            \
+        if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));         \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));          \
+        HOOK(tm * 8 + tn)                                                                                        \
+    }                                                                                                            \
+    __builtin_amdgcn_s_setprio(0);
+    // even sub-step: reads the odd sub-step's fragments (k-half 1 of the same slot) under MFMAs 0..47 and issues the W part
+    // of the refill that the previous odd sub-step began (the other slot), one fill per four MFMAs of the first half
+#define W4_H_EVEN(i)                                                                                             \
+    if ((i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);                                          \
+    if ((i) < 48 && (i) % 3 == 0) W4_RD(fwB[((i) / 3) & 7], fw1 + so, (((i) / 3) & 7) * 2048);                   \
+    if ((i) < 48 && (i) % 3 == 1) W4_RD(faB[((i) / 3) & 7], fa1 + so, (((i) / 3) & 7) * 2048);
+    // odd sub-step: reads the next chunk's first fragments (other slot) under MFMAs 0..47 and starts refilling this slot with
+    // chunk c+2: the A part (the one that can miss L2), one fill per eight MFMAs.  Measured: a wave is held ~64 cycles per
+    // fill while the CU's texture path (64 B/clk) takes the four waves' 1 KB instructions, so 16 fills inside one sub-step
+    // doubled its length; spread over two sub-steps they fit under the MFMAs.
+#define W4_H_ODD(i)                                                                                              \
+    if ((i) < 48 && (i) % 3 == 0) W4_RD(fwA[((i) / 3) & 7], fw0 + no, (((i) / 3) & 7) * 2048);                   \
+    if ((i) < 48 && (i) % 3 == 1) W4_RD(faA[((i) / 3) & 7], fa0 + no, (((i) / 3) & 7) * 2048);                   \
+    if (((i) & 7) == 4) issue_a(((i) >> 3) & 7, cslot);
+#define W4_EVEN(Z)                                                                                               \
     {                                                                                                            \
-        const unsigned cur = sbase + cslot * SLOT + offa0;                                                       \
-        const int nslot = cslot + 1 == NSLOT ? 0 : cslot + 1;                                                    \
-        W4_RD(a23[0], cur, 2 * 1024);                                                                            \
-        W4_RD(a23[1], cur, 3 * 1024);                                                                            \
-        W4_LGKM(2);                                                                                              \
-        __builtin_amdgcn_s_setprio(1);                                                                           \
-        W4_GROUP(FWC, a01, 0, Z)                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                           \
-        W4_RD(a45[0], cur, 4 * 1024);                                                                            \
-        W4_RD(a45[1], cur, 5 * 1024);                                                                            \
-        W4_LGKM(2);                                                                                              \
-        __builtin_amdgcn_s_setprio(1);                                                                           \
-        W4_GROUP(FWC, a23, 2, Z)                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                           \
-        if (s + 1 < steps) {                                                                                     \
-            if (s + NSLOT - 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         \
-            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(36 + NT / 2) : "memory");           \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NT / 2) : "memory");                               \
-        }                                                                                                        \
-        ++store_age;                                                                                             \
+        const unsigned so = cslot * SLOT;                                                                        \
+        W4_LGKM(0);                                                                                              \
+        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_odd += t - t_sub; t_sub = t; } \
+        W4_SUB(fwA, faA, Z, W4_H_EVEN)                                                                           \
+    }
+#define W4_ODD()                                                                                                 \
+    {                                                                                                            \
+        const unsigned no = (cslot ^ 1) * SLOT; /* past the last chunk: a stale slot, values unused */           \
+        /* all of this wave's reads of the chunk have completed: after the barrier the slot can be refilled */   \
+        W4_LGKM(0);                                                                                              \
+        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_even += t - t_sub; t_sub = t; } \
+        /* chunk g+1: A part issued under the previous odd sub-step, W part under the even one just finished; an epilogue's  \
+           stores, if any, sit between the two in the in-order queue, so this waits for them as well */                 \
+        if (!(xmode & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_s_barrier();                                                                            \
         asm volatile("" ::: "memory");                                                                           \
-        if (s + NSLOT - 1 < steps && !((xmode & 1) && s >= 2)) {                                                 \
-            int ls = cslot + NSLOT - 1;                                                                          \
-            if (ls >= NSLOT) ls -= NSLOT;                                                                        \
-            issue(ntile, nkt, ls);                                                                               \
-        }                                                                                                        \
-        if (++nkt == nk) { nkt = 0; ntile += tstride; }                                                          \
-        W4_RD(a67[0], cur, 6 * 1024);                                                                            \
-        W4_RD(a67[1], cur, 7 * 1024);                                                                            \
-        W4_LGKM(2);                                                                                              \
-        __builtin_amdgcn_s_setprio(1);                                                                           \
-        W4_GROUP(FWC, a45, 4, Z)                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                           \
-        {                                                                                                        \
-            const unsigned nw = sbase + nslot * SLOT + offw0; /* past the last step: a stale slot, values unused */ \
-            const unsigned na = sbase + nslot * SLOT + offa0;                                                    \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) W4_RD(FWN[t], nw, t * 1024);                          \
-            W4_RD(a01[0], na, 0);                                                                                \
-            W4_RD(a01[1], na, 1024);                                                                             \
-        }                                                                                                        \
-        W4_LGKM(NT + 2);                                                                                         \
-        __builtin_amdgcn_s_setprio(1);                                                                           \
-        W4_GROUP(FWC, a67, 6, Z)                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                           \
-        cslot = nslot;                                                                                           \
-        ++s;                                                                                                     \
+        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_bar += t - t_sub; t_sub = t; } \
+        /* past this block's last chunk the refill re-reads the current tile's first chunk into the free slot: no branch  \
+           around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
+        if (g + 2 < chunks) chunk_ptrs(nit, nkt); else chunk_ptrs(cit, 0);                                       \
+        issue_advance();                                                                                         \
+        W4_SUB(fwB, faB, 0, W4_H_ODD)                                                                            \
+        cslot ^= 1;                                                                                              \
+        ++g;                                                                                                     \
     }
+    unsigned long long t_main = 0, t_epi = 0, t_begin = __builtin_readcyclecounter();
+    unsigned long long t_even = 0, t_odd = 0, t_bar = 0, t_sub = t_begin;
     for (int ti = 0; ti < my_tiles; ++ti) {
-        int bm, bn;
-        tile_mn(tile, bm, bn);
-        const int nb0 = bn * BN + wn * (NT * 16);
-        const int c16r = (NT < 8 && c16 >= NT * 2) ? 0 : c16;   // lanes past the tile's 32*NT columns only shadow lane 0's loads
-        f32x4v acc[NT][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
-        f32x4v bq[NT];
-        // bias and the first residual rows are fetched one sub-step before the tile ends: a plain load issued in the epilogue
+        const int bm = cit.bm, bn = cit.n0 + cit.bnl;
+        const int nb0 = bn * BN + wn * 128;
+        const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
+        f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
+        f32x4v bq[8];
+        // bias and the first residual rows are fetched one chunk before the tile ends: a plain load issued in the epilogue
         // would sit behind the ring refills in the (in-order) vmcnt queue and stall on them.
 #define W4_PRE()                                                                                                 \
     {                                                                                                            \
         if (HAS_RES) {                                                                                           \
-            _Pragma("unroll") for (int p = 0; p < 4; ++p) rpre[p] =                                              \
-                *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 4 + q16) * N + nb0 + c16r * 8);            \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
+                *(const half8*)(R + ((size_t)bm * BM + wm * 128 + e * 16 + p * 4 + q16) * N + nb0 + c16 * 8);    \
         }                                                                                                        \
         if (HAS_BIAS) {                                                                                          \
-            _Pragma("unroll") for (int tn = 0; tn < NT; ++tn) {                                                  \
+            _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
                 const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);                              \
                 bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;                          \
             }                                                                                                    \
         }                                                                                                        \
     }
-        W4_SUBSTEP(fwA, fwB, 1)
-        if (nk == 2) W4_PRE()
-        W4_SUBSTEP(fwB, fwA, 0)
-        for (int kt = 2; kt < nk; kt += 2) {
-            W4_SUBSTEP(fwA, fwB, 0)
-            if (kt == nk - 2) W4_PRE()
-            W4_SUBSTEP(fwB, fwA, 0)
+        if (nkc == 1) W4_PRE()
+        W4_EVEN(1)
+        W4_ODD()
+        for (int kc = 1; kc < nkc; ++kc) {
+            if (kc == nkc - 1) W4_PRE()
+            W4_EVEN(0)
+            W4_ODD()
         }
 #undef W4_PRE
         W4_LGKM(0);                                            // next tile's first fragments (read under the last group)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read
-        {
+        const unsigned long long t1 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
+        if (!(xmode & 16)) {
             // epilogue, one 16-row m-tile at a time through a per-wave LDS patch [16 m][128 n] fp16 (256-B rows, chunk XOR row):
-            // lane (c16 = m, q16) holds n = tn*16 + q16*4 + 0..3; rows leave as whole 256-byte segments.
-            char* ep = smem + NSLOT * SLOT + wave * 4096;
+            // lane (c16 = m, q16) holds n = tn*16 + q16*4 + 0..3; rows leave as whole 256-byte segments.  No lgkmcnt waits
+            // between the patch writes and reads: one wave's LDS operations execute in order.  Residual rows are fetched two
+            // m-tiles ahead (ring of three).
+            char* ep = smem + EPI + wave * 4096;
 #pragma unroll
             for (int tm = 0; tm < 8; ++tm) {
-                half8 rcur[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
-                if (HAS_RES && tm < 7) {
+                if (HAS_RES && tm < 6) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + 1) * 16 + p * 4 + q16) * N + nb0 + c16r * 8);
+                        rq[(tm + 2) % 3][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + 2) * 16 + p * 4 + q16) * N + nb0 + c16 * 8);
                 }
 #pragma unroll
-                for (int tn = 0; tn < NT; ++tn) {
+                for (int tn = 0; tn < 8; ++tn) {
                     half4 o;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
@@ -840,47 +896,91 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                     }
                     *(half4*)(ep + c16 * 256 + (((tn * 2 + (q16 >> 1)) ^ c16) << 4) + (q16 & 1) * 8) = o;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int rr = p * 4 + q16;
-                    if (NT < 8 && c16 >= NT * 2) continue;
                     half8 hv = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
                     const size_t off = ((size_t)bm * BM + wm * 128 + tm * 16 + rr) * N + nb0 + c16 * 8;
-                    if (HAS_RES) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)((float)hv[q] + (float)rcur[p][q]);
-                    }
+                    if (HAS_RES) hv = hv + rq[tm % 3][p];   // fp16 add of two fp16 values: the same rounding as via fp32
                     if (!(xmode & 2)) *(half8*)(C + off) = hv;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            tile += tstride;
-            store_age = 0;
+        }
+        if (ti + 1 < my_tiles) it_step(cit);
+        if (xmode & 64) {
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            t_main += t1 - t0;
+            t_epi += t2 - t1;
         }
     }
-#undef W4_SUBSTEP
-#undef W4_GROUP
+    if ((xmode & 64) && tid == 0) {
+        g_w4_dbg[blockIdx.x * 4 + 0] = t_main;
+        g_w4_dbg[blockIdx.x * 4 + 1] = t_epi;
+        g_w4_dbg[blockIdx.x * 4 + 2] = my_tiles;
+        g_w4_dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter() - t_begin;
+        if (xmode & 128) {   // per sub-step: even, wait+barrier, odd (the odd figure of a tile's last chunk includes the epilogue)
+            g_w4_dbg[blockIdx.x * 4 + 0] = t_even;
+            g_w4_dbg[blockIdx.x * 4 + 1] = t_bar;
+            g_w4_dbg[blockIdx.x * 4 + 2] = t_odd;
+            g_w4_dbg[blockIdx.x * 4 + 3] = chunks;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail refills must land before the LDS is handed to another block
+#undef W4_EVEN
+#undef W4_ODD
+#undef W4_SUB
+#undef W4_H_EVEN
+#undef W4_H_ODD
+#undef W4_DMA
 #undef W4_RD
 #undef W4_LGKM
 }
 
+// n-tiles per group: the W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
+// re-reads the activations once.  Estimate the beyond-L2 traffic of each candidate and keep the cheapest.
+static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
+    static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
+    if (ng_env > 0) return ng_env < tiles_n ? ng_env : tiles_n;
+    int ng = tiles_n;
+    const double a_bytes = 2.0 * M * (double)K, panel = 512.0 * K;
+    double best = 1e300;
+    for (int groups = 1; groups <= tiles_n; ++groups) {
+        const int cand = (tiles_n + groups - 1) / groups;
+        const double wg = cand * panel;
+        const double rounds = (double)total / resident;
+        const double w_traffic = wg <= 2.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
+        const double cost = groups * a_bytes + w_traffic;
+        if (cost < best) { best = cost; ng = cand; }
+    }
+    return ng;
+}
+
 template <int NT, int ACT, bool B, bool RR>
 static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K, hipStream_t st) {
-    constexpr int BN = 32 * NT, LDS = 4 * (16384 + BN * 64) + 16384;
-    if (M % 256 || N % BN || K % 64) return SCD_EINVAL;
+    constexpr int LDS = 2 * 65536 + 16384;
+    if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
     static bool attr = false;
     if (!attr) {
         SCD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<NT, ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int tiles_m = M / 256, tiles_n = N / BN, total = tiles_m * tiles_n;
+    const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
     static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
-    static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
-    int ng = ng_env > 0 ? ng_env : tiles_n;
-    if (ng > tiles_n) ng = tiles_n;
-    const int grid = total < 256 ? total : 256;
+    const int ng = choose_ng(M, K, tiles_n, total, 256);
+    const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
     gemm_w4_kernel<NT, ACT, B, RR><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+    if (xmode & 64) {
+        static unsigned long long h[256 * 4];
+        SCD_HIP(hipDeviceSynchronize());
+        SCD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4_dbg), sizeof(h)));
+        double tm = 0, te = 0, tt = 0, nt = 0;
+        for (int b = 0; b < grid; ++b) { tm += h[b * 4]; te += h[b * 4 + 1]; nt += h[b * 4 + 2]; tt += h[b * 4 + 3]; }
+        if (xmode & 128)
+            fprintf(stderr, "[w4 m=%d n=%d k=%d] per chunk: even %.0f, wait+barrier %.0f, odd(+epilogue share) %.0f cyc\n", M, N, K, tm / tt, te / tt, nt / tt);
+        else
+        fprintf(stderr, "[w4 m=%d n=%d k=%d] per tile: main %.0f cyc, epilogue %.0f cyc; per block total %.0f cyc, tiles %.1f\n", M, N, K,
+                tm / nt, te / nt, tt / grid, nt / grid);
+    }
     return SCD_OK;
 }
 
@@ -897,29 +997,10 @@ static int launch_dma(const half_t* A, const half_t* W, const float* bias, const
     const int resident = BM == 256 ? 256 : 512;
     const int grid = total < resident ? (total >= 8 ? total / 8 * 8 : total) : resident;
     static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
-    static const int ng_env = getenv("SCD_GEMM_NG") ? atoi(getenv("SCD_GEMM_NG")) : 0;
-    // n-tiles per group: W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
-    // re-reads the activations once.  Estimate the beyond-L2 traffic of each candidate and keep the cheapest.
-    int ng = tiles_n;
-    {
-        const double a_bytes = 2.0 * M * (double)K, panel = 512.0 * K;
-        double best = 1e300;
-        for (int groups = 1; groups <= tiles_n; ++groups) {
-            const int cand = (tiles_n + groups - 1) / groups;
-            const double wg = cand * panel;
-            const double rounds = (double)total / resident;
-            const double w_traffic = wg <= 2.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
-            const double cost = groups * a_bytes + w_traffic;
-            if (cost < best) { best = cost; ng = cand; }
-        }
-        if (ng_env > 0) ng = ng_env < tiles_n ? ng_env : tiles_n;
-    }
-    static const int mfma_sel = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) : 16;
+    const int ng = choose_ng(M, K, tiles_n, total, resident);
+    static const int mfma_sel = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) : 4;   // 4: four-wave kernel (default); 16 / 32: eight-wave kernels
     const bool mfma16 = mfma_sel == 16;
-    if (BM == 256 && (mfma_sel == 4 || mfma_sel == 6)) {
-        if (mfma_sel == 6) return launch_w4<6, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
-        return launch_w4<8, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
-    }
+    if (BM == 256 && mfma_sel == 4) return launch_w4<8, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
     if (BM == 256 && mfma16) {
         static bool attr16 = false;
         if (!attr16) {
