@@ -699,10 +699,6 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             it.r = tstride - it.q * it.w;
         }
     };
-    if (xmode >> 8) {   // experiment: phase-shift the blocks of an XCD so that their epilogues do not coincide
-        const long long target = wall_clock64() + (long long)(slot_id & 7) * (xmode >> 8);
-        while (wall_clock64() < target) __builtin_amdgcn_s_sleep(32);
-    }
 
     // DMA: instruction p of a wave covers rows wave*64 + p*8 + (lane>>3), lane&7 = physical chunk
     const int drow = lane >> 3, dpc = lane & 7;
@@ -900,9 +896,13 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 for (int p = 0; p < 4; ++p) {
                     const int rr = p * 4 + q16;
                     half8 hv = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
-                    const size_t off = ((size_t)bm * BM + wm * 128 + tm * 16 + rr) * N + nb0 + c16 * 8;
+                    const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + tm * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
                     if (HAS_RES) hv = hv + rq[tm % 3][p];   // fp16 add of two fp16 values: the same rounding as via fp32
-                    if (!(xmode & 2)) *(half8*)(C + off) = hv;
+                    // a large C streams past L2 ("nt"): written normally, each round of tiles pushes 32 MB of dirty lines
+                    // through the 32 MB of L2 and evicts the W panels every CU is about to re-read (measured +12 % on the
+                    // n = 2304 / 3072 shapes, nothing on n = 768)
+                    if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                    else if (!(xmode & 2)) *(half8*)(C + off) = hv;
                 }
             }
         }
@@ -965,7 +965,10 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
         attr = true;
     }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
-    static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int xenv = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;   // -1: by size
+    const bool nt = nt_env >= 0 ? nt_env != 0 : 2.0 * M * (double)N > 64e6;   // C beyond what L2 (32 MB) could keep anyway
+    const int xmode = xenv | (nt ? 512 : 0);
     const int ng = choose_ng(M, K, tiles_n, total, 256);
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
     gemm_w4_kernel<NT, ACT, B, RR><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
