@@ -343,6 +343,161 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
     }
 }
 
+// Persistent attention for the ViT towers (T <= 224 tokens, head_dim 64): one 8-wave block per CU loops over its
+// (image, head) items.  Wave 7 is the producer: it streams the NEXT item's K and V head slices into the other half of a
+// double-buffered LDS image with LDS-DMA (8 rows x 128 B per instruction, the bank swizzles applied to the per-lane source
+// address) while waves 0-6 each compute one 32-query block of the current item exactly as attention_kernel does (S^T = K Q^T,
+// in-lane softmax, O^T = V^T P^T through ds_read_b64_tr_b16); their Q fragments for the next item are prefetched into
+// registers at the start of the current one.  One barrier per item.  ~85 KB per CU stay in flight, which is what the qkv
+// stream (the kernel's floor: 620 MB per call) needs.
+// LDS image per buffer: K 224 rows x 128 B, chunk c of row r at c ^ ((r>>1)&7); V 224 rows x 128 B, its 64-byte halves
+// swapped when (r>>1)&1, which makes the transposing reads (4 rows x 64 B per 32-lane group) tile the 64 banks.  Rows past
+// T repeat row T-1 (finite values); their scores are masked to -inf, so their P is exactly 0.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width, int heads, int items) {
+    constexpr int NB = 7, TP = NB * 32, KV = TP * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | V]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 3 * width;
+    const int n_my = (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (n_my <= 0) return;
+    if (wave == 7) {
+        const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        const int drow = lane >> 3, pc = lane & 7;
+        auto issue_item = [&](int item, int buf) {
+            const int img = item / heads, head = item - img * heads;
+            const half_t* kb = qkv + (size_t)img * T * ld + width + head * 64;
+            const half_t* vb = kb + width;
+#pragma unroll 4
+            for (int p = 0; p < TP / 8; ++p) {
+                const int row = p * 8 + drow;
+                const int rowc = row < T ? row : T - 1;
+                const unsigned voff_k = (unsigned)(rowc * ld + ((pc ^ ((row >> 1) & 7)) << 3)) * 2;
+                const unsigned voff_v = (unsigned)(rowc * ld + ((pc ^ (((row >> 1) & 1) << 2)) << 3)) * 2;
+                const unsigned lds = sbase + buf * 2 * KV + p * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_k), "s"(kb) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds + KV), "v"(voff_v), "s"(vb) : "memory");
+            }
+        };
+        issue_item(blockIdx.x, 0);
+        for (int i = 0; i < n_my; ++i) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // item i has landed
+            __builtin_amdgcn_s_barrier();                               // consumers start item i; nobody reads item i-1's buffer any more
+            asm volatile("" ::: "memory");
+            if (i + 1 < n_my) issue_item(blockIdx.x + (i + 1) * gridDim.x, (i + 1) & 1);
+        }
+        return;
+    }
+    // ---- consumers: wave = query block
+    const int r = lane & 31, hh = lane >> 5, L = lane & 15;
+    const int query = wave * 32 + r;
+    const int qrow = query < T ? query : T - 1;
+    const int vswz = ((L >> 3) & 1) * 64;
+    const int tr_off = (4 * hh + (L >> 2)) * 128 + 32 * ((lane >> 4) & 1) + 8 * (L & 3);
+    half8 qf[4], qn[4];
+    {
+        const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
+        const half_t* qbase = qkv + (size_t)img * T * ld + head * 64;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qbase + (size_t)qrow * ld + 16 * s + 8 * hh);
+    }
+    for (int i = 0; i < n_my; ++i) {
+        const int item = blockIdx.x + i * gridDim.x;
+        const int img = item / heads, head = item - img * heads;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + 1 < n_my) {
+            const int item2 = item + gridDim.x;
+            const int img2 = item2 / heads, head2 = item2 - img2 * heads;
+            const half_t* qbase = qkv + (size_t)img2 * T * ld + head2 * 64;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qn[s] = *(const half8*)(qbase + (size_t)qrow * ld + 16 * s + 8 * hh);
+        }
+        const char* kl = smem + (i & 1) * 2 * KV;
+        const char* vl = kl + KV;
+        f32x16 sacc[NB];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = kb * 32 + r;
+                const half8 kf = *(const half8*)(kl + row * 128 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 4));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // softmax over keys on the raw scores (only the last key block holds padded keys); 1/sqrt(64) folded into exp2
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = sacc[kb][e];
+                if (kb == NB - 1) {
+                    const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= T) v = -INFINITY;
+                    sacc[kb][e] = v;
+                }
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float cs = 0.125f * 1.4426950408889634f;
+        const float mxs = mx * cs;
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], cs, -mxs));
+                sacc[kb][e] = pv;
+                sum += pv;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        f32x16 oacc[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* base = vl + (kb * 32 + 16 * s) * 128 + ((db * 64) ^ vswz) + tr_off;
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 8 * 128));
+                    const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+                    half8 vf;
+                    vf[0] = l4[0]; vf[1] = l4[1]; vf[2] = l4[2]; vf[3] = l4[3];
+                    vf[4] = h4[0]; vf[5] = h4[1]; vf[6] = h4[2]; vf[7] = h4[3];
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        }
+        if (query < T) {
+            half_t* orow = out + ((size_t)img * T + query) * width + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 o;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) o[q4] = (half_t)(oacc[db][4 * g + q4] * inv);
+                    *(half4*)(orow + db * 32 + 8 * g + 4 * hh) = o;
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static inline int batch_pad(int b) { return (b + 255) / 256 * 256; }
 
@@ -446,7 +601,16 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t 
         int rc = scd_gemm_launch(w.y, (const half_t*)lw[L_QKV_W], (const float*)lw[L_QKV_B], nullptr, w.qkv, rows, 3 * d.width,
                                  d.width, SCD_ACT_NONE, st);
         if (rc) return rc;
-        if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
+        static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
+        if (d.tokens > 192 && d.tokens <= 224 && !causal && attn_persist) {
+            static bool attr = false;
+            if (!attr) {
+                SCD_HIP(hipFuncSetAttribute((const void*)attention_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 224 * 128));
+                attr = true;
+            }
+            const int items = bp * d.heads;
+            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items);
+        } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
                              SCD_ACT_NONE, st);
