@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--images", type=int, default=IMAGES_PER_GPU, help="images per GPU (default = BASELINE config)")
-    p.add_argument("--batch", type=int, default=512)
+    p.add_argument("--batch", type=int, default=665)   # 665*197 rows = 512 GEMM row tiles: every GEMM fills the 256 CUs exactly
     p.add_argument("--vocab", type=int, default=VOCAB)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()

@@ -83,10 +83,10 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const half_t* __restrict
 // ------------------------------------------------------------------------------------------------ embeddings
 // im2col for the stride-16 patch convolution: out[(b*np + p)][c*P*P + i*P + j] = img[b][c][py*P+i][px*P+j]
 template <typename T>
-__global__ void __launch_bounds__(256) im2col_kernel(const T* __restrict__ img, int batch, int batch_pad, int image, int patch,
+__global__ void __launch_bounds__(256) im2col_kernel(const T* __restrict__ img, int batch, long long rows_pad, int image, int patch,
                                                      half_t* __restrict__ out) {
     const int gp = image / patch, np = gp * gp, kk = 3 * patch * patch;
-    const long long total8 = (long long)batch_pad * np * kk / 8;
+    const long long total8 = rows_pad * kk / 8;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total8) return;
     const long long e = t * 8;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) im2col_kernel(const T* __restrict__ img, 
 // token assembly (+ optional ln_pre): x[b][0] = cls + pos[0]; x[b][1+p] = patch[b*np+p] + patch_bias + pos[1+p]
 __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __restrict__ patch, const float* __restrict__ patch_b,
                                                               const float* __restrict__ cls, const float* __restrict__ pos,
-                                                              long long rows, int T, int width, const float* __restrict__ lg,
+                                                              long long rows, int batch, int T, int width, const float* __restrict__ lg,
                                                               const float* __restrict__ lb, float eps, half_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -118,6 +118,10 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
     const long long b = r / T;
     const int t = (int)(r % T);
     const int groups = width >> 8;
+    if (b >= batch) {   // padding rows (the row count is rounded up to the GEMM tile): zeros
+        for (int c = lane * 4; c < width; c += 256) *(half4*)(out + r * width + c) = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        return;
+    }
     float v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -173,18 +177,22 @@ __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__
     }
     if (t == 0 && lane == 0) {
         int best = 0, bt = -2147483647;
-        if (b < batch)
+        if (b < batch) {
             for (int i = 0; i < T; ++i) {
                 const int v = tokens[b * T + i];
                 if (v > bt) { bt = v; best = i; }
             }
-        eot_row[b] = (int)(b * T + best);
+            eot_row[b] = (int)(b * T + best);
+        }
     }
 }
 
-__global__ void cls_rows_kernel(int* rows, int n, int T) {
+// rows[i] = i*T for the first `batch` entries (when first_only is 0), row 0 for the padding entries batch..n-1
+__global__ void cls_rows_kernel(int* rows, int n, int T, int batch, int pad_only) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rows[i] = i * T;
+    if (i >= n) return;
+    if (i >= batch) rows[i] = 0;
+    else if (!pad_only) rows[i] = i * T;
 }
 
 // copy the first `batch` rows to the caller, optionally L2-normalised (F.normalize semantics)
@@ -499,16 +507,30 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static inline int batch_pad(int b) { return (b + 255) / 256 * 256; }
+// Row counts are padded to the GEMM tile (256), not the image count: with 197 tokens per image a whole-image padding would
+// need multiples of 256 images.  rows: token rows; prows: patch rows (im2col); bh: rows of the CLS / EOT head.
+struct EncPad {
+    int batch, bh;
+    long long rows, prows;
+};
+static inline EncPad make_pad(const scd_encoder_desc& d, int batch) {
+    EncPad p;
+    p.batch = batch;
+    p.bh = (batch + 255) / 256 * 256;
+    p.rows = ((long long)batch * d.tokens + 255) / 256 * 256;
+    p.prows = ((long long)batch * (d.tokens - 1) + 255) / 256 * 256;
+    return p;
+}
 
 struct EncWs {
     half_t *x, *y, *qkv, *h, *cls, *outp;
     int* rows;
     size_t total;
 };
-static EncWs carve(const scd_encoder_desc& d, int bp, char* base) {
+static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
     EncWs w;
-    const size_t rows = (size_t)bp * d.tokens;
+    const size_t rows = (size_t)pad.rows;
+    const int bp = pad.bh;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += scd_align(bytes); return p; };
     w.x = (half_t*)take(rows * d.width * 2);
@@ -581,7 +603,7 @@ extern "C" int scd_encoder_timing(scd_encoder* e, int enable, double* ms_out, in
 
 extern "C" size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch) {
     if (!e || batch <= 0) return 0;
-    return carve(e->d, batch_pad(batch), nullptr).total;
+    return carve(e->d, make_pad(e->d, batch), nullptr).total;
 }
 
 static int attn_xmode() {
@@ -589,9 +611,10 @@ static int attn_xmode() {
     return x;
 }
 
-static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t st) {
+static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, hipStream_t st) {
     const scd_encoder_desc& d = e->d;
-    const long long rows = (long long)bp * d.tokens;
+    const long long rows = pad.rows;
+    const int bp = pad.batch;          // attention runs over the real images only
     const int act = d.act == 0 ? SCD_ACT_QUICKGELU : SCD_ACT_GELU;
     const int causal = d.kind == 1;
     for (int l = 0; l < d.layers; ++l) {
@@ -638,8 +661,9 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, int bp, hipStream_t 
     return SCD_OK;
 }
 
-static int run_head(const scd_encoder* e, const EncWs& w, int batch, int bp, void* out, int normalize, hipStream_t st) {
+static int run_head(const scd_encoder* e, const EncWs& w, const EncPad& pad, void* out, int normalize, hipStream_t st) {
     const scd_encoder_desc& d = e->d;
+    const int batch = pad.batch, bp = pad.bh;
     // final LayerNorm on the gathered CLS / EOT rows, then the projection
     layernorm_kernel<<<(unsigned)scd_cdiv(bp, 4), 256, 0, st>>>(w.x, w.rows, bp, d.width, d.ln_eps, (const float*)e->w[W_LNPOST_W],
                                                                  (const float*)e->w[W_LNPOST_B], w.cls);
@@ -664,25 +688,25 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
     SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_vit_encode_image: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     const scd_encoder_desc& d = e->d;
-    const int bp = batch_pad(batch);
-    EncWs w = carve(d, bp, (char*)ws);
-    const int np = d.tokens - 1, kk = 3 * d.patch * d.patch;
-    const long long total8 = (long long)bp * np * kk / 8;
-    half_t* cols = w.qkv;      // [bp*np, kk] scratch (fits: kk <= 3*width)
+    const EncPad pad = make_pad(d, batch);
+    EncWs w = carve(d, pad, (char*)ws);
+    const int kk = 3 * d.patch * d.patch;
+    const long long total8 = pad.prows * kk / 8;
+    half_t* cols = w.qkv;      // [prows, kk] scratch (fits: kk <= 3*width, prows <= rows)
     SCD_REQUIRE(kk <= 3 * d.width, "scd_vit_encode_image: patch too large for scratch");
-    if (dtype == SCD_F32) im2col_kernel<float><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const float*)pixels, batch, bp, d.image, d.patch, cols);
-    else im2col_kernel<half_t><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const half_t*)pixels, batch, bp, d.image, d.patch, cols);
-    int rc = scd_gemm_launch(cols, (const half_t*)e->w[W_PATCH], nullptr, nullptr, w.y, (long long)bp * np, d.width, kk, SCD_ACT_NONE, st);
+    if (dtype == SCD_F32) im2col_kernel<float><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const float*)pixels, batch, pad.prows, d.image, d.patch, cols);
+    else im2col_kernel<half_t><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const half_t*)pixels, batch, pad.prows, d.image, d.patch, cols);
+    int rc = scd_gemm_launch(cols, (const half_t*)e->w[W_PATCH], nullptr, nullptr, w.y, pad.prows, d.width, kk, SCD_ACT_NONE, st);
     if (rc) return rc;
-    const long long rows = (long long)bp * d.tokens;
+    const long long rows = pad.rows;
     assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
-                                                                         (const float*)e->w[W_POS], rows, d.tokens, d.width,
+                                                                         (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
                                                                          (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
                                                                          d.ln_eps, w.x);
-    cls_rows_kernel<<<(bp + 255) / 256, 256, 0, st>>>(w.rows, bp, d.tokens);
-    rc = run_blocks(e, w, bp, st);
+    cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 0);
+    rc = run_blocks(e, w, pad, st);
     if (rc) return rc;
-    return run_head(e, w, batch, bp, out, normalize, st);
+    return run_head(e, w, pad, out, normalize, st);
 }
 
 extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
@@ -692,12 +716,13 @@ extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const in
     SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_clip_encode_text: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     const scd_encoder_desc& d = e->d;
-    const int bp = batch_pad(batch);
-    EncWs w = carve(d, bp, (char*)ws);
-    const long long rows = (long long)bp * d.tokens;
+    const EncPad pad = make_pad(d, batch);
+    EncWs w = carve(d, pad, (char*)ws);
+    const long long rows = pad.rows;
     embed_text_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(tokens, batch, (const half_t*)e->w[W_PATCH], d.vocab,
                                                                     (const float*)e->w[W_POS], rows, d.tokens, d.width, w.x, w.rows);
-    int rc = run_blocks(e, w, bp, st);
+    cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 1);
+    int rc = run_blocks(e, w, pad, st);
     if (rc) return rc;
-    return run_head(e, w, batch, bp, out, normalize, st);
+    return run_head(e, w, pad, out, normalize, st);
 }
