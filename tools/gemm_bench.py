@@ -20,7 +20,7 @@ def bench(m, n, k, act=0, bias=True, res=False, iters=20):
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    M = B * 197
+    M = (B * 197 + 255) // 256 * 256
     bench(M, 2304, 768)
     bench(M, 768, 768, res=True)
     bench(M, 3072, 768, act=1)

@@ -1,0 +1,45 @@
+"""Summarise FETCH_SIZE / WRITE_SIZE passes of rocprofv3 for the dominant GEMM (ViT fc1) and the LayerNorm calibration kernel.
+
+usage: python tools/pmc_traffic.py FETCH_DIR WRITE_DIR M N K OUT.json
+Full-size launches are those within 10% of the largest counter value of the kernel (the last, partial batch is dropped).
+FETCH_SIZE is doubled (gfx950: 128-byte requests tallied at 64 B, MI355X guide); the doubling is checked in the same run on
+layernorm_kernel, whose read is exactly rows*width*2 bytes.
+"""
+import csv, glob, json, sys
+
+def load(d, counter):
+    out = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                out.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+    return out
+
+def full(vals):
+    m = max(vals)
+    sel = [v for v in vals if v > 0.9 * m]
+    return len(sel), sum(sel) / len(sel)
+
+fd, wd, M, N, K, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+fc1 = [k for k in fetch if "gemm_w4_kernel" in k and "Li1ELb1ELb0" in k]
+ln = [k for k in fetch if "layernorm_kernel" in k]
+assert fc1 and ln, (list(fetch)[:5])
+nf, f_kb = full(fetch[fc1[0]]); nw, w_kb = full(write[fc1[0]])
+nlf, lf_kb = full(fetch[ln[0]]); nlw, lw_kb = full(write[ln[0]])
+ln_bytes = M * 768 * 2
+res = {
+    "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual> (ViT fc1) m=%d n=%d k=%d" % (M, N, K),
+    "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 1 --warmup 0 --images 2660 --no-cpu-baseline (two separate passes)",
+    "raw": {"FETCH_SIZE": {"full_launches": nf, "avg_kb": f_kb}, "WRITE_SIZE": {"full_launches": nw, "avg_kb": w_kb},
+            "layernorm_FETCH_SIZE": {"full_launches": nlf, "avg_kb": lf_kb}, "layernorm_WRITE_SIZE": {"full_launches": nlw, "avg_kb": lw_kb}},
+    "correction": "FETCH_SIZE x2; same-run calibration on layernorm_kernel: raw fetch %.1f MB for a %.1f MB streaming read (ratio %.3f), WRITE_SIZE %.1f MB for %.1f MB written"
+                  % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, ln_bytes / 1e6),
+    "fetch_bytes_per_launch": 2 * f_kb * 1024,
+    "write_bytes_per_launch": w_kb * 1024,
+    "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
+    "algorithmic_bytes_per_launch": 2 * (M * K + N * K + M * N),
+    "rows": M,
+}
+json.dump(res, open(outp, "w"), indent=1)
+print(json.dumps(res, indent=1))
