@@ -94,7 +94,7 @@ def cpu_baseline(seed=0):
 
 
 def dominant_kernel_roofline(ms, launches, flop):
-    """fc1 GEMM of the ViT blocks (gemm_w4_kernel<QuickGELU,bias,no-residual>): [B*197,768] x [3072,768]^T.  Every launch
+    """fc1 GEMM of the ViT blocks (gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded>): [B*197,768] x [3072,768]^T.  Every launch
     inside the timed steps is bracketed by HIP events on its launch stream (scd_encoder_timing); algorithmic FLOPs =
     2*M*N*K per launch (M = 197 * batch padded to 256 images)."""
     sec = ms / 1e3
@@ -109,7 +109,7 @@ def dominant_kernel_roofline(ms, launches, flop):
         pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-            "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual> (ViT fc1, n=3072 k=768)", "launches": launches,
+            "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded> (ViT fc1, n=3072 k=768)", "launches": launches,
             "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
 

@@ -18,6 +18,11 @@ struct scd_encoder {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double timed_flop = 0.0;
+    // LayerNorm folded into the QKV / fc1 GEMMs (run_blocks): per layer W' = W * gamma (fp16), colsum[n] = sum_k W'[n][k],
+    // b'[n] = b[n] + sum_k beta[k] W[n][k]; one device allocation, owned here
+    struct Folded { const half_t *wq, *w1; const float *csq, *bq, *cs1, *b1; };
+    std::vector<Folded> folded;
+    void* folded_mem = nullptr;
 };
 
 enum { W_PATCH = 0, W_PATCH_B = 1, W_CLS = 2, W_POS = 3, W_LNPRE_W = 4, W_LNPRE_B = 5, W_LNPOST_W = 6, W_LNPOST_B = 7,
@@ -506,6 +511,53 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm folding
+// one wave per output row n: Wf[n][k] = fp16(W[n][k] * gamma[k]); colsum[n] = sum_k Wf[n][k]; biasf[n] = bias[n] + sum_k beta[k] W[n][k]
+__global__ void __launch_bounds__(256) fold_ln_kernel(const half_t* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
+                                                      half_t* __restrict__ Wf, float* __restrict__ colsum, float* __restrict__ biasf) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, bb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(size_t)n * K + k];
+        const half_t wf = (half_t)(w * gamma[k]);
+        Wf[(size_t)n * K + k] = wf;
+        cs += (float)wf;
+        bb = fmaf(beta[k], w, bb);
+    }
+    cs = wave_sum_f32(cs);
+    bb = wave_sum_f32(bb);
+    if (lane == 0) {
+        colsum[n] = cs;
+        biasf[n] = bias[n] + bb;
+    }
+}
+
+// stats[r] = {sum, sum of squares} of row r (fp16 values, fp32 accumulation); one wave per row
+__global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict__ x, long long rows, int width, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < width; c += 256) {
+        const half4 h4 = *(const half4*)(x + r * width + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float f = (float)h4[j];
+            s1 += f;
+            s2 = fmaf(f, f, s2);
+        }
+    }
+    s1 = wave_sum_f32(s1);
+    s2 = wave_sum_f32(s2);
+    if (lane == 0) {
+        stats[2 * r] = s1;
+        stats[2 * r + 1] = s2;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // Row counts are padded to the GEMM tile (256), not the image count: with 197 tokens per image a whole-image padding would
 // need multiples of 256 images.  rows: token rows; prows: patch rows (im2col); bh: rows of the CLS / EOT head.
@@ -525,6 +577,7 @@ static inline EncPad make_pad(const scd_encoder_desc& d, int batch) {
 struct EncWs {
     half_t *x, *y, *qkv, *h, *cls, *outp;
     int* rows;
+    float *stats_a, *stats_b;   // [rows][2] row sums of x for the folded LayerNorms (LN1 / LN2 input)
     size_t total;
 };
 static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
@@ -540,6 +593,8 @@ static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
     w.cls = (half_t*)take((size_t)bp * d.width * 2);
     w.outp = (half_t*)take((size_t)bp * (d.out_dim > 0 ? d.out_dim : d.width) * 2);
     w.rows = (int*)take((size_t)bp * 4);
+    w.stats_a = (float*)take(rows * 8);
+    w.stats_b = (float*)take(rows * 8);
     w.total = off + 256;
     return w;
 }
@@ -572,11 +627,37 @@ extern "C" int scd_encoder_create(scd_handle h, const scd_encoder_desc* desc, co
     scd_encoder* e = new scd_encoder();
     e->d = d;
     e->w.assign(weights, weights + n_weights);
+    // fold LN1 into the QKV weights and LN2 into the fc1 weights (used when every GEMM of a block can take the four-wave
+    // kernel: widths multiples of 256)
+    if (d.width % 256 == 0 && d.mlp_dim % 256 == 0) {
+        const size_t wq = (size_t)3 * d.width * d.width * 2, w1 = (size_t)d.mlp_dim * d.width * 2;
+        const size_t vq = scd_align((size_t)3 * d.width * 4), v1 = scd_align((size_t)d.mlp_dim * 4);
+        const size_t per_layer = scd_align(wq) + scd_align(w1) + 2 * vq + 2 * v1;
+        SCD_HIP(hipMalloc(&e->folded_mem, per_layer * d.layers));
+        char* base = (char*)e->folded_mem;
+        for (int l = 0; l < d.layers; ++l) {
+            const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
+            char* p = base + per_layer * l;
+            half_t* fwq = (half_t*)p; p += scd_align(wq);
+            half_t* fw1 = (half_t*)p; p += scd_align(w1);
+            float* csq = (float*)p; p += vq;
+            float* bq = (float*)p; p += vq;
+            float* cs1 = (float*)p; p += v1;
+            float* b1 = (float*)p;
+            fold_ln_kernel<<<(3 * d.width + 3) / 4, 256>>>((const half_t*)lw[L_QKV_W], (const float*)lw[L_LN1_W], (const float*)lw[L_LN1_B],
+                                                           (const float*)lw[L_QKV_B], 3 * d.width, d.width, fwq, csq, bq);
+            fold_ln_kernel<<<(d.mlp_dim + 3) / 4, 256>>>((const half_t*)lw[L_FC1_W], (const float*)lw[L_LN2_W], (const float*)lw[L_LN2_B],
+                                                         (const float*)lw[L_FC1_B], d.mlp_dim, d.width, fw1, cs1, b1);
+            e->folded.push_back({fwq, fw1, csq, bq, cs1, b1});
+        }
+        SCD_HIP(hipDeviceSynchronize());
+    }
     *out = e;
     return SCD_OK;
 }
 
 extern "C" int scd_encoder_destroy(scd_encoder* e) {
+    if (e && e->folded_mem) hipFree(e->folded_mem);
     delete e;
     return SCD_OK;
 }
@@ -617,12 +698,26 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     const int bp = pad.batch;          // attention runs over the real images only
     const int act = d.act == 0 ? SCD_ACT_QUICKGELU : SCD_ACT_GELU;
     const int causal = d.kind == 1;
+    // LayerNorm folded into the GEMMs (gemm.h scd_gemm_ln): the QKV / fc1 GEMMs read the raw residual stream x and apply
+    // mean / rstd in their epilogue; the row statistics come from the epilogue of the GEMM that wrote x (proj / fc2), for
+    // layer 0 from row_stats_kernel.  Two of the seven kernels of a block disappear.  SCD_LN_FUSE=0 restores the LN kernels.
+    static const int ln_fuse_env = getenv("SCD_LN_FUSE") ? atoi(getenv("SCD_LN_FUSE")) : 1;
+    const bool fuse = ln_fuse_env && !e->folded.empty() && rows % 256 == 0;
+    const size_t stats_bytes = (size_t)rows * 8;
+    if (fuse) row_stats_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, rows, d.width, w.stats_a);
     for (int l = 0; l < d.layers; ++l) {
         const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
-        layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN1_W],
-                                                                       (const float*)lw[L_LN1_B], w.y);
-        int rc = scd_gemm_launch(w.y, (const half_t*)lw[L_QKV_W], (const float*)lw[L_QKV_B], nullptr, w.qkv, rows, 3 * d.width,
+        int rc;
+        if (fuse) {
+            SCD_HIP(hipMemsetAsync(w.stats_b, 0, stats_bytes, st));
+            scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr};
+            rc = scd_gemm_launch_ln(w.x, e->folded[l].wq, e->folded[l].bq, nullptr, w.qkv, rows, 3 * d.width, d.width, SCD_ACT_NONE, &ln, st);
+        } else {
+            layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN1_W],
+                                                                           (const float*)lw[L_LN1_B], w.y);
+            rc = scd_gemm_launch(w.y, (const half_t*)lw[L_QKV_W], (const float*)lw[L_QKV_B], nullptr, w.qkv, rows, 3 * d.width,
                                  d.width, SCD_ACT_NONE, st);
+        }
         if (rc) return rc;
         static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
         if (d.tokens > 192 && d.tokens <= 224 && !causal && attn_persist) {
@@ -635,18 +730,31 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items);
         } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
-        rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
-                             SCD_ACT_NONE, st);
-        if (rc) return rc;
-        layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
-                                                                       (const float*)lw[L_LN2_B], w.y);
+        if (fuse) {
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b};
+            rc = scd_gemm_launch_ln(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
+                                    SCD_ACT_NONE, &ln, st);
+            if (rc) return rc;
+            SCD_HIP(hipMemsetAsync(w.stats_a, 0, stats_bytes, st));
+        } else {
+            rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
+                                 SCD_ACT_NONE, st);
+            if (rc) return rc;
+            layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
+                                                                           (const float*)lw[L_LN2_B], w.y);
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (e->timing) {
             SCD_HIP(hipEventCreate(&e0));
             SCD_HIP(hipEventCreate(&e1));
             SCD_HIP(hipEventRecord(e0, st));
         }
-        rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
+        if (fuse) {
+            scd_gemm_ln ln{w.stats_b, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr};
+            rc = scd_gemm_launch_ln(w.x, e->folded[l].w1, e->folded[l].b1, nullptr, w.h, rows, d.mlp_dim, d.width, act, &ln, st);
+        } else {
+            rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
+        }
         if (rc) return rc;
         if (e->timing) {
             SCD_HIP(hipEventRecord(e1, st));
@@ -654,8 +762,14 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             me->ev.emplace_back(e0, e1);
             me->timed_flop += 2.0 * (double)rows * d.mlp_dim * d.width;
         }
-        rc = scd_gemm_launch(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
-                             SCD_ACT_NONE, st);
+        if (fuse) {
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_a};
+            rc = scd_gemm_launch_ln(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
+                                    SCD_ACT_NONE, &ln, st);
+        } else {
+            rc = scd_gemm_launch(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
+                                 SCD_ACT_NONE, st);
+        }
         if (rc) return rc;
     }
     return SCD_OK;

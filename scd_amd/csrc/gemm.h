@@ -4,3 +4,13 @@
 enum { SCD_ACT_NONE = 0, SCD_ACT_QUICKGELU = 1, SCD_ACT_GELU = 2 };
 int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
                     int act, hipStream_t st);
+
+// LayerNorm folded into the four-wave GEMM (gemm.hip, gemm_w4_kernel LN = 1 / 2).  Requires M % 256 = N % 256 = K % 64 = 0.
+struct scd_gemm_ln {
+    const float* stats_in;   // [M][2] {sum, sum of squares} of A's rows: normalise A on the fly (W, bias pre-folded) - or null
+    const float* colsum;     // [N] sum_k W'[n][k]                                       (with stats_in)
+    float inv_k, eps;        // 1 / (row length), LayerNorm epsilon                       (with stats_in)
+    float* stats_out;        // [M][2] += {sum, sum of squares} of the rows of C (atomic) - or null; needs bias + residual
+};
+int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
+                       int act, const scd_gemm_ln* ln, hipStream_t st);

@@ -652,11 +652,17 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 // hazard the compiler cannot see.
 __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
 
-template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES>
+// LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
+//         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_stats[m] = {sum_k x, sum_k x^2} of the raw input rows:
+//         out = rstd * (acc - mean * colsum[n]) + b'[n], then the activation.  The raw x goes through the MFMAs unchanged.
+// LN = 2: this GEMM produces the rows the NEXT LayerNorm normalises: the epilogue adds each row's {sum, sum of squares} of
+//         the fp16 values it stores into ln_out[m] (float atomics, one 64-row instruction per 64 rows).
+template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-               int xmode, int ng) {
+               int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
+               float ln_eps, float* __restrict__ ln_out) {
     static_assert(NT == 8, "wave tile is 128 x 128");
     constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -759,9 +765,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #pragma unroll
     for (int p = 0; p < 8; ++p) issue_a(p, 1);
     issue_advance();
-    half8 rq[3][4];
+    constexpr int RD = LN == 2 ? 2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
+    half8 rq[RD][4];
 #pragma unroll
-    for (int e = 0; e < 3; ++e)
+    for (int e = 0; e < RD; ++e)
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -839,13 +846,15 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         const int nb0 = bn * BN + wn * 128;
         const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
         f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
-        f32x4v bq[8];
+        f32x4v bq[8], sq[8];
+        float2 lst[8];
+        float keep1[2] = {0.f, 0.f}, keep2[2] = {0.f, 0.f};   // LN = 2: this lane's rows 4*c16 + 64*j + q16
         // bias and the first residual rows are fetched one chunk before the tile ends: a plain load issued in the epilogue
         // would sit behind the ring refills in the (in-order) vmcnt queue and stall on them.
 #define W4_PRE()                                                                                                 \
     {                                                                                                            \
         if (HAS_RES) {                                                                                           \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
+            _Pragma("unroll") for (int e = 0; e < RD - 1; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
                 *(const half8*)(R + ((size_t)bm * BM + wm * 128 + e * 16 + p * 4 + q16) * N + nb0 + c16 * 8);    \
         }                                                                                                        \
         if (HAS_BIAS) {                                                                                          \
@@ -853,6 +862,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);                              \
                 bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;                          \
             }                                                                                                    \
+        }                                                                                                        \
+        if (LN == 1) {                                                                                           \
+            _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
+                const float4 c4 = *(const float4*)(ln_colsum + nb0 + tn * 16 + q16 * 4);                         \
+                sq[tn][0] = c4.x; sq[tn][1] = c4.y; sq[tn][2] = c4.z; sq[tn][3] = c4.w;                          \
+            }                                                                                                    \
+            _Pragma("unroll") for (int tm = 0; tm < 8; ++tm)                                                     \
+                lst[tm] = *(const float2*)(ln_stats + 2 * ((size_t)bm * BM + wm * 128 + tm * 16 + c16));         \
         }                                                                                                        \
     }
         if (nkc == 1) W4_PRE()
@@ -875,10 +892,17 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             char* ep = smem + EPI + wave * 4096;
 #pragma unroll
             for (int tm = 0; tm < 8; ++tm) {
-                if (HAS_RES && tm < 6) {
+                if (HAS_RES && tm + RD - 1 < 8) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        rq[(tm + 2) % 3][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + 2) * 16 + p * 4 + q16) * N + nb0 + c16 * 8);
+                        rq[(tm + RD - 1) % RD][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + RD - 1) * 16 + p * 4 + q16) * N + nb0 + c16 * 8);
+                }
+                float rstd = 1.f, nmr = 0.f;
+                if (LN == 1) {
+                    const float mu = lst[tm].x * ln_invk;
+                    const float var = fmaxf(fmaf(-mu, mu, lst[tm].y * ln_invk), 0.f);
+                    rstd = __builtin_amdgcn_rsqf(var + ln_eps);
+                    nmr = -mu * rstd;
                 }
 #pragma unroll
                 for (int tn = 0; tn < 8; ++tn) {
@@ -887,7 +911,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                     for (int q4 = 0; q4 < 4; ++q4) {
                         float v;
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[tn][tm][q4]));
-                        if (HAS_BIAS) v += bq[tn][q4];
+                        if (LN == 1) v = fmaf(v, rstd, fmaf(nmr, sq[tn][q4], HAS_BIAS ? bq[tn][q4] : 0.f));
+                        else if (HAS_BIAS) v += bq[tn][q4];
                         o[q4] = (half_t)act_apply(v, ACT);
                     }
                     *(half4*)(ep + c16 * 256 + (((tn * 2 + (q16 >> 1)) ^ c16) << 4) + (q16 & 1) * 8) = o;
@@ -897,13 +922,42 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                     const int rr = p * 4 + q16;
                     half8 hv = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
                     const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + tm * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
-                    if (HAS_RES) hv = hv + rq[tm % 3][p];   // fp16 add of two fp16 values: the same rounding as via fp32
+                    if (HAS_RES) hv = hv + rq[tm % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
+                    if (LN == 2) {
+                        // row sums of the stored fp16 values over this wave's 128 columns: 8 values in-lane, then the 16 lanes
+                        // (c16) that share row rr by DPP (rotations by 8 and 4 inside the 16-lane row, then inside the quad)
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float f = (float)hv[q];
+                            s1 += f;
+                            s2 = fmaf(f, f, s2);
+                        }
+#define W4_DPP_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xF, 0xF, true))
+                        W4_DPP_ADD(s1, 0x128); W4_DPP_ADD(s2, 0x128);   // row_ror:8
+                        W4_DPP_ADD(s1, 0x124); W4_DPP_ADD(s2, 0x124);   // row_ror:4
+                        W4_DPP_ADD(s1, 0x4E); W4_DPP_ADD(s2, 0x4E);     // quad_perm [2,3,0,1]
+                        W4_DPP_ADD(s1, 0xB1); W4_DPP_ADD(s2, 0xB1);     // quad_perm [1,0,3,2]
+#undef W4_DPP_ADD
+                        // every lane of the row group now holds the totals; lane c16 keeps those of (tm*4+p) == c16 (mod 16)
+                        const bool mine = ((tm * 4 + p) & 15) == c16;
+                        keep1[tm >> 2] = mine ? s1 : keep1[tm >> 2];
+                        keep2[tm >> 2] = mine ? s2 : keep2[tm >> 2];
+                    }
                     // a large C streams past L2 ("nt"): written normally, each round of tiles pushes 32 MB of dirty lines
                     // through the 32 MB of L2 and evicts the W panels every CU is about to re-read (measured +12 % on the
                     // n = 2304 / 3072 shapes, nothing on n = 768)
                     if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
                     else if (!(xmode & 2)) *(half8*)(C + off) = hv;
                 }
+            }
+        }
+        if (LN == 2 && !(xmode & 16)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* dst = ln_out + 2 * ((size_t)bm * BM + wm * 128 + 4 * c16 + 64 * j + q16);
+                unsafeAtomicAdd(dst, keep1[j]);
+                unsafeAtomicAdd(dst + 1, keep2[j]);
             }
         }
         if (ti + 1 < my_tiles) it_step(cit);
@@ -955,13 +1009,14 @@ static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
     return ng;
 }
 
-template <int NT, int ACT, bool B, bool RR>
-static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K, hipStream_t st) {
+template <int NT, int ACT, bool B, bool RR, int LN>
+static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
+                     const scd_gemm_ln* ln, hipStream_t st) {
     constexpr int LDS = 2 * 65536 + 16384;
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
     static bool attr = false;
     if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<NT, ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SCD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
@@ -971,20 +1026,36 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     const int xmode = xenv | (nt ? 512 : 0);
     const int ng = choose_ng(M, K, tiles_n, total, 256);
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
-    gemm_w4_kernel<NT, ACT, B, RR><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+    gemm_w4_kernel<NT, ACT, B, RR, LN><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
+                                                               LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
+                                                               LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,
+                                                               LN == 2 ? ln->stats_out : nullptr);
     if (xmode & 64) {
         static unsigned long long h[256 * 4];
         SCD_HIP(hipDeviceSynchronize());
         SCD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4_dbg), sizeof(h)));
-        double tm = 0, te = 0, tt = 0, nt = 0;
-        for (int b = 0; b < grid; ++b) { tm += h[b * 4]; te += h[b * 4 + 1]; nt += h[b * 4 + 2]; tt += h[b * 4 + 3]; }
+        double tm = 0, te = 0, tt = 0, nt2 = 0;
+        for (int b = 0; b < grid; ++b) { tm += h[b * 4]; te += h[b * 4 + 1]; nt2 += h[b * 4 + 2]; tt += h[b * 4 + 3]; }
         if (xmode & 128)
-            fprintf(stderr, "[w4 m=%d n=%d k=%d] per chunk: even %.0f, wait+barrier %.0f, odd(+epilogue share) %.0f cyc\n", M, N, K, tm / tt, te / tt, nt / tt);
+            fprintf(stderr, "[w4 m=%d n=%d k=%d] per chunk: even %.0f, wait+barrier %.0f, odd(+epilogue share) %.0f cyc\n", M, N, K, tm / tt, te / tt, nt2 / tt);
         else
-        fprintf(stderr, "[w4 m=%d n=%d k=%d] per tile: main %.0f cyc, epilogue %.0f cyc; per block total %.0f cyc, tiles %.1f\n", M, N, K,
-                tm / nt, te / nt, tt / grid, nt / grid);
+            fprintf(stderr, "[w4 m=%d n=%d k=%d] per tile: main %.0f cyc, epilogue %.0f cyc; per block total %.0f cyc, tiles %.1f\n", M, N, K,
+                    tm / nt2, te / nt2, tt / grid, nt2 / grid);
     }
     return SCD_OK;
+}
+
+// the LayerNorm-folded variants exist for the shapes the encoders use: bias, no residual (LN = 1) and bias + residual (LN = 2)
+static int launch_w4_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K, int act,
+                        const scd_gemm_ln* ln, hipStream_t st) {
+    if (ln->stats_in) {
+        if (!bias || R || ln->stats_out) return SCD_EINVAL;
+        if (act == SCD_ACT_NONE) return launch_w4<8, SCD_ACT_NONE, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
+        if (act == SCD_ACT_QUICKGELU) return launch_w4<8, SCD_ACT_QUICKGELU, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
+        return launch_w4<8, SCD_ACT_GELU, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
+    }
+    if (!bias || !R || act != SCD_ACT_NONE) return SCD_EINVAL;
+    return launch_w4<8, SCD_ACT_NONE, true, true, 2>(A, W, bias, R, C, M, N, K, ln, st);
 }
 
 template <int BM, int ACT, bool B, bool RR>
@@ -1003,7 +1074,7 @@ static int launch_dma(const half_t* A, const half_t* W, const float* bias, const
     const int ng = choose_ng(M, K, tiles_n, total, resident);
     static const int mfma_sel = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) : 4;   // 4: four-wave kernel (default); 16 / 32: eight-wave kernels
     const bool mfma16 = mfma_sel == 16;
-    if (BM == 256 && mfma_sel == 4) return launch_w4<8, ACT, B, RR>(A, W, bias, R, C, M, N, K, st);
+    if (BM == 256 && mfma_sel == 4) return launch_w4<8, ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
     if (BM == 256 && mfma16) {
         static bool attr16 = false;
         if (!attr16) {
@@ -1040,6 +1111,18 @@ static void launch_act(const half_t* A, const half_t* W, const float* bias, cons
     else if (bias) gemm_f16_kernel<ACT, true, false><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
     else if (R) gemm_f16_kernel<ACT, false, true><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
     else gemm_f16_kernel<ACT, false, false><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
+}
+
+int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
+                       int act, const scd_gemm_ln* ln, hipStream_t st) {
+    SCD_REQUIRE(ln && (ln->stats_in || ln->stats_out), "gemm_ln: no LayerNorm term");
+    SCD_REQUIRE(A && W && C && M > 0 && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && M < (1ll << 31),
+                "gemm_ln: shape m=%lld n=%d k=%d must be multiples of 256/256/64", (long long)M, N, K);
+    SCD_REQUIRE(C != (half_t*)A, "gemm_ln: C must not alias A");
+    const int rc = launch_w4_ln(A, W, bias, R, C, (int)M, N, K, act, ln, st);
+    SCD_REQUIRE(rc == SCD_OK, "gemm_ln: unsupported combination (bias %d residual %d act %d)", bias != nullptr, R != nullptr, act);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
 }
 
 int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
