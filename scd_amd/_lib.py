@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libscd_hip.so")
+_LIB_PATH = os.environ.get("SCD_HIP_LIB") or os.path.join(_HERE, "lib", "libscd_hip.so")   # override: A/B runs of two builds
 
 SCD_OK, SCD_EINVAL, SCD_EHIP, SCD_ERCCL, SCD_EINFEASIBLE = 0, -1, -2, -3, -4
 SCD_F32, SCD_F16 = 0, 1
