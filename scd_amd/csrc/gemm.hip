@@ -652,6 +652,9 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 // the accumulators between AGPRs and VGPRs around every group), C = 0 on a tile's first sub-step instead of zeroing,
 // ds_read_b128 with counted lgkmcnt (for asm operands hipcc only emits lgkmcnt(0)); s_nop covers the MFMA -> v_accvgpr_read
 // hazard the compiler cannot see.
+#ifndef W4_DMA_SPLIT
+#define W4_DMA_SPLIT 1
+#endif
 __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
 
 // LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
@@ -666,6 +669,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
                float ln_eps, float* __restrict__ ln_out) {
     static_assert(NT == 8, "wave tile is 128 x 128");
+    constexpr bool DMA_SPLIT = W4_DMA_SPLIT;   // true: A part of a refill in the odd sub-step, W part in the next even one
     constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -766,6 +770,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     if (chunks > 1) chunk_ptrs(nit, nkt); else chunk_ptrs(cit, 0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) issue_a(p, 1);
+    if (!DMA_SPLIT) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) issue_w(p, 1);
+    }
     issue_advance();
     constexpr int RD = LN == 2 ? 2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
     half8 rq[RD][4];
@@ -779,7 +787,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     half8 fwA[8], fwB[8], faA[8], faB[8];   // W / A fragments of the even (A) and odd (B) sub-step
 #define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W4_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (DMA_SPLIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -803,7 +812,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // even sub-step: reads the odd sub-step's fragments (k-half 1 of the same slot) under MFMAs 0..47 and issues the W part
     // of the refill that the previous odd sub-step began (the other slot), one fill per four MFMAs of the first half
 #define W4_H_EVEN(i)                                                                                             \
-    if ((i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);                                          \
+    if (DMA_SPLIT && (i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);                             \
     if ((i) < 48 && (i) % 3 == 0) W4_RD(fwB[((i) / 3) & 7], fw1 + so, (((i) / 3) & 7) * 2048);                   \
     if ((i) < 48 && (i) % 3 == 1) W4_RD(faB[((i) / 3) & 7], fa1 + so, (((i) / 3) & 7) * 2048);
     // odd sub-step: reads the next chunk's first fragments (other slot) under MFMAs 0..47 and starts refilling this slot with
@@ -813,7 +822,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_H_ODD(i)                                                                                              \
     if ((i) < 48 && (i) % 3 == 0) W4_RD(fwA[((i) / 3) & 7], fw0 + no, (((i) / 3) & 7) * 2048);                   \
     if ((i) < 48 && (i) % 3 == 1) W4_RD(faA[((i) / 3) & 7], fa0 + no, (((i) / 3) & 7) * 2048);                   \
-    if (((i) & 7) == 4) issue_a(((i) >> 3) & 7, cslot);
+    if (DMA_SPLIT && ((i) & 7) == 4) issue_a(((i) >> 3) & 7, cslot);                                             \
+    if (!DMA_SPLIT && ((i) & 3) == 2) { if ((i) < 32) issue_a(((i) >> 2) & 7, cslot); else issue_w(((i) >> 2) & 7, cslot); }
 #define W4_EVEN(Z)                                                                                               \
     {                                                                                                            \
         const unsigned so = cslot * SLOT;                                                                        \
