@@ -902,80 +902,95 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             // between the patch writes and reads: one wave's LDS operations execute in order.  Residual rows are fetched two
             // m-tiles ahead (ring of three).
             char* ep = smem + EPI + wave * 4096;
+            // software pipeline over the 8 m-tiles: the patch read of m-tile tm-1 is in flight while m-tile tm is converted,
+            // and its rows are stored after that (one wave per SIMD: nothing else would cover the LDS round trip)
+            half8 hvb[4];
 #pragma unroll
-            for (int tm = 0; tm < 8; ++tm) {
-                if (HAS_RES && tm + RD - 1 < 8) {
+            for (int tm = 0; tm <= 8; ++tm) {
+                if (tm < 8) {
+                    float rstd = 1.f, nmr = 0.f;
+                    if (LN == 1) {
+                        const float mu = lst[tm].x * ln_invk;
+                        const float var = fmaxf(fmaf(-mu, mu, lst[tm].y * ln_invk), 0.f);
+                        rstd = __builtin_amdgcn_rsqf(var + ln_eps);
+                        nmr = -mu * rstd;
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < 8; ++tn) {
+                        // four values as two register pairs, so that bias / LayerNorm terms are packed-fp32 operations and the
+                        // fp16 conversion is v_cvt_pk_f16_f32 (8-10 VALU instructions per 4 values instead of 14)
+                        float2v v01, v23;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v01.x) : "a"(acc[tn][tm][0]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v01.y) : "a"(acc[tn][tm][1]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.x) : "a"(acc[tn][tm][2]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.y) : "a"(acc[tn][tm][3]));
+                        if (LN == 1) {
+                            const float2v r2 = {rstd, rstd}, m2 = {nmr, nmr};
+                            float2v t01 = m2 * sq[tn].lo, t23 = m2 * sq[tn].hi;
+                            if (HAS_BIAS) { t01 += bq[tn].lo; t23 += bq[tn].hi; }
+                            v01 = v01 * r2 + t01;
+                            v23 = v23 * r2 + t23;
+                        } else if (HAS_BIAS) {
+                            v01 += bq[tn].lo;
+                            v23 += bq[tn].hi;
+                        }
+                        if (ACT != SCD_ACT_NONE) {
+                            v01.x = act_apply(v01.x, ACT); v01.y = act_apply(v01.y, ACT);
+                            v23.x = act_apply(v23.x, ACT); v23.y = act_apply(v23.y, ACT);
+                        }
+                        const half2v h01 = __builtin_convertvector(v01, half2v), h23 = __builtin_convertvector(v23, half2v);
+                        const half4 o = {h01.x, h01.y, h23.x, h23.y};
+                        *(half4*)(ep + c16 * 256 + (((tn * 2 + (q16 >> 1)) ^ c16) << 4) + (q16 & 1) * 8) = o;
+                    }
+                }
+                if (tm > 0) {
+                    const int ts = tm - 1;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int rr = p * 4 + q16;
+                        half8 hv = hvb[p];
+                        const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + ts * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
+                        if (HAS_RES) hv = hv + rq[ts % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
+                        if (LN == 2) {
+                            // row sums of the stored fp16 values over this wave's 128 columns: 8 values in-lane, then the 16 lanes
+                            // (c16) that share row rr by DPP (rotations by 8 and 4 inside the 16-lane row, then inside the quad)
+                            float s1 = 0.f, s2 = 0.f;
+                            const half2v ones = {(half_t)1.f, (half_t)1.f};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {   // v_dot2_f32_f16: exact fp16 products, fp32 accumulation
+                                const half2v pr = {hv[2 * q], hv[2 * q + 1]};
+                                s1 = __builtin_amdgcn_fdot2(pr, ones, s1, false);
+                                s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
+                            }
+#define W4_DPP_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xF, 0xF, true))
+                            W4_DPP_ADD(s1, 0x128); W4_DPP_ADD(s2, 0x128);   // row_ror:8
+                            W4_DPP_ADD(s1, 0x124); W4_DPP_ADD(s2, 0x124);   // row_ror:4
+                            W4_DPP_ADD(s1, 0x4E); W4_DPP_ADD(s2, 0x4E);     // quad_perm [2,3,0,1]
+                            W4_DPP_ADD(s1, 0xB1); W4_DPP_ADD(s2, 0xB1);     // quad_perm [1,0,3,2]
+#undef W4_DPP_ADD
+                            // every lane of the row group now holds the totals; lane c16 keeps those of (tm*4+p) == c16 (mod 16)
+                            const bool mine = ((ts * 4 + p) & 15) == c16;
+                            keep1[ts >> 2] = mine ? s1 : keep1[ts >> 2];
+                            keep2[ts >> 2] = mine ? s2 : keep2[ts >> 2];
+                        }
+                        // a large C streams past L2 ("nt"): written normally, each round of tiles pushes 32 MB of dirty lines
+                        // through the 32 MB of L2 and evicts the W panels every CU is about to re-read (measured +12 % on the
+                        // n = 2304 / 3072 shapes, nothing on n = 768)
+                        if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                        else if (!(xmode & 2)) *(half8*)(C + off) = hv;
+                    }
+                }
+                if (HAS_RES && tm < 8 && tm + RD - 1 < 8) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         rq[(tm + RD - 1) % RD][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + RD - 1) * 16 + p * 4 + q16) * N + nb0 + c16 * 8);
                 }
-                float rstd = 1.f, nmr = 0.f;
-                if (LN == 1) {
-                    const float mu = lst[tm].x * ln_invk;
-                    const float var = fmaxf(fmaf(-mu, mu, lst[tm].y * ln_invk), 0.f);
-                    rstd = __builtin_amdgcn_rsqf(var + ln_eps);
-                    nmr = -mu * rstd;
-                }
+                if (tm < 8) {
 #pragma unroll
-                for (int tn = 0; tn < 8; ++tn) {
-                    // four values as two register pairs, so that bias / LayerNorm terms are packed-fp32 operations and the
-                    // fp16 conversion is v_cvt_pk_f16_f32 (8-10 VALU instructions per 4 values instead of 14)
-                    float2v v01, v23;
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v01.x) : "a"(acc[tn][tm][0]));
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v01.y) : "a"(acc[tn][tm][1]));
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.x) : "a"(acc[tn][tm][2]));
-                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.y) : "a"(acc[tn][tm][3]));
-                    if (LN == 1) {
-                        const float2v r2 = {rstd, rstd}, m2 = {nmr, nmr};
-                        float2v t01 = m2 * sq[tn].lo, t23 = m2 * sq[tn].hi;
-                        if (HAS_BIAS) { t01 += bq[tn].lo; t23 += bq[tn].hi; }
-                        v01 = v01 * r2 + t01;
-                        v23 = v23 * r2 + t23;
-                    } else if (HAS_BIAS) {
-                        v01 += bq[tn].lo;
-                        v23 += bq[tn].hi;
+                    for (int p = 0; p < 4; ++p) {
+                        const int rr = p * 4 + q16;
+                        hvb[p] = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
                     }
-                    if (ACT != SCD_ACT_NONE) {
-                        v01.x = act_apply(v01.x, ACT); v01.y = act_apply(v01.y, ACT);
-                        v23.x = act_apply(v23.x, ACT); v23.y = act_apply(v23.y, ACT);
-                    }
-                    const half2v h01 = __builtin_convertvector(v01, half2v), h23 = __builtin_convertvector(v23, half2v);
-                    const half4 o = {h01.x, h01.y, h23.x, h23.y};
-                    *(half4*)(ep + c16 * 256 + (((tn * 2 + (q16 >> 1)) ^ c16) << 4) + (q16 & 1) * 8) = o;
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int rr = p * 4 + q16;
-                    half8 hv = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
-                    const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + tm * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
-                    if (HAS_RES) hv = hv + rq[tm % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
-                    if (LN == 2) {
-                        // row sums of the stored fp16 values over this wave's 128 columns: 8 values in-lane, then the 16 lanes
-                        // (c16) that share row rr by DPP (rotations by 8 and 4 inside the 16-lane row, then inside the quad)
-                        float s1 = 0.f, s2 = 0.f;
-                        const half2v ones = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {   // v_dot2_f32_f16: exact fp16 products, fp32 accumulation
-                            const half2v pr = {hv[2 * q], hv[2 * q + 1]};
-                            s1 = __builtin_amdgcn_fdot2(pr, ones, s1, false);
-                            s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
-                        }
-#define W4_DPP_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xF, 0xF, true))
-                        W4_DPP_ADD(s1, 0x128); W4_DPP_ADD(s2, 0x128);   // row_ror:8
-                        W4_DPP_ADD(s1, 0x124); W4_DPP_ADD(s2, 0x124);   // row_ror:4
-                        W4_DPP_ADD(s1, 0x4E); W4_DPP_ADD(s2, 0x4E);     // quad_perm [2,3,0,1]
-                        W4_DPP_ADD(s1, 0xB1); W4_DPP_ADD(s2, 0xB1);     // quad_perm [1,0,3,2]
-#undef W4_DPP_ADD
-                        // every lane of the row group now holds the totals; lane c16 keeps those of (tm*4+p) == c16 (mod 16)
-                        const bool mine = ((tm * 4 + p) & 15) == c16;
-                        keep1[tm >> 2] = mine ? s1 : keep1[tm >> 2];
-                        keep2[tm >> 2] = mine ? s2 : keep2[tm >> 2];
-                    }
-                    // a large C streams past L2 ("nt"): written normally, each round of tiles pushes 32 MB of dirty lines
-                    // through the 32 MB of L2 and evicts the W panels every CU is about to re-read (measured +12 % on the
-                    // n = 2304 / 3072 shapes, nothing on n = 768)
-                    if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
-                    else if (!(xmode & 2)) *(half8*)(C + off) = hv;
                 }
             }
         }
