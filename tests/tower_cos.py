@@ -1,6 +1,6 @@
 """Print the worst cosine between the HIP towers and the fp32 oracle (same inputs as tests/test_gpu_parity.py)."""
 import sys, os, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root (this script lives in tests/: it uses the oracle)
 sys.path.insert(0, ROOT)
 from scd_amd.clip import weights as W
 from scd_amd.clip.model import CLIP, DinoViT
