@@ -2,7 +2,17 @@
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scd_amd import ops
-from oracle import synth
+
+
+def clustered_features(n, d, k, seed, center_seed, noise):
+    """k Gaussian blobs (unit-norm random centres, isotropic noise scaled so that neighbouring blobs overlap a little)."""
+    rs = np.random.RandomState(center_seed)
+    cent = rs.randn(k, d).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    rs = np.random.RandomState(seed)
+    y = rs.randint(0, k, size=n)
+    x = cent[y] + (noise / np.sqrt(d)) * rs.randn(n, d).astype(np.float32)
+    return x.astype(np.float32), y, cent
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -15,7 +25,7 @@ def timeit(fn, iters=20):
 if __name__ == "__main__":
     n, d, k = 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, 100
     noise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
-    x, y, cent = synth.clustered_features(n, d, k, seed=21, center_seed=22, noise=noise)
+    x, y, cent = clustered_features(n, d, k, seed=21, center_seed=22, noise=noise)
     X = torch.from_numpy(x).cuda(); C = torch.from_numpy(cent).cuda()
     C2 = X[torch.randperm(n, device="cuda")[:k]].clone()          # k-means++-like start: data points as centres
     data = ops.KMeansData(X)
