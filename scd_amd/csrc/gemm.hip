@@ -934,7 +934,18 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                             v01 += bq[tn].lo;
                             v23 += bq[tn].hi;
                         }
-                        if (ACT != SCD_ACT_NONE) {
+                        if (ACT == SCD_ACT_QUICKGELU) {
+                            // x * sigmoid(1.702 x) = x * rcp(1 + 2^(-1.702 log2(e) x)): the three non-transcendental steps packed
+                            const float2v c2 = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
+                            const float2v one2 = {1.f, 1.f};
+                            float2v e01 = v01 * c2, e23 = v23 * c2;
+                            e01.x = __builtin_amdgcn_exp2f(e01.x); e01.y = __builtin_amdgcn_exp2f(e01.y);
+                            e23.x = __builtin_amdgcn_exp2f(e23.x); e23.y = __builtin_amdgcn_exp2f(e23.y);
+                            e01 += one2; e23 += one2;
+                            e01.x = __builtin_amdgcn_rcpf(e01.x); e01.y = __builtin_amdgcn_rcpf(e01.y);
+                            e23.x = __builtin_amdgcn_rcpf(e23.x); e23.y = __builtin_amdgcn_rcpf(e23.y);
+                            v01 *= e01; v23 *= e23;
+                        } else if (ACT != SCD_ACT_NONE) {
                             v01.x = act_apply(v01.x, ACT); v01.y = act_apply(v01.y, ACT);
                             v23.x = act_apply(v23.x, ACT); v23.y = act_apply(v23.y, ACT);
                         }
