@@ -655,6 +655,12 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_DMA_SPLIT
 #define W4_DMA_SPLIT 1
 #endif
+#ifndef W4_LATE_BAR
+#define W4_LATE_BAR 1
+#endif
+#ifndef W4_LATE_TM
+#define W4_LATE_TM 2
+#endif
 __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
 
 // LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
@@ -669,7 +675,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
                float ln_eps, float* __restrict__ ln_out) {
     static_assert(NT == 8, "wave tile is 128 x 128");
-    constexpr bool DMA_SPLIT = W4_DMA_SPLIT;   // true: A part of a refill in the odd sub-step, W part in the next even one
+    constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
+    constexpr bool LATE_BAR = W4_LATE_BAR;     // the chunk's barrier after the odd sub-step's first L0 MFMAs instead of before them
+    constexpr int L0 = W4_LATE_TM * 8, LS = (64 - L0) / 8;   // first hooked MFMA; MFMAs per ring fill   // true: A part of a refill in the odd sub-step, W part in the next even one
     constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -801,14 +809,16 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // has to issue - the fragment reads of the NEXT sub-step and the ring refill - is spread between the MFMAs through the
     // hook: issued back to back they hold up the wave's in-order instruction stream, and with it the matrix pipe, for as
     // long as the LDS / texture queues take to accept them.
-#define W4_SUB(FW, FA, Z, HOOK)                                                                                  \
+#define W4_SUB(FW, FA, Z, HOOK) W4_SUB_RANGE(FW, FA, Z, HOOK, 0, 8)
+#define W4_SUB_RANGE(FW, FA, Z, HOOK, TM0, TM1)                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int tm = 0; tm < 8; ++tm) _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {            \
+    _Pragma("unroll") for (int tm = (TM0); tm < (TM1); ++tm) _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {     \
         if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));         \
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));          \
         HOOK(tm * 8 + tn)                                                                                        \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);
+#define W4_H_NONE(i)
     // even sub-step: reads the odd sub-step's fragments (k-half 1 of the same slot) under MFMAs 0..47 and issues the W part
     // of the refill that the previous odd sub-step began (the other slot), one fill per four MFMAs of the first half
 #define W4_H_EVEN(i)                                                                                             \
@@ -820,10 +830,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // fill while the CU's texture path (64 B/clk) takes the four waves' 1 KB instructions, so 16 fills inside one sub-step
     // doubled its length; spread over two sub-steps they fit under the MFMAs.
 #define W4_H_ODD(i)                                                                                              \
-    if ((i) < 48 && (i) % 3 == 0) W4_RD(fwA[((i) / 3) & 7], fw0 + no, (((i) / 3) & 7) * 2048);                   \
-    if ((i) < 48 && (i) % 3 == 1) W4_RD(faA[((i) / 3) & 7], fa0 + no, (((i) / 3) & 7) * 2048);                   \
-    if (DMA_SPLIT && ((i) & 7) == 4) issue_a(((i) >> 3) & 7, cslot);                                             \
-    if (!DMA_SPLIT && ((i) & 3) == 2) { if ((i) < 32) issue_a(((i) >> 2) & 7, cslot); else issue_w(((i) >> 2) & 7, cslot); }
+    if (!LATE_BAR && (i) < 48 && (i) % 3 == 0) W4_RD(fwA[((i) / 3) & 7], fw0 + no, (((i) / 3) & 7) * 2048);      \
+    if (!LATE_BAR && (i) < 48 && (i) % 3 == 1) W4_RD(faA[((i) / 3) & 7], fa0 + no, (((i) / 3) & 7) * 2048);      \
+    if (!LATE_BAR && DMA_SPLIT && ((i) & 7) == 4) issue_a(((i) >> 3) & 7, cslot);                                \
+    if (!DMA_SPLIT && ((i) & 3) == 2) { if ((i) < 32) issue_a(((i) >> 2) & 7, cslot); else issue_w(((i) >> 2) & 7, cslot); } \
+    /* LATE_BAR: the barrier sits after MFMA L0-1, so everything that needs it is packed under MFMAs L0..63 */    \
+    if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) < 8) W4_RD(fwA[(((i) - L0) >> 1) & 7], fw0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
+    if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) >= 8 && (((i) - L0) >> 1) < 16) W4_RD(faA[(((i) - L0) >> 1) & 7], fa0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
+    if (LATE_BAR && DMA_SPLIT && (i) >= L0 && ((i) - L0) % LS == LS / 2 && ((i) - L0) / LS < 8) issue_a((((i) - L0) / LS) & 7, cslot);
 #define W4_EVEN(Z)                                                                                               \
     {                                                                                                            \
         const unsigned so = cslot * SLOT;                                                                        \
@@ -839,6 +853,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_even += t - t_sub; t_sub = t; } \
         /* chunk g+1: A part issued under the previous odd sub-step, W part under the even one just finished; an epilogue's  \
            stores, if any, sit between the two in the in-order queue, so this waits for them as well */                 \
+        if (LATE_BAR) { W4_SUB_RANGE(fwB, faB, 0, W4_H_NONE, 0, W4_LATE_TM) }   /* MFMAs that need nothing new */    \
         if (!(xmode & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_s_barrier();                                                                            \
         asm volatile("" ::: "memory");                                                                           \
@@ -847,7 +862,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
            around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
         if (g + 2 < chunks) chunk_ptrs(nit, nkt); else chunk_ptrs(cit, 0);                                       \
         issue_advance();                                                                                         \
-        W4_SUB(fwB, faB, 0, W4_H_ODD)                                                                            \
+        if (LATE_BAR) { W4_SUB_RANGE(fwB, faB, 0, W4_H_ODD, W4_LATE_TM, 8) } else { W4_SUB(fwB, faB, 0, W4_H_ODD) }  \
         cslot ^= 1;                                                                                              \
         ++g;                                                                                                     \
     }
@@ -1036,6 +1051,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #undef W4_EVEN
 #undef W4_ODD
 #undef W4_SUB
+#undef W4_SUB_RANGE
+#undef W4_H_NONE
 #undef W4_H_EVEN
 #undef W4_H_ODD
 #undef W4_DMA
