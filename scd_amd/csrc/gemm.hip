@@ -658,6 +658,9 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_LATE_BAR
 #define W4_LATE_BAR 1
 #endif
+#ifndef W4_DEFER_STORES
+#define W4_DEFER_STORES 1
+#endif
 #ifndef W4_LATE_TM
 #define W4_LATE_TM 2
 #endif
@@ -673,9 +676,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
                int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, float* __restrict__ ln_out) {
+               float ln_eps, float* __restrict__ ln_out, int stagger) {
     static_assert(NT == 8, "wave tile is 128 x 128");
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
+    constexpr bool DEFER_ST = HAS_RES && W4_DEFER_STORES;   // residual variants: all stores after the last residual load
     constexpr bool LATE_BAR = W4_LATE_BAR;     // the chunk's barrier after the odd sub-step's first L0 MFMAs instead of before them
     constexpr int L0 = W4_LATE_TM * 8, LS = (64 - L0) / 8;   // first hooked MFMA; MFMAs per ring fill   // true: A part of a refill in the odd sub-step, W part in the next even one
     constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
@@ -708,6 +712,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int chunks = my_tiles * nkc;
     if (chunks <= 0) return;
     const int tstride = per_xcd;
+    if (stagger > 0) {   // phase-shift the blocks of an XCD (see launch_w4): wall_clock64 ticks at 100 MHz
+        const long long target = wall_clock64() + (long long)(slot_id & 7) * stagger;
+        while (wall_clock64() < target) __builtin_amdgcn_s_sleep(32);
+    }
     auto it_step = [&](TileIt& it) {       // t += tstride
         it.t += tstride;
         it.bnl += it.r;
@@ -920,6 +928,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             // software pipeline over the 8 m-tiles: the patch read of m-tile tm-1 is in flight while m-tile tm is converted,
             // and its rows are stored after that (one wave per SIMD: nothing else would cover the LDS round trip)
             half8 hvb[4];
+            unsigned stash[8][16];
 #pragma unroll
             for (int tm = 0; tm <= 8; ++tm) {
                 if (tm < 8) {
@@ -1002,8 +1011,19 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         // a large C streams past L2 ("nt"): written normally, each round of tiles pushes 32 MB of dirty lines
                         // through the 32 MB of L2 and evicts the W panels every CU is about to re-read (measured +12 % on the
                         // n = 2304 / 3072 shapes, nothing on n = 768)
-                        if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
-                        else if (!(xmode & 2)) *(half8*)(C + off) = hv;
+                        if (DEFER_ST) {
+                            // residual variants: a row's residual load issued behind earlier rows' stores waits in the in-order
+                            // queue until those have drained (measured: 17 k cycles of epilogue against 6 k without the stores).
+                            // The finished rows are parked in the accumulator registers their m-tile has just vacated and all
+                            // 32 stores are issued after the last residual load.
+                            const uint4 w4 = __builtin_bit_cast(uint4, hv);
+                            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 0]) : "v"(w4.x));
+                            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 1]) : "v"(w4.y));
+                            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 2]) : "v"(w4.z));
+                            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 3]) : "v"(w4.w));
+                        } else if (xmode & 2) { /* ablation: no stores */
+                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                        else *(half8*)(C + off) = hv;
                     }
                 }
                 if (HAS_RES && tm < 8 && tm + RD - 1 < 8) {
@@ -1018,6 +1038,23 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         hvb[p] = *(const half8*)(ep + rr * 256 + ((c16 ^ rr) << 4));
                     }
                 }
+            }
+            if (DEFER_ST) {
+#pragma unroll
+                for (int ts = 0; ts < 8; ++ts)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        uint4 w4;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.x) : "a"(stash[ts][p * 4 + 0]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.y) : "a"(stash[ts][p * 4 + 1]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.z) : "a"(stash[ts][p * 4 + 2]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.w) : "a"(stash[ts][p * 4 + 3]));
+                        const half8 hv = __builtin_bit_cast(half8, w4);
+                        const size_t off = ((size_t)bm * BM + wm * 128 + ts * 16 + p * 4 + q16) * N + nb0 + c16 * 8;
+                        if (xmode & 2) { /* ablation: no stores */
+                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                        else *(half8*)(C + off) = hv;
+                    }
             }
         }
         if (LN == 2 && !(xmode & 16)) {
@@ -1096,10 +1133,12 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     const int xmode = xenv | (nt ? 512 : 0);
     const int ng = choose_ng(M, K, tiles_n, total, 256);
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
+    static const int stagger_env = getenv("SCD_GEMM_STAGGER") ? atoi(getenv("SCD_GEMM_STAGGER")) : 0;   // ticks per phase, experiment
+    const int stagger = stagger_env;
     gemm_w4_kernel<NT, ACT, B, RR, LN><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
                                                                LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
                                                                LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,
-                                                               LN == 2 ? ln->stats_out : nullptr);
+                                                               LN == 2 ? ln->stats_out : nullptr, stagger);
     if (xmode & 64) {
         static unsigned long long h[256 * 4];
         SCD_HIP(hipDeviceSynchronize());
