@@ -658,6 +658,9 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_LATE_BAR
 #define W4_LATE_BAR 1
 #endif
+#ifndef W4_TN_MAJOR
+#define W4_TN_MAJOR 0   // MFMA order inside a sub-step: 0 = m-tile outer (eight MFMAs share the A fragment), 1 = n-tile outer
+#endif
 #ifndef W4_DEFER_STORES
 #define W4_DEFER_STORES 1
 #endif
@@ -820,10 +823,11 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_SUB(FW, FA, Z, HOOK) W4_SUB_RANGE(FW, FA, Z, HOOK, 0, 8)
 #define W4_SUB_RANGE(FW, FA, Z, HOOK, TM0, TM1)                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int tm = (TM0); tm < (TM1); ++tm) _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {     \
+    _Pragma("unroll") for (int o_ = (TM0); o_ < (TM1); ++o_) _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {     \
+        const int tm = W4_TN_MAJOR ? i_ : o_, tn = W4_TN_MAJOR ? o_ : i_;                                        \
         if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));         \
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));          \
-        HOOK(tm * 8 + tn)                                                                                        \
+        HOOK(o_ * 8 + i_)                                                                                        \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);
 #define W4_H_NONE(i)
