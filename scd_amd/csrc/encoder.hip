@@ -703,14 +703,12 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     // layer 0 from row_stats_kernel.  Two of the seven kernels of a block disappear.  SCD_LN_FUSE=0 restores the LN kernels.
     static const int ln_fuse_env = getenv("SCD_LN_FUSE") ? atoi(getenv("SCD_LN_FUSE")) : 1;
     const bool fuse = ln_fuse_env && !e->folded.empty() && rows % 256 == 0;
-    const size_t stats_bytes = (size_t)rows * 8;
     if (fuse) row_stats_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, rows, d.width, w.stats_a);
     for (int l = 0; l < d.layers; ++l) {
         const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
         int rc;
         if (fuse) {
-            SCD_HIP(hipMemsetAsync(w.stats_b, 0, stats_bytes, st));
-            scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr};
+            scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_b};   // also clears stats_b
             rc = scd_gemm_launch_ln(w.x, e->folded[l].wq, e->folded[l].bq, nullptr, w.qkv, rows, 3 * d.width, d.width, SCD_ACT_NONE, &ln, st);
         } else {
             layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN1_W],
@@ -731,11 +729,10 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         if (fuse) {
-            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b};
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b, nullptr};
             rc = scd_gemm_launch_ln(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
                                     SCD_ACT_NONE, &ln, st);
             if (rc) return rc;
-            SCD_HIP(hipMemsetAsync(w.stats_a, 0, stats_bytes, st));
         } else {
             rc = scd_gemm_launch(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
                                  SCD_ACT_NONE, st);
@@ -750,7 +747,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             SCD_HIP(hipEventRecord(e0, st));
         }
         if (fuse) {
-            scd_gemm_ln ln{w.stats_b, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr};
+            scd_gemm_ln ln{w.stats_b, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_a};   // also clears stats_a
             rc = scd_gemm_launch_ln(w.x, e->folded[l].w1, e->folded[l].b1, nullptr, w.h, rows, d.mlp_dim, d.width, act, &ln, st);
         } else {
             rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
@@ -763,7 +760,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             me->timed_flop += 2.0 * (double)rows * d.mlp_dim * d.width;
         }
         if (fuse) {
-            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_a};
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_a, nullptr};
             rc = scd_gemm_launch_ln(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
                                     SCD_ACT_NONE, &ln, st);
         } else {

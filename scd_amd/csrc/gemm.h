@@ -11,6 +11,7 @@ struct scd_gemm_ln {
     const float* colsum;     // [N] sum_k W'[n][k]                                       (with stats_in)
     float inv_k, eps;        // 1 / (row length), LayerNorm epsilon                       (with stats_in)
     float* stats_out;        // [M][2] += {sum, sum of squares} of the rows of C (atomic) - or null; needs bias + residual
+    float* zero_out;         // with stats_in: a second [M][2] buffer this launch clears (the next residual GEMM's stats_out) - or null
 };
 int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
                        int act, const scd_gemm_ln* ln, hipStream_t st);

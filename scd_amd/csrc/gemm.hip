@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
                int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, float* __restrict__ ln_out, int stagger) {
+               float ln_eps, float* __restrict__ ln_out, int stagger, float* __restrict__ ln_zero) {
     static_assert(NT == 8, "wave tile is 128 x 128");
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
     constexpr bool DEFER_ST = HAS_RES && W4_DEFER_STORES;   // residual variants: all stores after the last residual load
@@ -712,6 +712,11 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
     const int tb = c0 + slot_id;
     const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
+    if (LN == 1 && ln_zero) {   // clear the OTHER statistics buffer (2*M floats) for the residual GEMM that follows: saves a memset launch
+        float4* z = (float4*)ln_zero;
+        const int n4 = M / 2;
+        for (int i = blockIdx.x * 256 + tid; i < n4; i += gridDim.x * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int chunks = my_tiles * nkc;
     if (chunks <= 0) return;
     const int tstride = per_xcd;
@@ -1142,7 +1147,7 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     gemm_w4_kernel<NT, ACT, B, RR, LN><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
                                                                LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
                                                                LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,
-                                                               LN == 2 ? ln->stats_out : nullptr, stagger);
+                                                               LN == 2 ? ln->stats_out : nullptr, stagger, LN == 1 ? ln->zero_out : nullptr);
     if (xmode & 64) {
         static unsigned long long h[256 * 4];
         SCD_HIP(hipDeviceSynchronize());
