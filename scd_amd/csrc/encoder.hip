@@ -535,8 +535,8 @@ __global__ void __launch_bounds__(256) fold_ln_kernel(const half_t* __restrict__
     }
 }
 
-// stats[r] = {sum, sum of squares} of row r (fp16 values, fp32 accumulation); one wave per row
-__global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict__ x, long long rows, int width, float* __restrict__ stats) {
+// stats[r] = {sum, sum of squares} of row r (fp16 values, fp32 accumulation, stored as 64-bit fixed point); one wave per row
+__global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict__ x, long long rows, int width, long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -552,9 +552,9 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict
     }
     s1 = wave_sum_f32(s1);
     s2 = wave_sum_f32(s2);
-    if (lane == 0) {
-        stats[2 * r] = s1;
-        stats[2 * r + 1] = s2;
+    if (lane == 0) {   // the fixed-point format of scd_gemm_ln (gemm.h)
+        stats[2 * r] = __float2ll_rn(s1 * 16777216.f);
+        stats[2 * r + 1] = __float2ll_rn(s2 * 1048576.f);
     }
 }
 
@@ -577,7 +577,7 @@ static inline EncPad make_pad(const scd_encoder_desc& d, int batch) {
 struct EncWs {
     half_t *x, *y, *qkv, *h, *cls, *outp;
     int* rows;
-    float *stats_a, *stats_b;   // [rows][2] row sums of x for the folded LayerNorms (LN1 / LN2 input)
+    long long *stats_a, *stats_b;   // [rows][2] fixed-point row sums of x for the folded LayerNorms (LN1 / LN2 input)
     size_t total;
 };
 static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
@@ -593,8 +593,8 @@ static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
     w.cls = (half_t*)take((size_t)bp * d.width * 2);
     w.outp = (half_t*)take((size_t)bp * (d.out_dim > 0 ? d.out_dim : d.width) * 2);
     w.rows = (int*)take((size_t)bp * 4);
-    w.stats_a = (float*)take(rows * 8);
-    w.stats_b = (float*)take(rows * 8);
+    w.stats_a = (long long*)take(rows * 16);
+    w.stats_b = (long long*)take(rows * 16);
     w.total = off + 256;
     return w;
 }

@@ -7,11 +7,11 @@ int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const h
 
 // LayerNorm folded into the four-wave GEMM (gemm.hip, gemm_w4_kernel LN = 1 / 2).  Requires M % 256 = N % 256 = K % 64 = 0.
 struct scd_gemm_ln {
-    const float* stats_in;   // [M][2] {sum, sum of squares} of A's rows: normalise A on the fly (W, bias pre-folded) - or null
+    const long long* stats_in;   // [M][2] {sum * 2^24, sum of squares * 2^20} of A's rows (fixed point): normalise A on the fly - or null
     const float* colsum;     // [N] sum_k W'[n][k]                                       (with stats_in)
     float inv_k, eps;        // 1 / (row length), LayerNorm epsilon                       (with stats_in)
-    float* stats_out;        // [M][2] += {sum, sum of squares} of the rows of C (atomic) - or null; needs bias + residual
-    float* zero_out;         // with stats_in: a second [M][2] buffer this launch clears (the next residual GEMM's stats_out) - or null
+    long long* stats_out;    // [M][2] += the same fixed-point sums of the rows of C (integer atomics) - or null; needs bias + residual
+    long long* zero_out;     // with stats_in: a second [M][2] buffer this launch clears (the next residual GEMM's stats_out) - or null
 };
 int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
                        int act, const scd_gemm_ln* ln, hipStream_t st);

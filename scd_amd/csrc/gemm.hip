@@ -670,16 +670,18 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
 
 // LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
-//         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_stats[m] = {sum_k x, sum_k x^2} of the raw input rows:
+//         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_stats[m] = {sum_k x, sum_k x^2} of the raw input rows
+//         (64-bit fixed point, units 2^-24 and 2^-20):
 //         out = rstd * (acc - mean * colsum[n]) + b'[n], then the activation.  The raw x goes through the MFMAs unchanged.
 // LN = 2: this GEMM produces the rows the NEXT LayerNorm normalises: the epilogue adds each row's {sum, sum of squares} of
-//         the fp16 values it stores into ln_out[m] (float atomics, one 64-row instruction per 64 rows).
+//         the fp16 values it stores into ln_out[m] (64-bit integer atomics - order-independent, so the encoder stays
+//         bit-reproducible - one 64-row instruction per 64 rows).
 template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-               int xmode, int ng, const float* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, float* __restrict__ ln_out, int stagger, float* __restrict__ ln_zero) {
+               int xmode, int ng, const long long* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
+               float ln_eps, long long* __restrict__ ln_out, int stagger, long long* __restrict__ ln_zero) {
     static_assert(NT == 8, "wave tile is 128 x 128");
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
     constexpr bool DEFER_ST = HAS_RES && W4_DEFER_STORES;   // residual variants: all stores after the last residual load
@@ -714,7 +716,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
     if (LN == 1 && ln_zero) {   // clear the OTHER statistics buffer (2*M floats) for the residual GEMM that follows: saves a memset launch
         float4* z = (float4*)ln_zero;
-        const int n4 = M / 2;
+        const int n4 = M;
         for (int i = blockIdx.x * 256 + tid; i < n4; i += gridDim.x * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int chunks = my_tiles * nkc;
@@ -891,7 +893,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
         f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
         f32x4v bq[8], sq[8];
-        float2 lst[8];
+        long long lst[8][2];
         float keep1[2] = {0.f, 0.f}, keep2[2] = {0.f, 0.f};   // LN = 2: this lane's rows 4*c16 + 64*j + q16
         // bias and the first residual rows are fetched one chunk before the tile ends: a plain load issued in the epilogue
         // would sit behind the ring refills in the (in-order) vmcnt queue and stall on them.
@@ -912,8 +914,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 const float4 c4 = *(const float4*)(ln_colsum + nb0 + tn * 16 + q16 * 4);                         \
                 sq[tn][0] = c4.x; sq[tn][1] = c4.y; sq[tn][2] = c4.z; sq[tn][3] = c4.w;                          \
             }                                                                                                    \
-            _Pragma("unroll") for (int tm = 0; tm < 8; ++tm)                                                     \
-                lst[tm] = *(const float2*)(ln_stats + 2 * ((size_t)bm * BM + wm * 128 + tm * 16 + c16));         \
+            _Pragma("unroll") for (int tm = 0; tm < 8; ++tm) {                                                   \
+                const longlong2 q = *(const longlong2*)(ln_stats + 2 * ((size_t)bm * BM + wm * 128 + tm * 16 + c16)); \
+                lst[tm][0] = q.x; lst[tm][1] = q.y;                                                              \
+            }                                                                                                    \
         }                                                                                                        \
     }
         if (nkc == 1) W4_PRE()
@@ -943,8 +947,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 if (tm < 8) {
                     float rstd = 1.f, nmr = 0.f;
                     if (LN == 1) {
-                        const float mu = lst[tm].x * ln_invk;
-                        const float var = fmaxf(fmaf(-mu, mu, lst[tm].y * ln_invk), 0.f);
+                        // row sums are 64-bit fixed point (2^-24 / 2^-20 units): integer atomics add in any order to the same bits
+                        const float mu = __ll2float_rn(lst[tm][0]) * (5.9604644775390625e-8f * ln_invk);
+                        const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(lst[tm][1]) * (9.5367431640625e-7f * ln_invk)), 0.f);
                         rstd = __builtin_amdgcn_rsqf(var + ln_eps);
                         nmr = -mu * rstd;
                     }
@@ -1069,9 +1074,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         if (LN == 2 && !(xmode & 16)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float* dst = ln_out + 2 * ((size_t)bm * BM + wm * 128 + 4 * c16 + 64 * j + q16);
-                unsafeAtomicAdd(dst, keep1[j]);
-                unsafeAtomicAdd(dst + 1, keep2[j]);
+                // fixed point so that the six partial sums of a row (3 tile columns x 2 waves) add up deterministically
+                unsigned long long* dst = (unsigned long long*)(ln_out + 2 * ((size_t)bm * BM + wm * 128 + 4 * c16 + 64 * j + q16));
+                atomicAdd(dst, (unsigned long long)__float2ll_rn(keep1[j] * 16777216.f));
+                atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(keep2[j] * 1048576.f));
             }
         }
         if (ti + 1 < my_tiles) it_step(cit);

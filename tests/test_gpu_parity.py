@@ -344,6 +344,21 @@ def test_clip_towers_match_oracle(ops, layers):
     assert _cos(tout, tref).min().item() > 1 - 1e-3
 
 
+def test_encoder_batch_invariance(ops):
+    # token rows (not images) are padded to the GEMM tile: an image's features must not depend on how many images share the
+    # batch, nor on the zero rows behind them (every row's K loop runs in the same order whatever M is)
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    sd = W.synthetic_clip_state_dict(seed=3, cfg=dict(v_layers=2, t_layers=2))
+    model = CLIP(sd).cuda().eval()
+    img = torch.randn(13, 3, 224, 224, generator=torch.Generator().manual_seed(5)).cuda()
+    all13 = model.encode_image(img).float().cpu()
+    one = model.encode_image(img[:1]).float().cpu()
+    five = model.encode_image(img[4:9]).float().cpu()
+    assert torch.equal(one[0], all13[0])
+    assert torch.equal(five, all13[4:9])
+
+
 def test_dino_tower_matches_oracle(ops):
     from scd_amd.clip import weights as W
     from scd_amd.clip.model import DinoViT
