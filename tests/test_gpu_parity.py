@@ -64,6 +64,30 @@ def test_gemm_matches_fp32(ops, m, n, k, variant):
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err     # fp16 output rounding
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (768, 512, 192), (2560, 1280, 320), (256, 2304, 64), (5120, 256, 1024), (1792, 768, 768)])
+@pytest.mark.parametrize("variant", ["plain", "bias_qgelu", "bias_res"])
+def test_gemm_four_wave_edge_shapes(ops, m, n, k, variant):
+    # the persistent four-wave kernel at its corners: 1-5 chunks per tile, fewer tiles than CUs, tile counts that are not
+    # multiples of 8 (XCD split), one tile column
+    g = torch.Generator().manual_seed(7 * m + 3 * n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(n, k, generator=g) * (k ** -0.5)).half().cuda()
+    bias = torch.randn(n, generator=g).cuda() if variant != "plain" else None
+    res = torch.randn(m, n, generator=g).half().cuda() if variant == "bias_res" else None
+    act = 1 if variant == "bias_qgelu" else 0
+    c = ops.gemm_f16(a, w, bias, res, act).float()
+    ref = a.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if act == 1:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if res is not None:
+        ref = ref + res.float()
+    err = (c - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(c, ops.gemm_f16(a, w, bias, res, act).float())      # run-to-run reproducible
+
+
 # ----------------------------------------------------------------------------------------------- k-means pieces
 @pytest.mark.parametrize("n,d,k,seed", [(500, 8, 4, 1), (1500, 32, 10, 2), (3000, 768, 20, 3), (4097, 768, 100, 4),
                                         (2000, 768, 200, 5)])
