@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
 // swapped when (r>>1)&1, which makes the transposing reads (4 rows x 64 B per 32-lane group) tile the 64 banks.  Rows past
 // T repeat row T-1 (finite values); their scores are masked to -inf, so their P is exactly 0.
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width, int heads, int items) {
+attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width, int heads, int items, int xmode) {
     constexpr int NB = 7, TP = NB * 32, KV = TP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K | V]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -429,6 +429,11 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
         }
         const char* kl = smem + (i & 1) * 2 * KV;
         const char* vl = kl + KV;
+        if (xmode & 4) {   // timing ablation: no compute at all
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+            continue;
+        }
         f32x16 sacc[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
@@ -444,29 +449,36 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
         // softmax over keys on the raw scores (only the last key block holds padded keys); 1/sqrt(64) folded into exp2
         float mx = -INFINITY;
 #pragma unroll
+        for (int e = 0; e < 16; ++e) {   // only the last key block can hold padded keys
+            const int key = (NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (key >= T) sacc[NB - 1][e] = -INFINITY;
+        }
+#pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = sacc[kb][e];
-                if (kb == NB - 1) {
-                    const int key = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (key >= T) v = -INFINITY;
-                    sacc[kb][e] = v;
-                }
-                mx = fmaxf(mx, v);
-            }
+            for (int e = 0; e < 16; e += 2) mx = fmaxf(fmaxf(mx, sacc[kb][e]), sacc[kb][e + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // p = 2^((s - max) * 0.125 * log2 e), two keys per instruction wherever the ISA has a packed form (v_pk_fma_f32,
+        // v_pk_add_f32, v_cvt_pk_f16_f32): the kernel is VALU-bound (two consumer waves per SIMD, ~600 VALU instructions per
+        // item and wave before this), not MFMA- or HBM-bound.  The probabilities are kept as packed fp16 - exactly the PV operand.
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         const float cs = 0.125f * 1.4426950408889634f;
-        const float mxs = mx * cs;
-        float sum = 0.f;
+        const f2v cs2 = {cs, cs}, nmx2 = {-mx * cs, -mx * cs};
+        f2v sum2 = {0.f, 0.f};
+        h2v ph[NB][8];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], cs, -mxs));
-                sacc[kb][e] = pv;
-                sum += pv;
+            for (int e = 0; e < 8; ++e) {
+                f2v t = {sacc[kb][2 * e], sacc[kb][2 * e + 1]};
+                t = t * cs2 + nmx2;
+                t.x = __builtin_amdgcn_exp2f(t.x);
+                t.y = __builtin_amdgcn_exp2f(t.y);
+                sum2 += t;
+                ph[kb][e] = __builtin_convertvector(t, h2v);
             }
+        float sum = sum2.x + sum2.y;
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
         f32x16 oacc[2];
@@ -480,7 +492,7 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
             for (int s = 0; s < 2; ++s) {
                 half8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[kb][8 * s + j];
+                for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kb][4 * s + j].x; pf[2 * j + 1] = ph[kb][4 * s + j].y; }
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const char* base = vl + (kb * 32 + 16 * s) * 128 + ((db * 64) ^ vswz) + tr_off;
@@ -725,7 +737,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
                 attr = true;
             }
             const int items = bp * d.heads;
-            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items);
+            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items, attn_xmode());
         } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         if (fuse) {
