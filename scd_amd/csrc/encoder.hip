@@ -570,6 +570,20 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict
     }
 }
 
+// dst_a[i] = a[rows[i]], dst_b[i] = b[rows[i]] (one wave per row, width % 256 == 0)
+__global__ void __launch_bounds__(256) gather2_rows_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                           const int* __restrict__ rows, int n, int width,
+                                                           half_t* __restrict__ dst_a, half_t* __restrict__ dst_b) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const size_t src = (size_t)rows[i] * width, dst = (size_t)i * width;
+    for (int c = lane * 8; c < width; c += 512) {
+        *(half8*)(dst_a + dst + c) = *(const half8*)(a + src + c);
+        *(half8*)(dst_b + dst + c) = *(const half8*)(b + src + c);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // Row counts are padded to the GEMM tile (256), not the image count: with 197 tokens per image a whole-image padding would
 // need multiples of 256 images.  rows: token rows; prows: patch rows (im2col); bh: rows of the CLS / EOT head.
@@ -590,6 +604,8 @@ struct EncWs {
     half_t *x, *y, *qkv, *h, *cls, *outp;
     int* rows;
     long long *stats_a, *stats_b;   // [rows][2] fixed-point row sums of x for the folded LayerNorms (LN1 / LN2 input)
+    half_t *xsel, *ysel, *hsel;     // the last block's CLS / EOT rows only: [bh][width], [bh][width], [bh][mlp_dim]
+    long long* stats_sel;
     size_t total;
 };
 static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
@@ -607,6 +623,10 @@ static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
     w.rows = (int*)take((size_t)bp * 4);
     w.stats_a = (long long*)take(rows * 16);
     w.stats_b = (long long*)take(rows * 16);
+    w.xsel = (half_t*)take((size_t)bp * d.width * 2);
+    w.ysel = (half_t*)take((size_t)bp * d.width * 2);
+    w.hsel = (half_t*)take((size_t)bp * d.mlp_dim * 2);
+    w.stats_sel = (long long*)take((size_t)bp * 16);
     w.total = off + 256;
     return w;
 }
@@ -704,7 +724,7 @@ static int attn_xmode() {
     return x;
 }
 
-static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, hipStream_t st) {
+static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, hipStream_t st, bool* selected_out) {
     const scd_encoder_desc& d = e->d;
     const long long rows = pad.rows;
     const int bp = pad.batch;          // attention runs over the real images only
@@ -715,6 +735,12 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     // layer 0 from row_stats_kernel.  Two of the seven kernels of a block disappear.  SCD_LN_FUSE=0 restores the LN kernels.
     static const int ln_fuse_env = getenv("SCD_LN_FUSE") ? atoi(getenv("SCD_LN_FUSE")) : 1;
     const bool fuse = ln_fuse_env && !e->folded.empty() && rows % 256 == 0;
+    // Only the CLS (EOT) row of the last block's output is ever used (LN_post -> projection): after its attention the last
+    // block continues on those rows alone - the output projection, LayerNorm, fc1 and fc2 of the other 196 (76) tokens of
+    // every image are never computed.  Identical features (each row's arithmetic is unchanged).  SCD_LAST_SEL=0 disables it.
+    static const int last_sel_env = getenv("SCD_LAST_SEL") ? atoi(getenv("SCD_LAST_SEL")) : 1;
+    const bool last_sel = last_sel_env && d.mlp_dim % 256 == 0 && d.width % 256 == 0;
+    *selected_out = last_sel;
     if (fuse) row_stats_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, rows, d.width, w.stats_a);
     for (int l = 0; l < d.layers; ++l) {
         const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
@@ -740,6 +766,31 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items, attn_xmode());
         } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
+        if (last_sel && l == d.layers - 1) {
+            const int bh = pad.bh;
+            gather2_rows_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.y, w.x, w.rows, bh, d.width, w.ysel, w.xsel);
+            if (fuse) {
+                SCD_HIP(hipMemsetAsync(w.stats_sel, 0, (size_t)bh * 16, st));
+                scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr};
+                rc = scd_gemm_launch_ln(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
+                                        SCD_ACT_NONE, &lo, st);
+                if (rc) return rc;
+                scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+                rc = scd_gemm_launch_ln(w.xsel, e->folded[l].w1, e->folded[l].b1, nullptr, w.hsel, bh, d.mlp_dim, d.width, act, &li, st);
+            } else {
+                rc = scd_gemm_launch(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
+                                     SCD_ACT_NONE, st);
+                if (rc) return rc;
+                layernorm_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.xsel, nullptr, bh, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
+                                                                             (const float*)lw[L_LN2_B], w.ysel);
+                rc = scd_gemm_launch(w.ysel, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.hsel, bh, d.mlp_dim, d.width, act, st);
+            }
+            if (rc) return rc;
+            rc = scd_gemm_launch(w.hsel, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.xsel, w.xsel, bh, d.width, d.mlp_dim,
+                                 SCD_ACT_NONE, st);
+            if (rc) return rc;
+            break;
+        }
         if (fuse) {
             scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b, nullptr};
             rc = scd_gemm_launch_ln(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
@@ -784,12 +835,12 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     return SCD_OK;
 }
 
-static int run_head(const scd_encoder* e, const EncWs& w, const EncPad& pad, void* out, int normalize, hipStream_t st) {
+static int run_head(const scd_encoder* e, const EncWs& w, const EncPad& pad, bool selected, void* out, int normalize, hipStream_t st) {
     const scd_encoder_desc& d = e->d;
     const int batch = pad.batch, bp = pad.bh;
-    // final LayerNorm on the gathered CLS / EOT rows, then the projection
-    layernorm_kernel<<<(unsigned)scd_cdiv(bp, 4), 256, 0, st>>>(w.x, w.rows, bp, d.width, d.ln_eps, (const float*)e->w[W_LNPOST_W],
-                                                                 (const float*)e->w[W_LNPOST_B], w.cls);
+    // final LayerNorm on the CLS / EOT rows (already gathered by the last block, or gathered here), then the projection
+    layernorm_kernel<<<(unsigned)scd_cdiv(bp, 4), 256, 0, st>>>(selected ? w.xsel : w.x, selected ? nullptr : w.rows, bp, d.width, d.ln_eps,
+                                                                 (const float*)e->w[W_LNPOST_W], (const float*)e->w[W_LNPOST_B], w.cls);
     const half_t* fin = w.cls;
     int dim = d.width;
     if (d.out_dim > 0) {
@@ -827,9 +878,10 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
                                                                          (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
                                                                          d.ln_eps, w.x);
     cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 0);
-    rc = run_blocks(e, w, pad, st);
+    bool selected = false;
+    rc = run_blocks(e, w, pad, st, &selected);
     if (rc) return rc;
-    return run_head(e, w, pad, out, normalize, st);
+    return run_head(e, w, pad, selected, out, normalize, st);
 }
 
 extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
@@ -845,7 +897,8 @@ extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const in
     embed_text_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(tokens, batch, (const half_t*)e->w[W_PATCH], d.vocab,
                                                                     (const float*)e->w[W_POS], rows, d.tokens, d.width, w.x, w.rows);
     cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 1);
-    int rc = run_blocks(e, w, pad, st);
+    bool selected = false;
+    int rc = run_blocks(e, w, pad, st, &selected);
     if (rc) return rc;
-    return run_head(e, w, pad, out, normalize, st);
+    return run_head(e, w, pad, selected, out, normalize, st);
 }
