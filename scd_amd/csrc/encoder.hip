@@ -570,6 +570,92 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict
     }
 }
 
+// dst[i] = x[rows[i]] and, when stats != null, dst_stats[i] = stats[rows[i]] (one wave per row)
+__global__ void __launch_bounds__(256) gather_rows_stats_kernel(const half_t* __restrict__ x, const long long* __restrict__ stats,
+                                                                const int* __restrict__ rows, int n, int width,
+                                                                half_t* __restrict__ dst, long long* __restrict__ dst_stats) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const size_t src = (size_t)rows[i] * width;
+    for (int c = lane * 8; c < width; c += 512) *(half8*)(dst + (size_t)i * width + c) = *(const half8*)(x + src + c);
+    if (stats && lane < 2) dst_stats[2 * i + lane] = stats[2 * (size_t)rows[i] + lane];
+}
+
+// Attention of ONE query row per (image, head) - the last block only needs the CLS / EOT row (see run_blocks).  One wave per
+// item: lanes = keys for the scores (each lane dots its keys' 128-byte K rows with the query), then lanes = head dims for
+// O = P V with P broadcast from LDS.  Same scaling, fp16-rounded probabilities and fp32 accumulation as the block kernels.
+// kv: [rows][2*width] (K | V), q: [n_img][width], out: [n_img][width]; qpos[img] = query position (causal limit) or null.
+__global__ void __launch_bounds__(256) attention_single_query_kernel(const half_t* __restrict__ kv, const half_t* __restrict__ q,
+                                                                     const int* __restrict__ qrow, half_t* __restrict__ out, int T,
+                                                                     int width, int heads, int items, int causal) {
+    __shared__ float ps[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wv;
+    if (item >= items) return;
+    const int img = item / heads, head = item - img * heads;
+    const int ldk = 2 * width;
+    const half_t* kbase = kv + (size_t)img * T * ldk + head * 64;
+    const half_t* vbase = kbase + width;
+    const int limit = causal ? (qrow[img] - img * T) : T - 1;      // last key the query may see
+    const int nkeys = (limit < T - 1 ? limit : T - 1) + 1;
+    // lanes = (key sub-index ks, 16-byte chunk dc of the 128-byte head row): every load instruction covers 8 whole rows
+    const int ks = lane >> 3, dc = lane & 7;
+    const half8 q8 = *(const half8*)(q + (size_t)img * width + head * 64 + 8 * dc);
+    for (int key0 = 0; key0 < nkeys; key0 += 8) {
+        const int key = key0 + ks;
+        const int kc = key < nkeys ? key : nkeys - 1;
+        const half8 k8 = *(const half8*)(kbase + (size_t)kc * ldk + 8 * dc);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf((float)k8[e], (float)q8[e], d);
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (dc == 0 && key < nkeys) ps[wv][key] = d;
+    }
+    __builtin_amdgcn_s_waitcnt(0);      // this wave's own LDS traffic only (one wave per item)
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = lane + 64 * j;
+        sc[j] = key < nkeys ? ps[wv][key] : -INFINITY;
+        mx = fmaxf(mx, sc[j]);
+    }
+    mx = wave_max_f32(mx);
+    const float cs = 0.125f * 1.4426950408889634f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[j], cs, -mx * cs));     // exp2(-inf) = 0 for masked keys
+        sum += pv;
+        ps[wv][lane + 64 * j] = (float)(half_t)pv;
+    }
+    sum = wave_sum_f32(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    __builtin_amdgcn_s_waitcnt(0);
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = 0.f;
+    for (int key = ks; key < nkeys; key += 8) {
+        const half8 v8 = *(const half8*)(vbase + (size_t)key * ldk + 8 * dc);
+        const float pk = ps[wv][key];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = fmaf(pk, (float)v8[e], o8[e]);
+    }
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = o8[e];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        o[e] = (half_t)(v * inv);
+    }
+    if (ks == 0) *(half8*)(out + (size_t)img * width + head * 64 + 8 * dc) = o;
+}
+
 // dst_a[i] = a[rows[i]], dst_b[i] = b[rows[i]] (one wave per row, width % 256 == 0)
 __global__ void __launch_bounds__(256) gather2_rows_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
                                                            const int* __restrict__ rows, int n, int width,
@@ -745,6 +831,37 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     for (int l = 0; l < d.layers; ++l) {
         const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
         int rc;
+        // last block, fused path: only the CLS / EOT query is needed, so K and V are projected for all rows (two thirds of
+        // the QKV GEMM), Q for the selected rows only, and the attention is one query per (image, head)
+        static const int last_q_env = getenv("SCD_LAST_Q") ? atoi(getenv("SCD_LAST_Q")) : 1;
+        const bool last_q = last_sel && fuse && last_q_env && l == d.layers - 1 && d.width % 128 == 0 && d.tokens <= 256;
+        if (last_q) {
+            const int bh = pad.bh;
+            const size_t wk = (size_t)d.width * d.width;
+            scd_gemm_ln lkv{w.stats_a, e->folded[l].csq + d.width, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_launch_ln(w.x, e->folded[l].wq + wk, e->folded[l].bq + d.width, nullptr, w.qkv, rows, 2 * d.width, d.width,
+                                    SCD_ACT_NONE, &lkv, st);
+            if (rc) return rc;
+            gather_rows_stats_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.x, w.stats_a, w.rows, bh, d.width, w.xsel, w.stats_sel);
+            scd_gemm_ln lq{w.stats_sel, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_launch_ln(w.xsel, e->folded[l].wq, e->folded[l].bq, nullptr, w.hsel, bh, d.width, d.width, SCD_ACT_NONE, &lq, st);
+            if (rc) return rc;
+            const int items = bp * d.heads;
+            attention_single_query_kernel<<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.qkv, w.hsel, w.rows, w.ysel, d.tokens, d.width,
+                                                                                         d.heads, items, causal);
+            SCD_HIP(hipMemsetAsync(w.stats_sel, 0, (size_t)bh * 16, st));
+            scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr};
+            rc = scd_gemm_launch_ln(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
+                                    SCD_ACT_NONE, &lo, st);
+            if (rc) return rc;
+            scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_launch_ln(w.xsel, e->folded[l].w1, e->folded[l].b1, nullptr, w.hsel, bh, d.mlp_dim, d.width, act, &li, st);
+            if (rc) return rc;
+            rc = scd_gemm_launch(w.hsel, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.xsel, w.xsel, bh, d.width, d.mlp_dim,
+                                 SCD_ACT_NONE, st);
+            if (rc) return rc;
+            break;
+        }
         if (fuse) {
             scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_b};   // also clears stats_b
             rc = scd_gemm_launch_ln(w.x, e->folded[l].wq, e->folded[l].bq, nullptr, w.qkv, rows, 3 * d.width, d.width, SCD_ACT_NONE, &ln, st);
