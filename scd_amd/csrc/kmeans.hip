@@ -12,6 +12,7 @@
 // ||c'||^2 - 2 x'.c' on a centred, power-of-two scaled fp16 copy of the data with an a-priori error
 // bound; rows whose best/second margin is inside the bound are re-evaluated exactly in float64.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // prepared data set layout (scd_kmeans_prepare):
@@ -128,11 +129,12 @@ extern "C" size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k) {
 // one block per (padded) centre: c' = (c-mu)*scale -> fp16; cn = ||c'||^2 (float64 -> float32)
 __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
                                                            const PrepHdr* hdr, const double* mu, EHdr* eh, float* cn,
-                                                           half_t* ch, float* ct, int kp) {
+                                                           half_t* ch, float* ct, int kp, int zero_counts) {
     __shared__ double red[4];
     __shared__ int bad;
     const int c = blockIdx.x;
     if (threadIdx.x == 0) bad = 0;
+    if (zero_counts && c == 0 && threadIdx.x == 0) { eh->flag_cnt = 0; eh->full_cnt = 0; }   // streaming path: no memset launch
     __syncthreads();
     const double sc = (double)hdr->scale;
     double ss = 0.0;
@@ -279,6 +281,237 @@ __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming MFMA filter for K <= 128, D <= 768 (the SSKM shapes of BASELINE C1-C3): the fp16 data set is read from HBM
+// exactly once, in whole cache lines, by LDS-DMA, and nothing else touches global memory while it streams.
+//   * persistent: block b owns a contiguous range of rows (whole 32-row groups, balanced over the grid to within one
+//     group, at most ES_RMAX rows) and walks it in 128-row tiles;
+//   * the 128 (padded) centres live in REGISTERS for the whole kernel: wave w holds centres 32w..32w+31 as the A
+//     operands of v_mfma_f32_32x32x16_f16 (NCH*8 fragments of 4 registers = 192 at D = 768), one wave per SIMD;
+//   * X flows through a 4-slot ring of [128 rows][128 cols] fp16 chunks (32 KB each): global_load_lds_dwordx4, 4 rows x
+//     256 B per instruction, 16-B pieces XOR-swizzled with row&15 on the SOURCE address so that the B-fragment
+//     ds_read_b128 (lane = point) is conflict-free; three chunks (96 KB per CU) are always in flight;
+//   * one barrier per chunk; every wave reads the whole chunk (B operand = 32 points per MFMA, 4 point blocks);
+//   * per tile each lane owns 16 scores per point block: the three smallest are kept with a 4-instruction min/med3/max
+//     network on KEYS = score bits with the centre index in the low mantissa bits (5 bits in-lane, 7 bits after the merge:
+//     a relative perturbation < 2^-16 that is added to the a-priori bound E); lanes r / r+32 merge by shuffle, the four
+//     waves through a 6 KB LDS patch; the merged triples of all the block's rows stay in LDS;
+//   * after the stream has drained: ||x'|| is read, E evaluated, labels stored, flagged rows appended to the refine lists
+//     with ONE global atomic per block and list.
+#define ES_RMAX 768
+#define ES_SLOT 32768
+#define ES_LDS (4 * ES_SLOT + 512 + 4 * 3 * 128 * 4 + 3 * ES_RMAX * 4 + 64)
+
+__device__ __forceinline__ float es_min(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float es_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float es_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// insert key k into the ascending triple (b0, b1, b2)
+__device__ __forceinline__ void es_insert(float& b0, float& b1, float& b2, float k) {
+    const float t = es_max(b1, k);
+    b2 = es_min(b2, t);
+    b1 = es_med3(b0, b1, k);
+    b0 = es_min(b0, k);
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
+                                                           const half_t* __restrict__ ch, const float* __restrict__ cn,
+                                                           EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
+                                                           long long n, int32_t* __restrict__ labels, int dbg) {
+    constexpr int DP = NCH * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    float* cnl = (float*)(smem + 4 * ES_SLOT);                       // [128] ||c'||^2, dead centres = 3e38
+    float* scr = (float*)(smem + 4 * ES_SLOT + 512);                 // [4 waves][3][128 points]
+    float* res = (float*)(smem + 4 * ES_SLOT + 512 + 6144);          // [3][ES_RMAX]
+    int* cnts = (int*)(smem + 4 * ES_SLOT + 512 + 6144 + 3 * ES_RMAX * 4);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+
+    const long long g32 = (n + 31) >> 5;
+    const long long row0 = 32 * (g32 * blockIdx.x / gridDim.x);
+    long long row1 = 32 * (g32 * (blockIdx.x + 1) / gridDim.x);
+    if (row1 > n) row1 = n;
+    const int rows = (int)(row1 - row0);
+    if (rows <= 0) return;
+    const int ntile = (rows + 127) >> 7, total = ntile * NCH;
+
+    // resident centre fragments: k-step s of chunk c covers columns 128c + 16s + 8hh .. +7 of centre 32w + r
+    half8 cf[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) cf[c][s] = *(const half8*)(ch + (size_t)(32 * wave + r) * DP + c * 128 + 16 * s + 8 * hh);
+    if (tid < 128) cnl[tid] = fminf(cn[tid], 3.0e38f);
+    if (tid < 4) cnts[tid] = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(cf[c][s]));     // loads complete before the ring starts
+
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const half_t* xblk = xh + row0 * DP;
+    const int lrow4 = lane >> 4, lq = lane & 15;
+    auto issue = [&](int gi) {
+        int t = gi / NCH, c = gi - t * NCH;
+        if (gi >= total) { t = ntile - 1; c = NCH - 1; }          // past the end: a harmless re-read keeps vmcnt uniform
+        const unsigned lds = sbase + (gi & 3) * ES_SLOT + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int rowsel = t * 128 + wave * 32 + 4 * i + lrow4;
+            rowsel = rowsel < rows ? rowsel : rows - 1;
+            const unsigned voff = (unsigned)rowsel * (DP * 2) + c * 256 + ((lq ^ ((4 * i + lrow4) & 15)) << 4);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds + i * 1024), "v"(voff), "s"(xblk) : "memory");
+        }
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+
+    const int xsw = (hh ^ (r & 15)) << 4;
+    const int base_idx = 32 * wave + 4 * hh;
+    int g = 0;
+    for (int t = 0; t < ntile; ++t) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pb][i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c, ++g) {
+            if (dbg & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");    // my part of chunk g has landed
+            __builtin_amdgcn_s_barrier();                                   // everyone's has; slot (g-1)&3 is free
+            asm volatile("" ::: "memory");
+            issue(g + 3);
+            // fragment reads run one k-step (4 MFMAs) ahead of the matrix pipe; reads, waits and MFMAs are asm so that the
+            // order below is the order issued (left alone, hipcc reuses one fragment register and serialises read -> MFMA)
+            const unsigned sl = sbase + (g & 3) * ES_SLOT + r * 256;
+            half8 fb[2][4];
+#define ES_RD(DST, S, PB) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(sl + ((((S) << 5) ^ xsw))), "n"((PB) * 8192))
+#define ES_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) ES_RD(fb[0][pb], 0, pb);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                // the waits carry the fragments as operands, so the MFMAs (builtins: hipcc sees them and handles the MFMA
+                // hazards and the accumulator allocation) cannot be scheduled above them
+                if (s < 7) {
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb) ES_RD(fb[(s + 1) & 1][pb], s + 1, pb);
+                    ES_WAIT(4, fb[s & 1]);
+                } else {
+                    ES_WAIT(0, fb[s & 1]);
+                }
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[c][s], fb[s & 1][pb], acc[pb], 0, 0, 0);
+            }
+            if (dbg & 2) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        }
+        // tile epilogue: per point block the lane's three smallest keys of its 16 centres
+        float cv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *(const f32x4*)(cnl + 32 * wave + 8 * j + 4 * hh);
+            cv[4 * j] = v[0]; cv[4 * j + 1] = v[1]; cv[4 * j + 2] = v[2]; cv[4 * j + 3] = v[3];
+        }
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float s = fmaf(-2.0f, acc[pb][i], cv[i]);
+                const unsigned key = (__float_as_uint(s) & 0xffffffe0u) | (unsigned)((i & 3) + 8 * (i >> 2));
+                es_insert(b0, b1, b2, __uint_as_float(key));
+            }
+            // full centre index (7 bits): bits 2, 5, 6 come from the wave / half-wave
+            b0 = __uint_as_float((__float_as_uint(b0) & 0xffffff9bu) | (unsigned)base_idx);
+            b1 = __uint_as_float((__float_as_uint(b1) & 0xffffff9bu) | (unsigned)base_idx);
+            b2 = __uint_as_float((__float_as_uint(b2) & 0xffffff9bu) | (unsigned)base_idx);
+            {   // rewriting low bits can reorder keys that agree above bit 6: the insert network needs an ascending triple
+                float n0, n1, n2;
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(n0) : "v"(b0), "v"(b1), "v"(b2));
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(b0), "v"(b1), "v"(b2));
+                n1 = es_med3(b0, b1, b2);
+                b0 = n0; b1 = n1; b2 = n2;
+            }
+            const float o0 = __shfl_xor(b0, 32, 64), o1 = __shfl_xor(b1, 32, 64), o2 = __shfl_xor(b2, 32, 64);
+            es_insert(b0, b1, b2, o0);
+            es_insert(b0, b1, b2, o1);
+            es_insert(b0, b1, b2, o2);
+            if (hh == 0) {
+                scr[(wave * 3 + 0) * 128 + pb * 32 + r] = b0;
+                scr[(wave * 3 + 1) * 128 + pb * 32 + r] = b1;
+                scr[(wave * 3 + 2) * 128 + pb * 32 + r] = b2;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < 128) {
+            float b0 = scr[tid], b1 = scr[128 + tid], b2 = scr[256 + tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                es_insert(b0, b1, b2, scr[(w * 3 + 0) * 128 + tid]);
+                es_insert(b0, b1, b2, scr[(w * 3 + 1) * 128 + tid]);
+                es_insert(b0, b1, b2, scr[(w * 3 + 2) * 128 + tid]);
+            }
+            const int p = t * 128 + tid;
+            if (p < rows) {
+                res[p] = b0;
+                res[ES_RMAX + p] = b1;
+                res[2 * ES_RMAX + p] = b2;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tail refills have landed: the ring is dead
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // decisions for all rows of the block
+    float cm2 = 0.f;
+    for (int c = 0; c < 128; ++c) {
+        const float v = cnl[c];
+        if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
+    }
+    const float cmax = sqrtf(cm2) * 1.0000002f;
+    const float sq = sqrtf((float)DP);
+    // |s~ - s| <= A*||x'|| + B (see estep_mfma_kernel) + the key's low 7 bits: 2^-16 * (||c'||^2 + 2 ||x'|| ||c'||)
+    const float A = 1.5f * (2.02f * (9.765625e-4f + DP * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 3.06e-5f * cmax);
+    const float B = 1.5f * (6.0e-8f * sq * cmax + 2.4e-7f * cmax * cmax + 1.53e-5f * cmax * cmax);
+    int* l_flag = (int*)ring;
+    int* l_cand = l_flag + ES_RMAX;
+    int* l_full = l_cand + ES_RMAX;
+    for (int p = tid; p < rows; p += 256) {
+        const float m0 = res[p], m1 = res[ES_RMAX + p], m2 = res[2 * ES_RMAX + p];
+        const int j0 = (int)(__float_as_uint(m0) & 127u), j1 = (int)(__float_as_uint(m1) & 127u);
+        const long long point = row0 + p;
+        labels[point] = j0;
+        const float E = A * xnorm[point] + B;
+        if (!(m1 - m0 > 2.0f * E)) {       // also catches NaN
+            if (m2 - m0 > 2.0f * E) {
+                const int pos = atomicAdd(&cnts[0], 1);
+                l_flag[pos] = (int)point;
+                l_cand[pos] = j0 | (j1 << 16);
+            } else {
+                l_full[atomicAdd(&cnts[1], 1)] = (int)point;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cnts[2] = cnts[0] ? atomicAdd(&eh->flag_cnt, cnts[0]) : 0;
+        cnts[3] = cnts[1] ? atomicAdd(&eh->full_cnt, cnts[1]) : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < cnts[0]; i += 256) {
+        flag_list[cnts[2] + i] = l_flag[i];
+        flag_cand[cnts[2] + i] = l_cand[i];
+    }
+    for (int i = tid; i < cnts[1]; i += 256) full_list[cnts[3] + i] = l_full[i];
+}
+
 // exact re-evaluation of flagged rows: one wave per row, float64 difference form over all K centres
 __global__ void __launch_bounds__(64) estep_refine_kernel(const float* __restrict__ X, const float* __restrict__ C,
                                                           const EHdr* eh, const int* flag_list, const int* flag_cand, int d,
@@ -366,6 +599,87 @@ __global__ void __launch_bounds__(128) estep_refine_full_kernel(const float* __r
     }
 }
 
+// both refine passes in one launch (streaming path): the lower half of the grid walks the pair list one wave per row, the
+// upper half the full list one block per row.
+__global__ void __launch_bounds__(128) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
+                                                                const float* __restrict__ ct, const EHdr* eh, const int* flag_list,
+                                                                const int* flag_cand, const int* full_list, int d, int k, int kp,
+                                                                int32_t* labels, int32_t* refine_rows_out) {
+    extern __shared__ double xs[];
+    __shared__ double rv[2];
+    __shared__ int ri[2];
+    const int half_grid = gridDim.x >> 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && refine_rows_out) *refine_rows_out = eh->flag_cnt + eh->full_cnt;
+    if ((int)blockIdx.x < half_grid) {
+        const int lane = threadIdx.x & 63;
+        const int cnt = eh->flag_cnt;
+        for (int f = blockIdx.x * 2 + (threadIdx.x >> 6); f < cnt; f += 2 * half_grid) {
+            const long long row = flag_list[f];
+            const int cand = flag_cand[f];
+            const float* x = X + row * d;
+            const int ca = cand & 0xffff, cb = cand >> 16;
+            const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+            const float *c0 = C + (size_t)lo * d, *c1 = C + (size_t)hi * d;
+            double s0 = 0.0, s1 = 0.0;
+            for (int j = lane; j < d; j += 64) {
+                const double xv = (double)x[j];
+                const double d0 = xv - (double)c0[j], d1 = xv - (double)c1[j];
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+            s0 = wave_sum_f64(s0);
+            s1 = wave_sum_f64(s1);
+            // same decision sequence as estep_refine_kernel: NaN never wins, ties keep the lower index
+            double best = INFINITY;
+            int bi = 0;
+            if (s0 < best) { best = s0; bi = lo; }
+            if (s1 < best) { best = s1; bi = hi; }
+            if (lane == 0) labels[row] = bi;
+        }
+        return;
+    }
+    const int cnt = eh->full_cnt;
+    for (int f = blockIdx.x - half_grid; f < cnt; f += half_grid) {
+        const long long row = full_list[f];
+        __syncthreads();
+        for (int j = threadIdx.x; j < d; j += 128) xs[j] = (double)X[row * d + j];
+        __syncthreads();
+        double best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int c0 = 0; c0 < k; c0 += 128) {
+            const int c = c0 + threadIdx.x;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const float* col = ct + c;
+            int j = 0;
+            for (; j + 4 <= d; j += 4) {
+                const double d0 = xs[j] - (double)col[(size_t)j * kp];
+                const double d1 = xs[j + 1] - (double)col[(size_t)(j + 1) * kp];
+                const double d2 = xs[j + 2] - (double)col[(size_t)(j + 2) * kp];
+                const double d3 = xs[j + 3] - (double)col[(size_t)(j + 3) * kp];
+                a0 = fma(d0, d0, a0); a1 = fma(d1, d1, a1); a2 = fma(d2, d2, a2); a3 = fma(d3, d3, a3);
+            }
+            for (; j < d; ++j) {
+                const double d0 = xs[j] - (double)col[(size_t)j * kp];
+                a0 = fma(d0, d0, a0);
+            }
+            const double s = (a0 + a1) + (a2 + a3);
+            if (c < k && s < best) { best = s; bi = c; }      // NaN never wins
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int w = (rv[1] < rv[0] || (rv[1] == rv[0] && ri[1] < ri[0])) ? 1 : 0;
+            labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
+        }
+    }
+}
+
 __global__ void refine_count_kernel(const EHdr* eh, int32_t* out) { *out = eh->flag_cnt + eh->full_cnt; }
 
 extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
@@ -387,8 +701,44 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     const PrepHdr* ph = (const PrepHdr*)p;
     const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
     const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
+    static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
+    if (use_stream && kp == 128 && dp <= 768) {
+        // streaming filter (K <= 128, D <= 768): 3 launches, no memset
+        prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1);
+        const long long g32 = (n + 31) / 32;
+        long long grid = scd_cdiv(n, 128) < h->n_cu ? scd_cdiv(n, 128) : h->n_cu;
+        if (grid < scd_cdiv(g32, ES_RMAX / 32)) grid = scd_cdiv(g32, ES_RMAX / 32);
+        const half_t* xh = (const half_t*)(p + xh_off);
+        const float* xn = (const float*)(p + xnorm_off);
+        static const int es_dbg = getenv("SCD_ESTEP_DBG") ? atoi(getenv("SCD_ESTEP_DBG")) : 0;
+#define ES_LAUNCH(NCH)                                                                                                       \
+    case NCH: {                                                                                                              \
+        static bool attr_set = false;                                                                                        \
+        if (!attr_set) {                                                                                                     \
+            SCD_HIP(hipFuncSetAttribute((const void*)estep_stream_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS)); \
+            attr_set = true;                                                                                                 \
+        }                                                                                                                    \
+        estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, ch, cn, eh, flags, fcand, fulls, n, labels_out, es_dbg); \
+    } break;
+        switch (dp / 128) {
+            ES_LAUNCH(1) ES_LAUNCH(2) ES_LAUNCH(3) ES_LAUNCH(4) ES_LAUNCH(5) ES_LAUNCH(6)
+        }
+#undef ES_LAUNCH
+        static const int split = getenv("SCD_ESTEP_REFINE_SPLIT") ? atoi(getenv("SCD_ESTEP_REFINE_SPLIT")) : 0;
+        if (split == 2) {
+            // debugging: filter labels only
+        } else if (split) {
+            estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);
+            estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
+            if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
+        } else
+        estep_refine_both_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+                                                                         refine_rows_out);
+        SCD_LAUNCH_CHECK();
+        return SCD_OK;
+    }
     SCD_HIP(hipMemsetAsync(eh, 0, 64, st));
-    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp);
+    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 0);
     estep_mfma_kernel<<<(unsigned)scd_cdiv(n, 128), 256, 0, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off),
                                                                     ch, cn, eh, flags, fcand, fulls, n, dp, kp, labels_out);
     estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);
