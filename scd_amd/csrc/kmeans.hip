@@ -34,7 +34,7 @@ static inline int dpad(int d) { return (d + 127) / 128 * 128; }
 
 extern "C" size_t scd_kmeans_prep_bytes(int64_t n, int d) {
     size_t dp = dpad(d);
-    return scd_align(64 + 8 * dp) + scd_align(4 * (size_t)n) + scd_align(2 * (size_t)n * dp) + 256;
+    return scd_align(64 + 8 * dp) + scd_align(4 * (size_t)n) + scd_align(2 * ((size_t)n + 32) * dp) + 256;   // + one unit of padding (estep_stream_kernel)
 }
 
 // column sums in float64: block (0..gridDim.x) strides over rows, thread t owns columns t, t+256, ...
@@ -112,7 +112,7 @@ extern "C" int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d
 
 // ------------------------------------------------------------------------------------------------
 // E-step workspace:  [0,64) EHdr | cn float[Kp] | ch half[Kp*Dp] | ct float[Dp*Kp] (centres transposed, exact)
-//                       | pair list int32[n] | pair candidates int32[n] | full list int32[n]
+//                       | pair list int32[n] | pair candidates int32[n] | full list int32[n] | chf half[Kp*Dp] (fragment order)
 struct EHdr {
     unsigned cmax_bits;   // max ||c'||
     int flag_cnt;         // rows whose exact argmin is among two known candidates
@@ -123,13 +123,13 @@ static inline int kpad(int k) { return (k + 127) / 128 * 128; }
 
 extern "C" size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k) {
     size_t kp = kpad(k), dp = dpad(d);
-    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * kp * dp) + 3 * scd_align(4 * (size_t)n) + 256;
+    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * kp * dp) + 3 * scd_align(4 * (size_t)n) + scd_align(2 * kp * dp) + 256;
 }
 
 // one block per (padded) centre: c' = (c-mu)*scale -> fp16; cn = ||c'||^2 (float64 -> float32)
 __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
                                                            const PrepHdr* hdr, const double* mu, EHdr* eh, float* cn,
-                                                           half_t* ch, float* ct, int kp, int zero_counts) {
+                                                           half_t* ch, float* ct, int kp, int zero_counts, half_t* chf) {
     __shared__ double red[4];
     __shared__ int bad;
     const int c = blockIdx.x;
@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restri
         }
         ss += v * v;
         ch[(size_t)c * dp + j] = (half_t)(float)v;
+        // fragment order of estep_stream_kernel: [wave c/32][segment j/128][k-step][lane (c%32) + 32 hh][8]
+        if (chf) chf[(((((size_t)(c >> 5) * (dp >> 7) + (j >> 7)) * 8 + ((j & 127) >> 4)) * 64 + (c & 31) + 32 * ((j >> 3) & 1)) << 3) + (j & 7)] = (half_t)(float)v;
         ct[(size_t)j * kp + c] = (c < k && j < d) ? C[(size_t)c * d + j] : NAN;     // untouched float32 values
     }
     ss = wave_sum_f64(ss);
@@ -154,7 +156,10 @@ __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restri
     __syncthreads();
     const bool dead = (c >= k) || bad;
     if (dead) {   // padded or NaN centre (empty cluster): can never win
-        for (int j = threadIdx.x; j < dp; j += 256) ch[(size_t)c * dp + j] = (half_t)0.f;
+        for (int j = threadIdx.x; j < dp; j += 256) {
+            ch[(size_t)c * dp + j] = (half_t)0.f;
+            if (chf) chf[(((((size_t)(c >> 5) * (dp >> 7) + (j >> 7)) * 8 + ((j & 127) >> 4)) * 64 + (c & 31) + 32 * ((j >> 3) & 1)) << 3) + (j & 7)] = (half_t)0.f;
+        }
     }
     if (threadIdx.x == 0) {
         double t = red[0] + red[1] + red[2] + red[3];
@@ -284,27 +289,37 @@ __global__ void __launch_bounds__(256) estep_mfma_kernel(const half_t* __restric
 // ------------------------------------------------------------------------------------------------
 // Streaming MFMA filter for K <= 128, D <= 768 (the SSKM shapes of BASELINE C1-C3): the fp16 data set is read from HBM
 // exactly once, in whole cache lines, by LDS-DMA, and nothing else touches global memory while it streams.
-//   * persistent: block b owns a contiguous range of rows (whole 32-row groups, balanced over the grid to within one
-//     group, at most ES_RMAX rows) and walks it in 128-row tiles;
+//   * unit of work = 32 consecutive rows = one CONTIGUOUS 64*Dp-byte span (48 KB at D = 768).  Block b takes units b, b+G,
+//     b+2G, ...: at any moment the grid reads one contiguous front of G units, every CU a sequential 48 KB of it;
 //   * the 128 (padded) centres live in REGISTERS for the whole kernel: wave w holds centres 32w..32w+31 as the A
 //     operands of v_mfma_f32_32x32x16_f16 (NCH*8 fragments of 4 registers = 192 at D = 768), one wave per SIMD;
-//   * X flows through a 4-slot ring of [128 rows][128 cols] fp16 chunks (32 KB each): global_load_lds_dwordx4, 4 rows x
-//     256 B per instruction, 16-B pieces XOR-swizzled with row&15 on the SOURCE address so that the B-fragment
-//     ds_read_b128 (lane = point) is conflict-free; three chunks (96 KB per CU) are always in flight;
-//   * one barrier per chunk; every wave reads the whole chunk (B operand = 32 points per MFMA, 4 point blocks);
-//   * per tile each lane owns 16 scores per point block: the three smallest are kept with a 4-instruction min/med3/max
-//     network on KEYS = score bits with the centre index in the low mantissa bits (5 bits in-lane, 7 bits after the merge:
-//     a relative perturbation < 2^-16 that is added to the a-priori bound E); lanes r / r+32 merge by shuffle, the four
-//     waves through a 6 KB LDS patch; the merged triples of all the block's rows stay in LDS;
-//   * after the stream has drained: ||x'|| is read, E evaluated, labels stored, flagged rows appended to the refine lists
-//     with ONE global atomic per block and list.
+//   * a unit lands in one slot of a 3-slot (4 below D = 640) LDS ring by global_load_lds_dwordx4, 1 KB of consecutive
+//     bytes per instruction; the LDS image is the unit itself with the 16-B pieces of every 256-B segment XOR-swizzled by
+//     row&15 (applied on the SOURCE address), so the B-fragment ds_read_b128 (lane = point) is conflict-free; two units
+//     (96 KB per CU) are always in flight;
+//   * one barrier per unit; every wave reads the whole unit (B operand) against its own 32 centres: 8*NCH MFMAs on two
+//     accumulators; fragment reads run four k-steps ahead;
+//   * per unit each lane owns 16 scores of one point: the three smallest are kept with a 4-instruction min/med3/max network
+//     on KEYS = score bits with the centre index in the low mantissa bits (5 bits in-lane, 7 bits after the merge: a
+//     relative perturbation < 2^-16 that is added to the a-priori bound E); lanes r / r+32 merge by shuffle, the four
+//     waves through a double-buffered 1.5 KB LDS patch read by 32 threads after the NEXT unit's barrier; the merged
+//     triples of all the block's rows stay in LDS;
+//   * after the stream has drained: E is evaluated (||x'|| was fetched at kernel start), labels are stored, flagged rows
+//     are appended to the refine lists with ONE global atomic per block and list.
+// The prepared data set carries 32 rows of padding behind row n-1 (scd_kmeans_prep_bytes), so the last unit needs no clamp.
 #define ES_RMAX 768
-#define ES_SLOT 32768
-#define ES_LDS (4 * ES_SLOT + 512 + 4 * 3 * 128 * 4 + 3 * ES_RMAX * 4 + 64)
+#define ES_RING 147456
+#define ES_LDS (ES_RING + 512 + 2 * 4 * 3 * 32 * 4 + 3 * ES_RMAX * 4 + 64)
 
 __device__ __forceinline__ float es_min(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float es_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float es_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// the value held by lane l ^ 32 (v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second)
+__device__ __forceinline__ float es_swap32(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // builtin: hipcc pads the permlane hazards
+    return __uint_as_float((threadIdx.x & 32) ? p[0] : p[1]);
+}
 // insert key k into the ascending triple (b0, b1, b2)
 __device__ __forceinline__ void es_insert(float& b0, float& b1, float& b2, float k) {
     const float t = es_max(b1, k);
@@ -319,110 +334,146 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
                                                            EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
                                                            long long n, int32_t* __restrict__ labels, int dbg) {
     constexpr int DP = NCH * 128;
+    constexpr int NSLOT = NCH >= 5 ? 3 : 4;
+    constexpr int SLOTB = 8192 * NCH;                 // one unit: 32 rows x DP fp16
+    constexpr int IPW = 2 * NCH;                      // ring-fill instructions per wave and unit
+    constexpr int NG = 2 * NCH;                       // fragment groups (4 k-steps each) per unit
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem;
-    float* cnl = (float*)(smem + 4 * ES_SLOT);                       // [128] ||c'||^2, dead centres = 3e38
-    float* scr = (float*)(smem + 4 * ES_SLOT + 512);                 // [4 waves][3][128 points]
-    float* res = (float*)(smem + 4 * ES_SLOT + 512 + 6144);          // [3][ES_RMAX]
-    int* cnts = (int*)(smem + 4 * ES_SLOT + 512 + 6144 + 3 * ES_RMAX * 4);
+    float* cnl = (float*)(smem + ES_RING);                            // [128] ||c'||^2, dead centres = 3e38
+    float* scr = (float*)(smem + ES_RING + 512);                      // [2][4 waves][3][32 points]
+    float* res = (float*)(smem + ES_RING + 512 + 3072);               // [3][ES_RMAX]
+    int* cnts = (int*)(smem + ES_RING + 512 + 3072 + 3 * ES_RMAX * 4);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
 
-    const long long g32 = (n + 31) >> 5;
-    const long long row0 = 32 * (g32 * blockIdx.x / gridDim.x);
-    long long row1 = 32 * (g32 * (blockIdx.x + 1) / gridDim.x);
-    if (row1 > n) row1 = n;
-    const int rows = (int)(row1 - row0);
-    if (rows <= 0) return;
-    const int ntile = (rows + 127) >> 7, total = ntile * NCH;
+    const long long U = (n + 31) >> 5;
+    const int G = gridDim.x, bid = blockIdx.x;
+    if (bid >= U) return;
+    const int nu = (int)((U - 1 - bid) / G) + 1;      // units bid, bid + G, ...
 
-    // resident centre fragments: k-step s of chunk c covers columns 128c + 16s + 8hh .. +7 of centre 32w + r
+    // ring fill: instruction i of wave w covers the 1 KB [1024 (w IPW + i), +1024) of the slot; lane l owns 16-B piece
+    // P = 64 (w IPW + i) + l = (row, segment, stored position q) and fetches logical piece q ^ (row & 15) of that segment
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned soff[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int P = 64 * (wave * IPW + i) + lane;
+        const int row = P / (16 * NCH), wq = P - row * (16 * NCH);
+        soff[i] = (unsigned)(row * (DP * 2) + (wq >> 4) * 256 + (((wq & 15) ^ (row & 15)) << 4));
+    }
+    // one ring-fill instruction of unit j (a unit past the end issues nothing: the waits below count exactly)
+    auto issue_one = [&](int j, int slot, int i) {
+        if (j >= nu) return;
+        const half_t* ubase = xh + (size_t)(bid + (long long)j * G) * (32 * DP);
+        const unsigned lds = sbase + slot * SLOTB + wave * (IPW * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds + i * 1024), "v"(soff[i]), "s"(ubase) : "memory");
+    };
+    auto issue = [&](int j, int slot) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) issue_one(j, slot, i);
+    };
+#pragma unroll
+    for (int j = 0; j < NSLOT - 1; ++j) issue(j, j);   // the ring starts first: the loads below overlap with its flight
+
+    // resident centre fragments: k-step s of segment c covers columns 128c + 16s + 8hh .. +7 of centre 32w + r
     half8 cf[NCH][8];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) cf[c][s] = *(const half8*)(ch + (size_t)(32 * wave + r) * DP + c * 128 + 16 * s + 8 * hh);
+        for (int s = 0; s < 8; ++s) cf[c][s] = *(const half8*)(ch + ((((size_t)wave * NCH + c) * 8 + s) * 64 + lane) * 8);   // fragment order: 1 KB per load
     if (tid < 128) cnl[tid] = fminf(cn[tid], 3.0e38f);
     if (tid < 4) cnts[tid] = 0;
+    float cv[16];                                   // ||c'||^2 of this lane's 16 centres (MFMA output rows)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cv[i] = fminf(cn[32 * wave + (i & 3) + 8 * (i >> 2) + 4 * hh], 3.0e38f);
+    float xn_r[ES_RMAX / 256];                      // ||x'|| of the rows this thread decides at the end
+#pragma unroll
+    for (int j = 0; j < ES_RMAX / 256; ++j) {
+        const int p = tid + 256 * j;
+        const long long point = (bid + (long long)(p >> 5) * G) * 32 + (p & 31);
+        xn_r[j] = (p < nu * 32 && point < n) ? xnorm[point] : 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(cf[c][s]));     // loads complete before the ring starts
-
-    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const half_t* xblk = xh + row0 * DP;
-    const int lrow4 = lane >> 4, lq = lane & 15;
-    auto issue = [&](int gi) {
-        int t = gi / NCH, c = gi - t * NCH;
-        if (gi >= total) { t = ntile - 1; c = NCH - 1; }          // past the end: a harmless re-read keeps vmcnt uniform
-        const unsigned lds = sbase + (gi & 3) * ES_SLOT + wave * 8192;
+        for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(cf[c][s]));     // no compiler-visible load is left in flight
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int rowsel = t * 128 + wave * 32 + 4 * i + lrow4;
-            rowsel = rowsel < rows ? rowsel : rows - 1;
-            const unsigned voff = (unsigned)rowsel * (DP * 2) + c * 256 + ((lq ^ ((4 * i + lrow4) & 15)) << 4);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds + i * 1024), "v"(voff), "s"(xblk) : "memory");
-        }
-    };
-    issue(0);
-    issue(1);
-    issue(2);
+    for (int j = 0; j < ES_RMAX / 256; ++j) asm volatile("" : "+v"(xn_r[j]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cv[i]));
 
     const int xsw = (hh ^ (r & 15)) << 4;
     const int base_idx = 32 * wave + 4 * hh;
-    int g = 0;
-    for (int t = 0; t < ntile; ++t) {
-        f32x16 acc[4];
+    // cross-wave merge of unit j (threads 0..31, one point each)
+    auto merge_unit = [&](int j) {
+        const float* sc = scr + (j & 1) * 384;
+        float b0 = sc[tid], b1 = sc[32 + tid], b2 = sc[64 + tid];
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
+        for (int w = 1; w < 4; ++w) {
+            es_insert(b0, b1, b2, sc[(w * 3 + 0) * 32 + tid]);
+            es_insert(b0, b1, b2, sc[(w * 3 + 1) * 32 + tid]);
+            es_insert(b0, b1, b2, sc[(w * 3 + 2) * 32 + tid]);
+        }
+        res[j * 32 + tid] = b0;
+        res[ES_RMAX + j * 32 + tid] = b1;
+        res[2 * ES_RMAX + j * 32 + tid] = b2;
+    };
+
+    int slot = 0, islot = NSLOT - 1;
+    for (int j = 0; j < nu; ++j) {
+        {   // my part of unit j has landed: at most min(NSLOT - 2, nu - 1 - j) younger units may still fly
+            const int younger = nu - 1 - j;
+            if (younger >= NSLOT - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSLOT - 2) * IPW) : "memory");
+            else if (NSLOT == 4 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                                        // everyone's has; slot islot is free
+        asm volatile("" ::: "memory");
+        if (dbg & 16) issue(j + NSLOT - 1, islot);
+        if (j > 0 && tid < 32) merge_unit(j - 1);
+        if (!(dbg & 16)) {
+            const unsigned sl = sbase + slot * SLOTB + r * (DP * 2);
+            f32x16 acc;           // one accumulation chain: back-to-back dependent MFMAs of this shape run at full rate
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[pb][i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c, ++g) {
-            if (dbg & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");    // my part of chunk g has landed
-            __builtin_amdgcn_s_barrier();                                   // everyone's has; slot (g-1)&3 is free
-            asm volatile("" ::: "memory");
-            issue(g + 3);
-            // fragment reads run one k-step (4 MFMAs) ahead of the matrix pipe; reads, waits and MFMAs are asm so that the
-            // order below is the order issued (left alone, hipcc reuses one fragment register and serialises read -> MFMA)
-            const unsigned sl = sbase + (g & 3) * ES_SLOT + r * 256;
-            half8 fb[2][4];
-#define ES_RD(DST, S, PB) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(sl + ((((S) << 5) ^ xsw))), "n"((PB) * 8192))
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            half8 fb[3][4];
+            // k-step kk = 8c + s reads the 16-B piece (2s + hh) ^ (r & 15) of segment c of row r
+#define ES_RD(DST, KK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(sl + (((((KK) & 7) << 5) ^ xsw))), "n"(((KK) >> 3) * 256))
 #define ES_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) ES_RD(fb[0][pb], 0, pb);
+            for (int i = 0; i < 4; ++i) ES_RD(fb[0][i], i);
+            if (NG > 1) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                // the waits carry the fragments as operands, so the MFMAs (builtins: hipcc sees them and handles the MFMA
-                // hazards and the accumulator allocation) cannot be scheduled above them
-                if (s < 7) {
+                for (int i = 0; i < 4; ++i) ES_RD(fb[1][i], 4 + i);
+            }
 #pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) ES_RD(fb[(s + 1) & 1][pb], s + 1, pb);
-                    ES_WAIT(4, fb[s & 1]);
+            for (int g = 0; g < NG; ++g) {
+                // fragment reads run two groups (8 MFMAs) ahead.  The waits carry the fragments as operands, so the MFMAs
+                // (builtins: hipcc sees them and handles the MFMA hazards and the accumulator allocation) cannot be
+                // scheduled above them
+                if (g + 2 < NG) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ES_RD(fb[(g + 2) % 3][i], 4 * (g + 2) + i);
+                    ES_WAIT(8, fb[g % 3]);
+                } else if (g + 1 < NG) {
+                    ES_WAIT(4, fb[g % 3]);
                 } else {
-                    ES_WAIT(0, fb[s & 1]);
+                    ES_WAIT(0, fb[g % 3]);
                 }
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb) acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[c][s], fb[s & 1][pb], acc[pb], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = 4 * g + i;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[kk >> 3][kk & 7], fb[g % 3][i], acc, 0, 0, 0);
+                }
+                issue_one(j + NSLOT - 1, islot, g);      // one ring-fill instruction per group, in the shadow of its MFMAs
             }
-            if (dbg & 2) { asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-        }
-        // tile epilogue: per point block the lane's three smallest keys of its 16 centres
-        float cv[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = *(const f32x4*)(cnl + 32 * wave + 8 * j + 4 * hh);
-            cv[4 * j] = v[0]; cv[4 * j + 1] = v[1]; cv[4 * j + 2] = v[2]; cv[4 * j + 3] = v[3];
-        }
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb) {
+            // unit epilogue: the lane's three smallest keys of its 16 centres for point r
             float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float s = fmaf(-2.0f, acc[pb][i], cv[i]);
-                const unsigned key = (__float_as_uint(s) & 0xffffffe0u) | (unsigned)((i & 3) + 8 * (i >> 2));
+                const float sc = fmaf(-2.0f, acc[i], cv[i]);
+                const unsigned key = (__float_as_uint(sc) & 0xffffffe0u) | (unsigned)((i & 3) + 8 * (i >> 2));
                 es_insert(b0, b1, b2, __uint_as_float(key));
             }
             // full centre index (7 bits): bits 2, 5, 6 come from the wave / half-wave
@@ -436,59 +487,51 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
                 n1 = es_med3(b0, b1, b2);
                 b0 = n0; b1 = n1; b2 = n2;
             }
-            const float o0 = __shfl_xor(b0, 32, 64), o1 = __shfl_xor(b1, 32, 64), o2 = __shfl_xor(b2, 32, 64);
+            const float o0 = es_swap32(b0), o1 = es_swap32(b1), o2 = es_swap32(b2);
             es_insert(b0, b1, b2, o0);
             es_insert(b0, b1, b2, o1);
             es_insert(b0, b1, b2, o2);
             if (hh == 0) {
-                scr[(wave * 3 + 0) * 128 + pb * 32 + r] = b0;
-                scr[(wave * 3 + 1) * 128 + pb * 32 + r] = b1;
-                scr[(wave * 3 + 2) * 128 + pb * 32 + r] = b2;
+                float* sc = scr + (j & 1) * 384 + wave * 96;
+                sc[r] = b0;
+                sc[32 + r] = b1;
+                sc[64 + r] = b2;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tid < 128) {
-            float b0 = scr[tid], b1 = scr[128 + tid], b2 = scr[256 + tid];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                es_insert(b0, b1, b2, scr[(w * 3 + 0) * 128 + tid]);
-                es_insert(b0, b1, b2, scr[(w * 3 + 1) * 128 + tid]);
-                es_insert(b0, b1, b2, scr[(w * 3 + 2) * 128 + tid]);
-            }
-            const int p = t * 128 + tid;
-            if (p < rows) {
-                res[p] = b0;
-                res[ES_RMAX + p] = b1;
-                res[2 * ES_RMAX + p] = b2;
-            }
-        }
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        islot = islot + 1 == NSLOT ? 0 : islot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tail refills have landed: the ring is dead
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (tid < 32) merge_unit(nu - 1);
+    __syncthreads();
 
     // decisions for all rows of the block
     float cm2 = 0.f;
-    for (int c = 0; c < 128; ++c) {
-        const float v = cnl[c];
-        if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
+    {
+        const float v0 = cnl[lane], v1 = cnl[lane + 64];
+        if (v0 < 3.0e38f) cm2 = v0;
+        if (v1 < 3.0e38f) cm2 = fmaxf(cm2, v1);
+        cm2 = wave_max_f32(cm2);
     }
     const float cmax = sqrtf(cm2) * 1.0000002f;
     const float sq = sqrtf((float)DP);
     // |s~ - s| <= A*||x'|| + B (see estep_mfma_kernel) + the key's low 7 bits: 2^-16 * (||c'||^2 + 2 ||x'|| ||c'||)
     const float A = 1.5f * (2.02f * (9.765625e-4f + DP * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 3.06e-5f * cmax);
     const float B = 1.5f * (6.0e-8f * sq * cmax + 2.4e-7f * cmax * cmax + 1.53e-5f * cmax * cmax);
-    int* l_flag = (int*)ring;
+    int* l_flag = (int*)smem;
     int* l_cand = l_flag + ES_RMAX;
     int* l_full = l_cand + ES_RMAX;
-    for (int p = tid; p < rows; p += 256) {
+#pragma unroll
+    for (int j = 0; j < ES_RMAX / 256; ++j) {
+        const int p = tid + 256 * j;
+        const long long point = (bid + (long long)(p >> 5) * G) * 32 + (p & 31);
+        if (p >= nu * 32 || point >= n) continue;
         const float m0 = res[p], m1 = res[ES_RMAX + p], m2 = res[2 * ES_RMAX + p];
         const int j0 = (int)(__float_as_uint(m0) & 127u), j1 = (int)(__float_as_uint(m1) & 127u);
-        const long long point = row0 + p;
         labels[point] = j0;
-        const float E = A * xnorm[point] + B;
+        const float E = A * xn_r[j] + B;
         if (!(m1 - m0 > 2.0f * E)) {       // also catches NaN
             if (m2 - m0 > 2.0f * E) {
                 const int pos = atomicAdd(&cnts[0], 1);
@@ -601,19 +644,19 @@ __global__ void __launch_bounds__(128) estep_refine_full_kernel(const float* __r
 
 // both refine passes in one launch (streaming path): the lower half of the grid walks the pair list one wave per row, the
 // upper half the full list one block per row.
-__global__ void __launch_bounds__(128) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
+__global__ void __launch_bounds__(256) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
                                                                 const float* __restrict__ ct, const EHdr* eh, const int* flag_list,
                                                                 const int* flag_cand, const int* full_list, int d, int k, int kp,
                                                                 int32_t* labels, int32_t* refine_rows_out) {
     extern __shared__ double xs[];
-    __shared__ double rv[2];
-    __shared__ int ri[2];
+    __shared__ double rv[4];
+    __shared__ int ri[4];
     const int half_grid = gridDim.x >> 1;
     if (blockIdx.x == 0 && threadIdx.x == 0 && refine_rows_out) *refine_rows_out = eh->flag_cnt + eh->full_cnt;
     if ((int)blockIdx.x < half_grid) {
         const int lane = threadIdx.x & 63;
         const int cnt = eh->flag_cnt;
-        for (int f = blockIdx.x * 2 + (threadIdx.x >> 6); f < cnt; f += 2 * half_grid) {
+        for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < cnt; f += 4 * half_grid) {
             const long long row = flag_list[f];
             const int cand = flag_cand[f];
             const float* x = X + row * d;
@@ -621,6 +664,38 @@ __global__ void __launch_bounds__(128) estep_refine_both_kernel(const float* __r
             const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
             const float *c0 = C + (size_t)lo * d, *c1 = C + (size_t)hi * d;
             double s0 = 0.0, s1 = 0.0;
+            if ((d & 3) == 0) {
+                // all loads of a 1024-column slab are issued before the first is consumed (a scalar loop paid one memory
+                // latency per 64 columns); the per-lane partial sums differ from the scalar loop's, the float64 total does
+                // not beyond 1e-16 relative (decision semantics)
+                for (int j0 = 0; j0 < d; j0 += 1024) {
+                    float4 xv[4], av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + 256 * u + 4 * lane;
+                        if (j < d) {
+                            xv[u] = *(const float4*)(x + j);
+                            av[u] = *(const float4*)(c0 + j);
+                            bv[u] = *(const float4*)(c1 + j);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + 256 * u + 4 * lane;
+                        if (j < d) {
+                            double t;
+                            t = (double)xv[u].x - (double)av[u].x; s0 = fma(t, t, s0);
+                            t = (double)xv[u].y - (double)av[u].y; s0 = fma(t, t, s0);
+                            t = (double)xv[u].z - (double)av[u].z; s0 = fma(t, t, s0);
+                            t = (double)xv[u].w - (double)av[u].w; s0 = fma(t, t, s0);
+                            t = (double)xv[u].x - (double)bv[u].x; s1 = fma(t, t, s1);
+                            t = (double)xv[u].y - (double)bv[u].y; s1 = fma(t, t, s1);
+                            t = (double)xv[u].z - (double)bv[u].z; s1 = fma(t, t, s1);
+                            t = (double)xv[u].w - (double)bv[u].w; s1 = fma(t, t, s1);
+                        }
+                    }
+                }
+            } else
             for (int j = lane; j < d; j += 64) {
                 const double xv = (double)x[j];
                 const double d0 = xv - (double)c0[j], d1 = xv - (double)c1[j];
@@ -638,43 +713,76 @@ __global__ void __launch_bounds__(128) estep_refine_both_kernel(const float* __r
         }
         return;
     }
+    // full list: the row as doubles in LDS; each of the four waves sweeps every fourth centre, eight centres per pass, whole
+    // centre rows in coalesced float4 loads that are all issued before the first is consumed (a walk down the transposed
+    // matrix paid one memory latency per 4 columns)
     const int cnt = eh->full_cnt;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int f = blockIdx.x - half_grid; f < cnt; f += half_grid) {
         const long long row = full_list[f];
         __syncthreads();
-        for (int j = threadIdx.x; j < d; j += 128) xs[j] = (double)X[row * d + j];
+        for (int j = threadIdx.x; j < d; j += 256) xs[j] = (double)X[row * d + j];
         __syncthreads();
         double best = INFINITY;
         int bi = 0x7fffffff;
-        for (int c0 = 0; c0 < k; c0 += 128) {
-            const int c = c0 + threadIdx.x;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const float* col = ct + c;
-            int j = 0;
-            for (; j + 4 <= d; j += 4) {
-                const double d0 = xs[j] - (double)col[(size_t)j * kp];
-                const double d1 = xs[j + 1] - (double)col[(size_t)(j + 1) * kp];
-                const double d2 = xs[j + 2] - (double)col[(size_t)(j + 2) * kp];
-                const double d3 = xs[j + 3] - (double)col[(size_t)(j + 3) * kp];
-                a0 = fma(d0, d0, a0); a1 = fma(d1, d1, a1); a2 = fma(d2, d2, a2); a3 = fma(d3, d3, a3);
-            }
-            for (; j < d; ++j) {
-                const double d0 = xs[j] - (double)col[(size_t)j * kp];
-                a0 = fma(d0, d0, a0);
-            }
-            const double s = (a0 + a1) + (a2 + a3);
-            if (c < k && s < best) { best = s; bi = c; }      // NaN never wins
-        }
+        for (int c0 = wv; c0 < k; c0 += 32) {
+            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if ((d & 3) == 0) {
+                for (int j0 = 4 * lane; j0 < d; j0 += 768) {
+                    float4 cv[8][3];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) {
+                            const int c = c0 + 4 * u, j = j0 + 256 * v;
+                            if (c < k && j < d) cv[u][v] = *(const float4*)(C + (size_t)c * d + j);
+                        }
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const int j = j0 + 256 * v;
+                        if (j < d) {
+                            const double x0 = xs[j], x1 = xs[j + 1], x2 = xs[j + 2], x3 = xs[j + 3];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                if (c0 + 4 * u < k) {
+                                    double t;
+                                    t = x0 - (double)cv[u][v].x; a[u] = fma(t, t, a[u]);
+                                    t = x1 - (double)cv[u][v].y; a[u] = fma(t, t, a[u]);
+                                    t = x2 - (double)cv[u][v].z; a[u] = fma(t, t, a[u]);
+                                    t = x3 - (double)cv[u][v].w; a[u] = fma(t, t, a[u]);
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                for (int j = lane; j < d; j += 64) {
+                    const double x0 = xs[j];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + 4 * u;
+                        if (c < k) {
+                            const double t = x0 - (double)C[(size_t)c * d + j];
+                            a[u] = fma(t, t, a[u]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 4 * u;
+                if (c < k) {
+                    const double sum = wave_sum_f64(a[u]);
+                    if (sum < best || (sum == best && c < bi)) { best = sum; bi = c; }      // NaN never wins
+                }
+            }
         }
-        if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+        if (lane == 0) { rv[wv] = best; ri[wv] = bi; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            int w = (rv[1] < rv[0] || (rv[1] == rv[0] && ri[1] < ri[0])) ? 1 : 0;
+            int w = 0;
+            for (int q = 1; q < 4; ++q)
+                if (rv[q] < rv[w] || (rv[q] == rv[w] && ri[q] < ri[w])) w = q;
             labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
         }
     }
@@ -697,6 +805,7 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     int* flags = (int*)((char*)ct + scd_align(4 * (size_t)kp * dp));
     int* fcand = (int*)((char*)flags + scd_align(4 * (size_t)n));
     int* fulls = (int*)((char*)fcand + scd_align(4 * (size_t)n));
+    half_t* chf = (half_t*)((char*)fulls + scd_align(4 * (size_t)n));       // centres in MFMA-fragment order (streaming path)
     const char* p = (const char*)prep;
     const PrepHdr* ph = (const PrepHdr*)p;
     const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
@@ -704,9 +813,9 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
     if (use_stream && kp == 128 && dp <= 768) {
         // streaming filter (K <= 128, D <= 768): 3 launches, no memset
-        prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1);
-        const long long g32 = (n + 31) / 32;
-        long long grid = scd_cdiv(n, 128) < h->n_cu ? scd_cdiv(n, 128) : h->n_cu;
+        prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
+        const long long g32 = (n + 31) / 32;               // units of 32 rows
+        long long grid = g32 < h->n_cu ? g32 : h->n_cu;
         if (grid < scd_cdiv(g32, ES_RMAX / 32)) grid = scd_cdiv(g32, ES_RMAX / 32);
         const half_t* xh = (const half_t*)(p + xh_off);
         const float* xn = (const float*)(p + xnorm_off);
@@ -718,7 +827,7 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             SCD_HIP(hipFuncSetAttribute((const void*)estep_stream_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS)); \
             attr_set = true;                                                                                                 \
         }                                                                                                                    \
-        estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, ch, cn, eh, flags, fcand, fulls, n, labels_out, es_dbg); \
+        estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, chf, cn, eh, flags, fcand, fulls, n, labels_out, es_dbg); \
     } break;
         switch (dp / 128) {
             ES_LAUNCH(1) ES_LAUNCH(2) ES_LAUNCH(3) ES_LAUNCH(4) ES_LAUNCH(5) ES_LAUNCH(6)
@@ -732,13 +841,13 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
             if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
         } else
-        estep_refine_both_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+        estep_refine_both_kernel<<<1024, 256, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
                                                                          refine_rows_out);
         SCD_LAUNCH_CHECK();
         return SCD_OK;
     }
     SCD_HIP(hipMemsetAsync(eh, 0, 64, st));
-    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 0);
+    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 0, nullptr);
     estep_mfma_kernel<<<(unsigned)scd_cdiv(n, 128), 256, 0, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off),
                                                                     ch, cn, eh, flags, fcand, fulls, n, dp, kp, labels_out);
     estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);

@@ -23,7 +23,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 if __name__ == "__main__":
-    n, d, k = 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, 100
+    n, d, k = int(sys.argv[3]) if len(sys.argv) > 3 else 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, 100
     noise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
     x, y, cent = clustered_features(n, d, k, seed=21, center_seed=22, noise=noise)
     X = torch.from_numpy(x).cuda(); C = torch.from_numpy(cent).cuda()
