@@ -398,10 +398,15 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(cf[c][s]));     // no compiler-visible load is left in flight
+    // values touched once per unit (or once per kernel) are parked in AGPRs: the 192 centre-fragment registers, the fragment
+    // ring and the selection state fill the 256 architectural VGPRs, and left alone hipcc parks centre fragments instead
+    // (four v_accvgpr_read in front of every MFMA)
 #pragma unroll
-    for (int j = 0; j < ES_RMAX / 256; ++j) asm volatile("" : "+v"(xn_r[j]));
+    for (int j = 0; j < ES_RMAX / 256; ++j) asm volatile("" : "+a"(xn_r[j]));
 #pragma unroll
-    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(cv[i]));
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+a"(cv[i]));
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) asm volatile("" : "+a"(soff[i]));
 
     const int xsw = (hh ^ (r & 15)) << 4;
     const int base_idx = 32 * wave + 4 * hh;
@@ -420,6 +425,46 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         res[2 * ES_RMAX + j * 32 + tid] = b2;
     };
 
+    // The selection ("epilogue") of unit j-1 runs INSIDE unit j's MFMA stream: its 19 steps (16 key inserts, index rewrite +
+    // sort, half-wave merge, patch write) are dealt over the NG fragment groups, and the running triple is threaded through
+    // each group's wait asm as an operand, so step group g sits between wait g and wait g+1, i.e. in the shadow of group g's
+    // MFMAs (a lone wave per SIMD overlaps nothing by itself).  accp holds unit j-1's accumulators.
+    f32x16 accp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accp[i] = 0.f;
+    float e0 = 3.0e38f, e1 = 3.0e38f, e2 = 3.0e38f;
+    auto epi_step = [&](int st, int unit) {
+        if (st < 16) {
+            if (st == 0) { e0 = 3.0e38f; e1 = 3.0e38f; e2 = 3.0e38f; }
+            const float sc = fmaf(-2.0f, accp[st], cv[st]);
+            const unsigned key = (__float_as_uint(sc) & 0xffffffe0u) | (unsigned)((st & 3) + 8 * (st >> 2));
+            es_insert(e0, e1, e2, __uint_as_float(key));
+        } else if (st == 16) {
+            // full centre index (7 bits): bits 2, 5, 6 come from the wave / half-wave.  Rewriting low bits can reorder keys
+            // that agree above bit 6: the insert network needs an ascending triple
+            e0 = __uint_as_float((__float_as_uint(e0) & 0xffffff9bu) | (unsigned)base_idx);
+            e1 = __uint_as_float((__float_as_uint(e1) & 0xffffff9bu) | (unsigned)base_idx);
+            e2 = __uint_as_float((__float_as_uint(e2) & 0xffffff9bu) | (unsigned)base_idx);
+            float n0, n1, n2;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(n0) : "v"(e0), "v"(e1), "v"(e2));
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(e0), "v"(e1), "v"(e2));
+            n1 = es_med3(e0, e1, e2);
+            e0 = n0; e1 = n1; e2 = n2;
+        } else if (st == 17) {
+            const float o0 = es_swap32(e0), o1 = es_swap32(e1), o2 = es_swap32(e2);
+            es_insert(e0, e1, e2, o0);
+            es_insert(e0, e1, e2, o1);
+            es_insert(e0, e1, e2, o2);
+        } else {
+            if (hh == 0) {
+                float* sc = scr + (unit & 1) * 384 + wave * 96;
+                sc[r] = e0;
+                sc[32 + r] = e1;
+                sc[64 + r] = e2;
+            }
+        }
+    };
+
     int slot = 0, islot = NSLOT - 1;
     for (int j = 0; j < nu; ++j) {
         {   // my part of unit j has landed: at most min(NSLOT - 2, nu - 1 - j) younger units may still fly
@@ -430,8 +475,8 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         }
         __builtin_amdgcn_s_barrier();                                                        // everyone's has; slot islot is free
         asm volatile("" ::: "memory");
-        if (dbg & 16) issue(j + NSLOT - 1, islot);
-        if (j > 0 && tid < 32) merge_unit(j - 1);
+        if (dbg & 17) issue(j + NSLOT - 1, islot);     // 16: ring-only ablation; 1: all fills right behind the barrier
+        if (j > 1 && tid < 32) merge_unit(j - 2);      // unit j-2's patch was written during unit j-1, before this barrier
         if (!(dbg & 16)) {
             const unsigned sl = sbase + slot * SLOTB + r * (DP * 2);
             f32x16 acc;           // one accumulation chain: back-to-back dependent MFMAs of this shape run at full rate
@@ -440,7 +485,7 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
             half8 fb[3][4];
             // k-step kk = 8c + s reads the 16-B piece (2s + hh) ^ (r & 15) of segment c of row r
 #define ES_RD(DST, KK) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(sl + (((((KK) & 7) << 5) ^ xsw))), "n"(((KK) >> 3) * 256))
-#define ES_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]))
+#define ES_WAIT(N, F) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(e0), "+v"(e1), "+v"(e2))
 #pragma unroll
             for (int i = 0; i < 4; ++i) ES_RD(fb[0][i], i);
             if (NG > 1) {
@@ -466,45 +511,26 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
                     const int kk = 4 * g + i;
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf[kk >> 3][kk & 7], fb[g % 3][i], acc, 0, 0, 0);
                 }
-                issue_one(j + NSLOT - 1, islot, g);      // one ring-fill instruction per group, in the shadow of its MFMAs
-            }
-            // unit epilogue: the lane's three smallest keys of its 16 centres for point r
-            float b0 = 3.0e38f, b1 = 3.0e38f, b2 = 3.0e38f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float sc = fmaf(-2.0f, acc[i], cv[i]);
-                const unsigned key = (__float_as_uint(sc) & 0xffffffe0u) | (unsigned)((i & 3) + 8 * (i >> 2));
-                es_insert(b0, b1, b2, __uint_as_float(key));
+                for (int st = 19 * g / NG; st < 19 * (g + 1) / NG; ++st) epi_step(st, j - 1);     // unit j-1 (a dummy at j = 0)
+                if (!(dbg & 1)) issue_one(j + NSLOT - 1, islot, g);      // one ring-fill instruction per group, in the shadow of its MFMAs
             }
-            // full centre index (7 bits): bits 2, 5, 6 come from the wave / half-wave
-            b0 = __uint_as_float((__float_as_uint(b0) & 0xffffff9bu) | (unsigned)base_idx);
-            b1 = __uint_as_float((__float_as_uint(b1) & 0xffffff9bu) | (unsigned)base_idx);
-            b2 = __uint_as_float((__float_as_uint(b2) & 0xffffff9bu) | (unsigned)base_idx);
-            {   // rewriting low bits can reorder keys that agree above bit 6: the insert network needs an ascending triple
-                float n0, n1, n2;
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(n0) : "v"(b0), "v"(b1), "v"(b2));
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(n2) : "v"(b0), "v"(b1), "v"(b2));
-                n1 = es_med3(b0, b1, b2);
-                b0 = n0; b1 = n1; b2 = n2;
-            }
-            const float o0 = es_swap32(b0), o1 = es_swap32(b1), o2 = es_swap32(b2);
-            es_insert(b0, b1, b2, o0);
-            es_insert(b0, b1, b2, o1);
-            es_insert(b0, b1, b2, o2);
-            if (hh == 0) {
-                float* sc = scr + (j & 1) * 384 + wave * 96;
-                sc[r] = b0;
-                sc[32 + r] = b1;
-                sc[64 + r] = b2;
-            }
+            accp = acc;
         }
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
         islot = islot + 1 == NSLOT ? 0 : islot + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the tail refills have landed: the ring is dead
+    if (!(dbg & 16)) {
+#pragma unroll
+        for (int st = 0; st < 19; ++st) epi_step(st, nu - 1);       // the last unit's selection has no stream to hide in
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the ring is dead, every patch is written
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (tid < 32) merge_unit(nu - 1);
+    if (tid < 32) {
+        if (nu > 1) merge_unit(nu - 2);
+        merge_unit(nu - 1);
+    }
     __syncthreads();
 
     // decisions for all rows of the block
