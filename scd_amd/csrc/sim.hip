@@ -10,6 +10,7 @@
 // recomputes the candidates' dot products in float64, sorts them, and certifies that no non-candidate
 // could reach rank k given the accumulation error bound; uncertified rows take an exact full-row pass.
 #include "common.h"
+#include <stdlib.h>
 
 #define TOPM 8
 
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
                                                           long long n, int d, long long v, float scale,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                           float* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 x 16 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 x 16 KB ring + 8 x 4 KB parked fragments
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
@@ -66,16 +67,27 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
     const long long irow = img < n ? img : n - 1;
     const half_t* frow = F + irow * d + 8 * hh;
 
-    half8 bf[32];
+    // 28 of the 32 image fragments stay in registers; the last four (d-chunk 7) are parked in a per-wave LDS
+    // patch and re-read once per tile: with all 32 resident hipcc spills some of them to scratch, and every scratch reload
+    // is a vmcnt(0) that drains the fill ring
+    half8 bf[28];
+    char* bfl = smem + 65536 + wave * 4096 + lane * 16;
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
+        half8 t;
         if (16 * s < d) {
-            bf[s] = *(const half8*)(frow + 16 * s);
+            t = *(const half8*)(frow + 16 * s);
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bf[s][q] = (half_t)0.f;
+            for (int q = 0; q < 8; ++q) t[q] = (half_t)0.f;
         }
+        if (s < 28) bf[s] = t;
+        else *(half8*)(bfl + (s - 28) * 1024) = t;
     }
+    // the image fragments are complete before the loop: a load still pending at the loop header makes hipcc put a
+    // vmcnt(0) in front of the first use of every fragment in every sub-step, which drains the fill ring each time
+#pragma unroll
+    for (int s = 0; s < 28; ++s) asm volatile("" : "+v"(bf[s]));
     float lv[TOPM];
     int li[TOPM];
 #pragma unroll
@@ -96,13 +108,16 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
         src_row[p] = rowl;
         src_col[p] = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
     }
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int tile, int dc, int slot) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             long long vr = (long long)tile * 128 + src_row[p];
             vr = vr < v ? vr : v - 1;                        // padded names re-read the last row; masked in the epilogue
-            __builtin_amdgcn_global_load_lds((const void*)(Wt + vr * d + dc * 64 + src_col[p]),
-                                             (sim_lds_ptr_t)(smem + slot * 16384 + wave * 2048 + p * 1024), 16, 0, 0);
+            // asm, not the builtin: for the builtin hipcc assumes the fill may alias every later ds_read and drains the whole
+            // ring (s_waitcnt vmcnt(0)) in the middle of each sub-step; the counted waits below are the synchronisation
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         ::"s"(sbase + slot * 16384 + wave * 2048 + p * 1024), "v"(Wt + vr * d + dc * 64 + src_col[p]) : "memory");
         }
     };
     auto off128 = [](int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); };
@@ -141,10 +156,18 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
         for (int dcc = 0; dcc < 8; ++dcc) {                 // d-chunk index is a compile-time constant: bf[] stays in registers
             if (dcc < nd) {
                 const char* cur = smem + (s & 3) * 16384;
+                half8 b0, b1, b2, b3;
+                if (dcc == 7) {
+                    b0 = *(const half8*)bfl; b1 = *(const half8*)(bfl + 1024);
+                    b2 = *(const half8*)(bfl + 2048); b3 = *(const half8*)(bfl + 3072);
+                } else {
+                    b0 = bf[(dcc & 7) * 4 + 0 < 28 ? dcc * 4 + 0 : 0]; b1 = bf[dcc * 4 + 1 < 28 ? dcc * 4 + 1 : 0];
+                    b2 = bf[dcc * 4 + 2 < 28 ? dcc * 4 + 2 : 0]; b3 = bf[dcc * 4 + 3 < 28 ? dcc * 4 + 3 : 0];
+                }
                 rd(cur, 1, fb);
-                mm(fa, bf[dcc * 4 + 0]);
+                mm(fa, b0);
                 rd(cur, 2, fa);
-                mm(fb, bf[dcc * 4 + 1]);
+                mm(fb, b1);
                 if (s + 1 < steps) {
                     if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -154,9 +177,9 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
                 if (s + 3 < steps) issue(ntile, ndc, (s + 3) & 3);
                 if (++ndc == nd) { ndc = 0; ++ntile; }
                 rd(cur, 3, fb);
-                mm(fa, bf[dcc * 4 + 2]);
+                mm(fa, b2);
                 if (s + 1 < steps) rd(smem + ((s + 1) & 3) * 16384, 0, fa);
-                mm(fb, bf[dcc * 4 + 3]);
+                mm(fb, b3);
                 ++s;
             }
         }
@@ -211,6 +234,229 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
             stats[(img * 2 + hh) * 2 + 1] = sm_z;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Four-wave variant (SCD_SIM_W4=1; same speed as the eight-wave kernel today): one wave per SIMD with the whole 512-register file.  Block = 256 images, wave w owns
+// 64 of them (two 32-image sets): the 2 x 32 image fragments (d <= 512) live in 256 AGPRs and are read by the MFMAs
+// directly as the B operand (v_mfma ... v[A], a[B], v[C]: asm, because left to itself hipcc treats AGPRs as spill space
+// and copies four registers in front of every MFMA), the 2 x 4 accumulators (64 images x 128 names) in 128 VGPRs.
+// Every A fragment read from LDS now feeds two MFMAs (half the LDS traffic of the eight-wave kernel), there are four
+// waves at the barrier instead of eight, and the W^T sub-tiles [128 names][64 d] stream through an 8-slot LDS-DMA ring
+// (a whole tile ahead).  Hazards the compiler cannot see (the MFMAs are asm): accumulators are (re)started by MFMAs with
+// C = 0, never by VALU writes; the tile epilogue reads them behind s_nop padding; A fragments come from asm ds_reads
+// with counted waits that carry the fragments as operands.
+template <bool SOFTMAX>
+__global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
+                                                          long long n, int d, long long v, float scale,
+                                                          float* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                          float* __restrict__ stats, int xmode) {
+    constexpr int NS = 8;                                             // ring slots of 16 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    half8 bf[2][32];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
+        const half_t* frow = F + (img < n ? img : n - 1) * d + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            if (16 * s < d) {
+                bf[q][s] = *(const half8*)(frow + 16 * s);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[q][s][e] = (half_t)0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(bf[q][s]));       // resident in AGPRs from here on
+
+    float lv0[TOPM], lv1[TOPM];
+    int li0[TOPM], li1[TOPM];
+    float sm_m0 = -INFINITY, sm_m1 = -INFINITY, sm_z0 = 0.f, sm_z1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < TOPM; ++j) {
+        lv0[j] = -INFINITY; lv1[j] = -INFINITY;
+        li0[j] = -1; li1[j] = -1;
+    }
+
+    const int nd = d >> 6;
+    const int ntiles = (int)((v + 127) / 128);
+    const int steps = ntiles * nd;
+    // ring fill: wave w stages rows 32w .. 32w+31 of a sub-tile, 4 instructions x 8 rows; lane -> (row lane/8, chunk lane%8)
+    int src_row[4], src_col[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int rowl = wave * 32 + p * 8 + (lane >> 3);
+        src_row[p] = rowl;
+        src_col[p] = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+    }
+    int itile = 0, idc = 0, istep = 0;                       // sub-step being issued
+    auto issue_one = [&](int p) {
+        if (istep >= steps) return;
+        long long vr = (long long)itile * 128 + src_row[p];
+        vr = vr < v ? vr : v - 1;                            // padded names re-read the last row; masked in the epilogue
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                     ::"s"(sbase + (istep & (NS - 1)) * 16384 + wave * 4096 + p * 1024), "v"(Wt + vr * d + idc * 64 + src_col[p]) : "memory");
+    };
+    auto issue_advance = [&]() {
+        ++istep;
+        if (++idc == nd) { idc = 0; ++itile; }
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < NS - 1; ++pre) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_one(p);
+        issue_advance();
+    }
+
+    f32x16 acc[2][4];
+    const unsigned fbase = sbase + r * 128;
+    const int fsw = (r >> 1) & 7;
+    // fragment (cb, k16) of the slot: row cb*32 + r, 16-B chunk (2 k16 + hh) ^ ((row >> 1) & 7)
+#define SW_RD(DST, SL, CB, K16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((SL) + ((((2 * (K16) + hh) ^ fsw)) << 4)), "n"((CB) * 4096))
+#define SW_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR[0]), "+v"(FR[1]), "+v"(FR[2]), "+v"(FR[3]))
+#define SW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define SW_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "a"(B))
+    int s = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+        for (int dcc = 0; dcc < 8; ++dcc) {
+            if (dcc < nd) {
+                // my part of sub-step s has landed: at most min(NS - 2, steps - 1 - s) younger sub-steps (4 fills each) fly
+                const int younger = steps - 1 - s;
+                if (younger >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * 4) : "memory");
+                else if (younger >= 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+                else if (younger == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // everyone's has; the slot of sub-step s-1 is free
+                asm volatile("" ::: "memory");
+                const unsigned sl = fbase + (s & (NS - 1)) * 16384;
+                half8 fr[3][4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) SW_RD(fr[0][cb], sl, cb, 0);
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) SW_RD(fr[1][cb], sl, cb, 1);
+#pragma unroll
+                for (int k16 = 0; k16 < 4; ++k16) {
+                    if (k16 + 2 < 4) {
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb) SW_RD(fr[(k16 + 2) % 3][cb], sl, cb, k16 + 2);
+                        SW_WAIT(8, fr[k16 % 3]);
+                    } else if (k16 + 1 < 4) {
+                        SW_WAIT(4, fr[k16 % 3]);
+                    } else {
+                        SW_WAIT(0, fr[k16 % 3]);
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if ((xmode & 2) && !(dcc == 0 && k16 == 0)) continue;      // xmode 2: ablation without the MFMAs
+                            if (dcc == 0 && k16 == 0) SW_MFMA0(acc[q][cb], fr[k16 % 3][cb], bf[q][dcc * 4 + k16]);
+                            else SW_MFMA(acc[q][cb], fr[k16 % 3][cb], bf[q][dcc * 4 + k16]);
+                        }
+                    issue_one(k16);                           // one ring-fill instruction per k16 group (sub-step s+NS-1)
+                }
+                issue_advance();
+                ++s;
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                                             "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));   // MFMA -> VALU read
+        {
+            // tile epilogue on UNSCALED dot products (scale > 0 is applied when the lists are written): one max3 tree per
+            // 32-name block decides whether any of its 16 values can enter the list; only the last tile has padded names.
+            const long long vbase = (long long)tile * 128 + 4 * hh;
+            const bool last = tile == ntiles - 1;
+            // (written out per image set: a q loop is "too large to unroll" for hipcc and the lists would go to scratch)
+            // The admission threshold is shared by the two lanes that serve one image (r and r+32 see different names):
+            // a value has to beat the larger of the two lists' 8th entries.  Everything rejected is <= that threshold, which
+            // only grows and ends as max(list_A[7], list_B[7]) - exactly the bound sim_refine_kernel certifies against - and
+            // the number of list insertions (the expensive, divergent part) drops by almost half.
+            auto epi = [&](float (&lvq)[TOPM], int (&liq)[TOPM], float& smm, float& smz, const f32x16 (&accq)[4]) {
+                float thr = lvq[TOPM - 1];
+                {
+                    const unsigned u = __float_as_uint(thr);
+                    const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    thr = fmaxf(thr, __uint_as_float((lane & 32) ? pr[0] : pr[1]));
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    f32x16 a = accq[cb];
+                    if (last) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (vbase + cb * 32 + (i & 3) + 8 * (i >> 2) >= v) a[i] = -INFINITY;
+                    }
+                    // block maximum first, then groups of four, then single values: every test is a wave-any branch.
+                    // (Measured alternative: wave-wide ballot masks per value + one conditional-move selection and a single
+                    // insertion per block when no lane has two candidates - 10 % slower than this, SGPR pressure.)
+                    float g[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) g[q4] = fmaxf(fmaxf(a[4 * q4], a[4 * q4 + 1]), fmaxf(a[4 * q4 + 2], a[4 * q4 + 3]));
+                    const float bm = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
+                    if (bm > thr) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            if (g[q4] > thr) {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    const int i = 4 * q4 + m;
+                                    const float val = a[i];
+                                    if (val > thr) {
+                                        topm_insert(lvq, liq, val, (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2)));
+                                        thr = fmaxf(thr, lvq[TOPM - 1]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (SOFTMAX) {
+                        if (bm > -INFINITY) {
+                            const float mn = fmaxf(smm, bm);
+                            float z = smz * __expf((smm - mn) * scale);
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) z += __expf((a[i] - mn) * scale);
+                            smz = z;
+                            smm = mn;
+                        }
+                    }
+                }
+            };
+            if (!(xmode & 1) || last) {          // xmode 1: timing ablation without the tile epilogue (results are wrong)
+                epi(lv0, li0, sm_m0, sm_z0, acc[0]);
+                epi(lv1, li1, sm_m1, sm_z1, acc[1]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto emit = [&](int q, const float (&lvq)[TOPM], const int (&liq)[TOPM], float smm, float smz) {
+        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
+        if (img < n) {
+            float* cv = cand_val + (img * 2 + hh) * TOPM;
+            int* ci = cand_idx + (img * 2 + hh) * TOPM;
+#pragma unroll
+            for (int j = 0; j < TOPM; ++j) {
+                cv[j] = lvq[j] * scale;
+                ci[j] = liq[j];
+            }
+            if (SOFTMAX) {
+                stats[(img * 2 + hh) * 2] = smm * scale;
+                stats[(img * 2 + hh) * 2 + 1] = smz;
+            }
+        }
+    };
+    emit(0, lv0, li0, sm_m0, sm_z0);
+    emit(1, lv1, li1, sm_m1, sm_z1);
 }
 
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
@@ -430,16 +676,32 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     static bool attr = false;
     if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
         attr = true;
     }
-    if (mode == SCD_SIM_SOFTMAX) {
-        sim_topk_kernel<true><<<g1, 512, 65536, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+    static const int use_w4 = getenv("SCD_SIM_W4") ? atoi(getenv("SCD_SIM_W4")) : 0;
+    static const int sim_x = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
+    static bool attr4 = false;
+    if (use_w4 && !attr4) {
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr4 = true;
+    }
+    if (use_w4 && mode == SCD_SIM_SOFTMAX) {
+        sim_topk_w4_kernel<true><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
+        sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+    } else if (use_w4) {
+        sim_topk_w4_kernel<false><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
+        sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+    } else if (mode == SCD_SIM_SOFTMAX) {
+        sim_topk_kernel<true><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else {
-        sim_topk_kernel<false><<<g1, 512, 65536, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        sim_topk_kernel<false><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     }
