@@ -54,8 +54,11 @@ __device__ __forceinline__ half8 bf_sel(const half8 (&bf)[32], int dc, int k16) 
 // running top-8 list, its threshold and the online-softmax statistics are lane-private registers.
 typedef __attribute__((address_space(3))) void* sim_lds_ptr_t;
 
-template <bool SOFTMAX>
-__global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
+// NW = 8 (default): one 512-thread block (256 images) per CU.  NW = 4 (SCD_SIM_NW=4, same speed): TWO independent 256-thread blocks (128 images each)
+// per CU: their tile epilogues (the divergent top-8 maintenance, ~1/3 of the kernel) drift apart, so one block's MFMAs run
+// under the other's epilogue - with eight waves behind one barrier all of them reach the epilogue together.
+template <bool SOFTMAX, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) sim_topk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
                                                           long long n, int d, long long v, float scale,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx,
                                                           float* __restrict__ stats) {
@@ -63,7 +66,8 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
-    const long long img = (long long)blockIdx.x * 256 + wave * 32 + r;
+    constexpr int IPW = 16 / NW;                                      // ring-fill instructions per wave and sub-step
+    const long long img = (long long)blockIdx.x * (NW * 32) + wave * 32 + r;
     const long long irow = img < n ? img : n - 1;
     const half_t* frow = F + irow * d + 8 * hh;
 
@@ -101,23 +105,31 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
     const int ntiles = (int)((v + 127) / 128);
     const int steps = ntiles * nd;
     // DMA source of this lane: wave w stages rows w*16 .. w*16+15 (2 instructions x 8 rows); lane -> (row lane/8, chunk lane%8)
-    int src_row[2], src_col[2];
+    // Every fill address = wave-uniform base (tile, d-chunk: scalar) + a per-lane 32-bit byte offset that never changes
+    // (row, swizzled chunk), so a fill costs no vector arithmetic; only the last tile, whose padded names re-read row v-1,
+    // has its own offsets.  (Computed per fill, the 64-bit address took ~14 VALU instructions with two quarter-rate
+    // multiplies: several hundred issue cycles per wave and sub-step.)
+    unsigned voff[IPW], voff_last[IPW];
+    const int ntiles_ = (int)((v + 127) / 128);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int rowl = wave * 16 + p * 8 + (lane >> 3);
-        src_row[p] = rowl;
-        src_col[p] = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+    for (int p = 0; p < IPW; ++p) {
+        const int rowl = wave * (8 * IPW) + p * 8 + (lane >> 3);
+        const int col = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+        long long vr = (long long)(ntiles_ - 1) * 128 + rowl;
+        vr = vr < v ? vr : v - 1;
+        voff[p] = (unsigned)((rowl * d + col) * 2);
+        voff_last[p] = (unsigned)(((int)(vr - (long long)(ntiles_ - 1) * 128) * d + col) * 2);
     }
     const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto issue = [&](int tile, int dc, int slot) {
+        const half_t* base = Wt + (size_t)tile * 128 * d + dc * 64;
+        const bool lastt = tile == ntiles_ - 1;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            long long vr = (long long)tile * 128 + src_row[p];
-            vr = vr < v ? vr : v - 1;                        // padded names re-read the last row; masked in the epilogue
+        for (int p = 0; p < IPW; ++p) {
             // asm, not the builtin: for the builtin hipcc assumes the fill may alias every later ds_read and drains the whole
             // ring (s_waitcnt vmcnt(0)) in the middle of each sub-step; the counted waits below are the synchronisation
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                         ::"s"(sbase + slot * 16384 + wave * 2048 + p * 1024), "v"(Wt + vr * d + dc * 64 + src_col[p]) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         ::"s"(sbase + slot * 16384 + wave * (1024 * IPW) + p * 1024), "v"(lastt ? voff_last[p] : voff[p]), "s"(base) : "memory");
         }
     };
     auto off128 = [](int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); };
@@ -134,7 +146,7 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
         if (pre < steps) issue(ntile, ndc, pre);
         if (++ndc == nd) { ndc = 0; ++ntile; }
     }
-    if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (steps >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -170,7 +182,7 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
                 mm(fb, b1);
                 if (s + 1 < steps) {
                     if (s + 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
                 }
                 __builtin_amdgcn_s_barrier();               // slot s+1 visible; slot s-1 free
                 asm volatile("" ::: "memory");
@@ -188,6 +200,23 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
             // 32-name block decides whether any of its 16 values can enter the list; only the last tile has padded names.
             const long long vbase = (long long)tile * 128 + 4 * hh;
             const bool last = tile == ntiles - 1;
+            // List maintenance is the expensive part of this kernel (1.5 of 4.0 ms measured with the insertion run for
+            // every value slot in which ANY of the 64 lanes had a candidate: ~2300 wave-wide insertions of ~40 VALU
+            // instructions per wave).  Two changes:
+            //  * the admission threshold is shared by the two lanes that serve one image (r and r+32 see different names):
+            //    a value has to beat the larger of the two lists' 8th entries.  Everything rejected is <= that threshold,
+            //    which only grows and ends as max(list_A[7], list_B[7]) - the bound sim_refine_kernel certifies against;
+            //  * a candidate is first parked in a one-entry per-lane queue (a 2-instruction conditional move); the wave-wide
+            //    insertion runs when some lane needs its queue slot again and once at the end of the tile, and then serves
+            //    every lane that has something parked.
+            float thr = lv[TOPM - 1];
+            {
+                const unsigned u = __float_as_uint(thr);
+                const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                thr = fmaxf(thr, __uint_as_float((lane & 32) ? pr[0] : pr[1]));
+            }
+            float qv = -INFINITY;
+            int qi = -1;
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 if (last) {
@@ -199,11 +228,21 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
 #pragma unroll
                 for (int i = 3; i < 15; i += 2) bm = fmaxf(fmaxf(bm, acc[cb][i]), acc[cb][i + 1]);
                 bm = fmaxf(bm, acc[cb][15]);
-                if (bm > lv[TOPM - 1]) {
+                if (__any(bm > thr)) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const float val = acc[cb][i];
-                        if (val > lv[TOPM - 1]) topm_insert(lv, li, val, (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2)));
+                        if (__any(val > thr)) {
+                            if (__any(val > thr && qi >= 0)) {         // somebody needs its queue slot: serve everybody
+                                if (qi >= 0) topm_insert(lv, li, qv, qi);
+                                qi = -1;
+                                thr = fmaxf(thr, lv[TOPM - 1]);
+                            }
+                            if (val > thr) {
+                                qv = val;
+                                qi = (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2));
+                            }
+                        }
                     }
                 }
                 if (SOFTMAX) {
@@ -218,6 +257,9 @@ __global__ void __launch_bounds__(512, 2) sim_topk_kernel(const half_t* __restri
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+            }
+            if (__any(qi >= 0)) {
+                if (qi >= 0) topm_insert(lv, li, qv, qi);
             }
         }
     }
@@ -291,20 +333,22 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
     const int ntiles = (int)((v + 127) / 128);
     const int steps = ntiles * nd;
     // ring fill: wave w stages rows 32w .. 32w+31 of a sub-tile, 4 instructions x 8 rows; lane -> (row lane/8, chunk lane%8)
-    int src_row[4], src_col[4];
+    unsigned voff[4], voff_last[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int rowl = wave * 32 + p * 8 + (lane >> 3);
-        src_row[p] = rowl;
-        src_col[p] = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+        const int col = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
+        long long vr = (long long)(ntiles - 1) * 128 + rowl;
+        vr = vr < v ? vr : v - 1;                            // padded names re-read the last row; masked in the epilogue
+        voff[p] = (unsigned)((rowl * d + col) * 2);
+        voff_last[p] = (unsigned)(((int)(vr - (long long)(ntiles - 1) * 128) * d + col) * 2);
     }
     int itile = 0, idc = 0, istep = 0;                       // sub-step being issued
     auto issue_one = [&](int p) {
         if (istep >= steps) return;
-        long long vr = (long long)itile * 128 + src_row[p];
-        vr = vr < v ? vr : v - 1;                            // padded names re-read the last row; masked in the epilogue
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                     ::"s"(sbase + (istep & (NS - 1)) * 16384 + wave * 4096 + p * 1024), "v"(Wt + vr * d + idc * 64 + src_col[p]) : "memory");
+        const half_t* base = Wt + (size_t)itile * 128 * d + idc * 64;      // wave-uniform: scalar arithmetic
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(sbase + (istep & (NS - 1)) * 16384 + wave * 4096 + p * 1024), "v"(itile == ntiles - 1 ? voff_last[p] : voff[p]), "s"(base) : "memory");
     };
     auto issue_advance = [&]() {
         ++istep;
@@ -389,6 +433,8 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
                     const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                     thr = fmaxf(thr, __uint_as_float((lane & 32) ? pr[0] : pr[1]));
                 }
+                float qv = -INFINITY;
+                int qi = -1;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     f32x16 a = accq[cb];
@@ -397,25 +443,25 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
                         for (int i = 0; i < 16; ++i)
                             if (vbase + cb * 32 + (i & 3) + 8 * (i >> 2) >= v) a[i] = -INFINITY;
                     }
-                    // block maximum first, then groups of four, then single values: every test is a wave-any branch.
-                    // (Measured alternative: wave-wide ballot masks per value + one conditional-move selection and a single
-                    // insertion per block when no lane has two candidates - 10 % slower than this, SGPR pressure.)
-                    float g[4];
+                    // candidates are parked in a one-entry per-lane queue; the wave-wide list insertion runs when some lane
+                    // needs its slot again and once per tile (see sim_topk_kernel)
+                    float bm = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) g[q4] = fmaxf(fmaxf(a[4 * q4], a[4 * q4 + 1]), fmaxf(a[4 * q4 + 2], a[4 * q4 + 3]));
-                    const float bm = fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3]));
-                    if (bm > thr) {
+                    for (int i = 3; i < 15; i += 2) bm = fmaxf(fmaxf(bm, a[i]), a[i + 1]);
+                    bm = fmaxf(bm, a[15]);
+                    if (__any(bm > thr)) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            if (g[q4] > thr) {
-#pragma unroll
-                                for (int m = 0; m < 4; ++m) {
-                                    const int i = 4 * q4 + m;
-                                    const float val = a[i];
-                                    if (val > thr) {
-                                        topm_insert(lvq, liq, val, (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2)));
-                                        thr = fmaxf(thr, lvq[TOPM - 1]);
-                                    }
+                        for (int i = 0; i < 16; ++i) {
+                            const float val = a[i];
+                            if (__any(val > thr)) {
+                                if (__any(val > thr && qi >= 0)) {
+                                    if (qi >= 0) topm_insert(lvq, liq, qv, qi);
+                                    qi = -1;
+                                    thr = fmaxf(thr, lvq[TOPM - 1]);
+                                }
+                                if (val > thr) {
+                                    qv = val;
+                                    qi = (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2));
                                 }
                             }
                         }
@@ -430,6 +476,9 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
                             smm = mn;
                         }
                     }
+                }
+                if (__any(qi >= 0)) {
+                    if (qi >= 0) topm_insert(lvq, liq, qv, qi);
                 }
             };
             if (!(xmode & 1) || last) {          // xmode 1: timing ablation without the tile epilogue (results are wrong)
@@ -676,12 +725,15 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     static bool attr = false;
     if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16384));
+        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16384));
         attr = true;
     }
     static const int use_w4 = getenv("SCD_SIM_W4") ? atoi(getenv("SCD_SIM_W4")) : 0;
     static const int sim_x = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
+    static const int sim_nw = getenv("SCD_SIM_NW") ? atoi(getenv("SCD_SIM_NW")) : 8;
     static bool attr4 = false;
     if (use_w4 && !attr4) {
         SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -697,11 +749,13 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else if (mode == SCD_SIM_SOFTMAX) {
-        sim_topk_kernel<true><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else {
-        sim_topk_kernel<false><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     }
