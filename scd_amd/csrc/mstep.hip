@@ -1,12 +1,13 @@
 // K-Means M-step partial sums + inertia for gfx950 (sskm_constrained.py:118-128 under /root/reference):
 //   for idx in range(k): centers[idx] = cat_feats[labels == idx].mean(0);   inertia = sum ||x - c_old[label]||^2
-// Sort-then-segment instead of scatter: a stable radix sort of (label, row) keys (rocPRIM) turns the scatter into
-// contiguous runs; each wave then streams 64 sorted rows (whole 2-3 KB rows, coalesced), keeps its 4*D/256 columns per
+// Sort-then-segment instead of scatter: a counting sort of (label, row) keys (rocPRIM radix sort for k > 8191) turns the
+// scatter into contiguous runs; each wave then streams 64 sorted rows (whole 2-3 KB rows, coalesced, eight in flight), keeps its 4*D/256 columns per
 // lane in float64 REGISTERS while the label is unchanged, and flushes a run with float64 global atomics (about
 // N/64 + K flushes of D values).  Float64 accumulation makes the result independent of the flush order after the
 // single rounding to float32 in scd_kmeans_finalize.  No LDS, no partial slabs.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -24,10 +25,99 @@ __global__ void __launch_bounds__(256) mstep_keys_kernel(const int32_t* __restri
     keys[i] = (bucket << 32) | (unsigned long long)i;
 }
 
+// Counting sort by label (k + 1 buckets, bucket k = invalid labels) in three short kernels; rows of one label end up in
+// one run, in no particular order inside it (float64 sums do not depend on it after the single rounding to float32).
+// rocPRIM's radix_sort_keys took 9 launches / ~55 us for 95k keys (merge-sort path); this takes ~15 us.  The first kernel
+// also clears sums / counts / inertia (three memset launches fewer).
+#define MS_BLK 1024
+__global__ void __launch_bounds__(256) mstep_hist_kernel(const int32_t* __restrict__ labels, long long n, int k, int* __restrict__ hist,
+                                                         double* sums, long long nsum, unsigned long long* counts, double* inertia) {
+    extern __shared__ int lh[];
+    for (int i = threadIdx.x; i <= k; i += 256) lh[i] = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nsum; i += (long long)gridDim.x * 256) sums[i] = 0.0;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < k; i += 256) counts[i] = 0;
+        if (inertia && threadIdx.x < 2) inertia[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * MS_BLK;
+#pragma unroll
+    for (int u = 0; u < MS_BLK / 256; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const int l = labels[i];
+            atomicAdd(&lh[(l < 0 || l >= k) ? k : l], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= k; i += 256) hist[(size_t)blockIdx.x * (k + 1) + i] = lh[i];
+}
+// hist[b][l] -> (rows with label l in blocks before b), tot[l] = rows with label l.  One wave per label, lane = block
+// (wave-level exclusive scans over the blocks, 64 at a time).
+__global__ void __launch_bounds__(256) mstep_scan_kernel(int* __restrict__ hist, int nblk, int k, int* __restrict__ tot) {
+    const int kb = k + 1;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= kb) return;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const int c = b < nblk ? hist[(size_t)b * kb + l] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (b < nblk) hist[(size_t)b * kb + l] = carry + inc - c;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) tot[l] = carry;
+}
+// keys[offset of (block, label) + arrival order] = (label, row); every block first scans the label totals itself
+// (<= 8192 values: thread t owns a contiguous segment, thread 0 chains the 256 segment sums)
+__global__ void __launch_bounds__(256) mstep_scatter_kernel(const int32_t* __restrict__ labels, long long n, int k,
+                                                            const int* __restrict__ offs, const int* __restrict__ tot,
+                                                            unsigned long long* __restrict__ keys) {
+    extern __shared__ int cur[];
+    __shared__ int seg_sum[256];
+    const int kb = k + 1;
+    const int seg = (kb + 255) / 256;
+    const int l0 = threadIdx.x * seg, l1 = l0 + seg < kb ? l0 + seg : kb;
+    int sum = 0;
+    for (int l = l0; l < l1; ++l) sum += tot[l];
+    seg_sum[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int r = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int c = seg_sum[t];
+            seg_sum[t] = r;
+            r += c;
+        }
+    }
+    __syncthreads();
+    int run = seg_sum[threadIdx.x];
+    for (int l = l0; l < l1; ++l) {
+        cur[l] = run + offs[(size_t)blockIdx.x * kb + l];
+        run += tot[l];
+    }
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * MS_BLK;
+#pragma unroll
+    for (int u = 0; u < MS_BLK / 256; ++u) {
+        const long long i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const int l = labels[i];
+            const int b = (l < 0 || l >= k) ? k : l;
+            const int pos = atomicAdd(&cur[b], 1);
+            keys[pos] = ((unsigned long long)b << 32) | (unsigned long long)i;
+        }
+    }
+}
+
 // Lane owns columns lane, lane+64, ... (MAXG = ceil(d/64) <= 16): every load and every float64 atomic of a wave touches
 // 64 consecutive elements (256 B / 512 B contiguous).  ROWS sorted rows per wave.
-#define MSTEP_ROWS 32
-template <int MAXG>
+template <int MAXG, int MSTEP_ROWS, int MU>
 __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restrict__ X, const unsigned long long* __restrict__ keys,
                                                             const float* __restrict__ Cold, long long n, int d, int k,
                                                             long long split, double* __restrict__ sums,
@@ -52,13 +142,13 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
         }
     };
     // 4 rows per iteration: their keys and row slices are all loaded before the first one is consumed
-    for (long long sb = s0; sb < s1; sb += 4) {
-        unsigned long long key[4];
-        float xv[4][MAXG];
+    for (long long sb = s0; sb < s1; sb += MU) {
+        unsigned long long key[MU];
+        float xv[MU][MAXG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = sb + u < s1 ? keys[sb + u] : ~0ull;
+        for (int u = 0; u < MU; ++u) key[u] = sb + u < s1 ? keys[sb + u] : ~0ull;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
             // unconditional loads from clamped (always valid) addresses: a per-element "load or zero" branch would make
             // the compiler wait for every load separately; out-of-range lanes are masked when the value is used
             const bool live = (unsigned)(key[u] >> 32) < (unsigned)k;
@@ -71,7 +161,7 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
             const int l = (int)(key[u] >> 32);
             const long long row = (long long)(key[u] & 0xffffffffull);
             if ((unsigned)l >= (unsigned)k) continue;        // sentinel bucket (invalid labels) / past the end
@@ -122,18 +212,34 @@ extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* lab
     unsigned long long* k1 = (unsigned long long*)w; w += scd_align(8 * (size_t)n);
     void* temp = w;
     const size_t temp_avail = scd_align(24 * (size_t)n + (8u << 20));
-    SCD_HIP(hipMemsetAsync(sums, 0, 8 * (size_t)k * d, st));
-    SCD_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)k, st));
-    if (inertia) SCD_HIP(hipMemsetAsync(inertia, 0, 16, st));
-    mstep_keys_kernel<<<(unsigned)scd_cdiv(n, 256), 256, 0, st>>>(labels, n, k, k0);
-    int bits = 1;
-    while ((1ll << bits) <= k) ++bits;                       // buckets 0..k
-    size_t need = 0;
-    SCD_HIP(rocprim::radix_sort_keys(nullptr, need, k0, k1, (size_t)n, 32, 32 + bits, st));
-    SCD_REQUIRE(need <= temp_avail, "scd_kmeans_mstep: rocprim temp storage %zu > %zu", need, temp_avail);
-    SCD_HIP(rocprim::radix_sort_keys(temp, need, k0, k1, (size_t)n, 32, 32 + bits, st));
-    const unsigned grid = (unsigned)scd_cdiv(n, 4 * MSTEP_ROWS);
-#define MSTEP_LAUNCH(G) mstep_segment_kernel<G><<<grid, 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia)
+    const int nblk = (int)scd_cdiv(n, MS_BLK);
+    if (k <= 8191 && ((size_t)nblk + 1) * (k + 1) * 4 <= temp_avail) {
+        int* hist = (int*)temp;
+        int* tot = hist + (size_t)nblk * (k + 1);
+        const size_t lds = (size_t)(k + 1) * 4;
+        mstep_hist_kernel<<<nblk, 256, lds, st>>>(labels, n, k, hist, sums, (long long)k * d, (unsigned long long*)counts, inertia);
+        mstep_scan_kernel<<<(unsigned)scd_cdiv(k + 1, 4), 256, 0, st>>>(hist, nblk, k, tot);
+        mstep_scatter_kernel<<<nblk, 256, lds, st>>>(labels, n, k, hist, tot, k1);
+    } else {
+        SCD_HIP(hipMemsetAsync(sums, 0, 8 * (size_t)k * d, st));
+        SCD_HIP(hipMemsetAsync(counts, 0, 8 * (size_t)k, st));
+        if (inertia) SCD_HIP(hipMemsetAsync(inertia, 0, 16, st));
+        mstep_keys_kernel<<<(unsigned)scd_cdiv(n, 256), 256, 0, st>>>(labels, n, k, k0);
+        int bits = 1;
+        while ((1ll << bits) <= k) ++bits;                       // buckets 0..k
+        size_t need = 0;
+        SCD_HIP(rocprim::radix_sort_keys(nullptr, need, k0, k1, (size_t)n, 32, 32 + bits, st));
+        SCD_REQUIRE(need <= temp_avail, "scd_kmeans_mstep: rocprim temp storage %zu > %zu", need, temp_avail);
+        SCD_HIP(rocprim::radix_sort_keys(temp, need, k0, k1, (size_t)n, 32, 32 + bits, st));
+    }
+    static const int ms_var = getenv("SCD_MSTEP_VAR") ? atoi(getenv("SCD_MSTEP_VAR")) : 3;      // rows per wave / rows in flight: 3 = 64/8 (default), 1 = 64/4, 2 = 32/8, 0 = 32/4
+#define MSTEP_LAUNCH(G)                                                                                                      \
+    do {                                                                                                                     \
+        if (ms_var == 1) mstep_segment_kernel<G, 64, 4><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+        else if (ms_var == 2) mstep_segment_kernel<G, 32, 8><<<(unsigned)scd_cdiv(n, 4 * 32), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+        else if (ms_var == 3) mstep_segment_kernel<G, 64, 8><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+        else mstep_segment_kernel<G, 32, 4><<<(unsigned)scd_cdiv(n, 4 * 32), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+    } while (0)
     if (d <= 64) MSTEP_LAUNCH(1);
     else if (d <= 128) MSTEP_LAUNCH(2);
     else if (d <= 256) MSTEP_LAUNCH(4);
