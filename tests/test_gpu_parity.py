@@ -127,6 +127,63 @@ def test_estep_nan_centre_never_wins(ops):
     assert np.array_equal(lab, olab) and 2 not in set(lab.tolist())
 
 
+@pytest.mark.parametrize("n,d,k,seed", [(31, 16, 3, 11), (33, 200, 128, 12), (1000, 300, 1, 13), (2049, 512, 64, 14), (777, 640, 128, 15),
+                                        (5000, 768, 128, 16), (1025, 100, 129, 17), (600, 896, 50, 18)])
+def test_estep_stream_kernel_shapes(ops, n, d, k, seed):
+    """Every column-chunk count of estep_stream_kernel (D <= 768: 1..6 x 128), K = 1 / 128, ragged last 32-row unit, and the
+    shapes just outside it (K = 129, D = 896: estep_mfma_kernel); centres are data points, so rows with distance 0 and
+    many small margins (both refine lists) occur."""
+    x, y, cent = synth.clustered_features(n, d, max(2, min(k, 20)), seed=seed, center_seed=seed + 7, noise=0.9)
+    rs = np.random.RandomState(seed)
+    c = x[rs.choice(n, k, replace=k > n)].copy()
+    data = ops.KMeansData(dev(x))
+    lab, ref = data.estep(dev(c), return_refined=True)
+    olab, omind, _ = ko.estep(x, c)
+    assert np.array_equal(lab.cpu().numpy().astype(np.int64), olab)
+    assert np.array_equal(data.rowdist(dev(c), lab).cpu().numpy(), omind)
+
+
+def test_estep_stream_kernel_many_units_per_block(ops):
+    """n above 256 blocks x 24 units x 32 rows: the grid grows beyond one block per CU (rows-per-block cap)."""
+    n, d, k = 200003, 64, 16
+    x, y, cent = synth.clustered_features(n, d, k, seed=31, center_seed=32, noise=0.7)
+    data = ops.KMeansData(dev(x))
+    lab = data.estep(dev(cent)).cpu().numpy()
+    assert (lab == y).mean() > 0.99
+    rows = np.random.RandomState(1).choice(n, 2048, replace=False)
+    rows[:4] = [0, 31, n - 1, n - 33]
+    olab, _, _ = ko.estep(x[rows], cent)
+    assert np.array_equal(lab[rows], olab)
+
+
+def test_estep_non_finite_rows_fall_back_to_exact(ops):
+    x, y, cent = synth.clustered_features(700, 96, 7, seed=41)
+    x[13, 5] = np.nan
+    x[200, :] = np.inf
+    lab = ops.KMeansData(dev(x)).estep(dev(cent)).cpu().numpy()
+    olab, _, _ = ko.estep(x, cent)
+    good = np.ones(700, bool); good[[13, 200]] = False
+    assert np.array_equal(lab[good], olab[good])
+    assert 0 <= lab[13] < 7 and 0 <= lab[200] < 7
+
+
+@pytest.mark.parametrize("n,d,k", [(1, 8, 1), (1023, 64, 1), (1025, 48, 1000), (3000, 20, 9000), (4096, 768, 3)])
+def test_mstep_counting_sort_edges(ops, n, d, k):
+    """mstep_hist / scan / scatter: one block, k = 1, more labels than rows, the rocPRIM path (k > 8191), invalid labels."""
+    rs = np.random.RandomState(n + k)
+    x = rs.randn(n, d).astype(np.float32)
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    if n > 10:
+        labels[3] = -1                                            # invalid labels are ignored
+        labels[7] = k
+    sums, counts, _ = ops.kmeans_mstep(dev(x), dev(labels), None, k, 0)
+    ok = (labels >= 0) & (labels < k)
+    ref = np.zeros((k, d), np.float64)
+    np.add.at(ref, labels[ok], x[ok].astype(np.float64))
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(labels[ok], minlength=k))
+    assert np.allclose(sums.cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+
+
 def test_dist_and_costs(ops):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kmeans_sskm.npz"))
     a, b = g["pd_a"], g["pd_b"]
