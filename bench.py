@@ -134,6 +134,15 @@ def main():
     model, _ = clip.load("ViT-B/16", device="cuda")
     images, y, base = pipeline.synthetic_images(args.images, N_CLASSES, seed=rank, device=dev)
     wt, nouns = pipeline.synthetic_vocab(model, base, args.vocab, 0, dev)
+    if world > 1:
+        # the open-vocabulary part of W is a real, SHARDED text-tower build: every rank encodes its contiguous range of
+        # names (2 prompts each) and one RCCL all-gather assembles the [512, V] classifier on all ranks (setup, untimed);
+        # the first N_CLASSES rows keep the planted prototypes so that the name accuracy stays meaningful
+        from scd_amd.local_utils import clip_lang_util as clu
+        w_text = clu.zeroshot_classifier_sharded(nouns, ["a photo of a {}.", "a {}."], model, group, names_per_batch=256)
+        wt_text = w_text.t().contiguous()
+        wt_text[:N_CLASSES] = wt[:N_CLASSES]
+        wt = wt_text
     mask_lab = pipeline.labelled_split(y, N_CLASSES, seed=5 + rank)
     l_targets = y[torch.as_tensor(mask_lab, device=dev)]
 

@@ -564,11 +564,35 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
         mya = cand_val[img * 2 * TOPM + lane];
     }
     double mye = -INFINITY;
-    for (int c = 0; c < 2 * TOPM; ++c) {
-        const int ci = __shfl(myi, c, 64);
-        if (ci < 0) continue;                                   // wave-uniform
-        const double e = (double)scale * dot64(f, Wt + (long long)ci * d, d, lane);
-        if (lane == c) mye = e;
+    if (d <= 512) {
+        // all 16 candidate rows are requested before the first is consumed (a loop with one load per iteration paid one
+        // L2 latency per candidate); lane l owns columns 8l .. 8l+7 of the image row and of every candidate row
+        half8 fv, wv[2 * TOPM];
+        const bool act = lane * 8 < d;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fv[q] = (half_t)0.f;
+        if (act) fv = *(const half8*)(f + lane * 8);
+#pragma unroll
+        for (int c = 0; c < 2 * TOPM; ++c) {
+            const int ci = __shfl(myi, c, 64);
+            wv[c] = fv;
+            if (act && ci >= 0) wv[c] = *(const half8*)(Wt + (long long)ci * d + lane * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * TOPM; ++c) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sacc = fma((double)(float)fv[q], (double)(float)wv[c][q], sacc);
+            const double e = (double)scale * wave_sum_f64(act ? sacc : 0.0);
+            if (lane == c && myi >= 0) mye = e;
+        }
+    } else {
+        for (int c = 0; c < 2 * TOPM; ++c) {
+            const int ci = __shfl(myi, c, 64);
+            if (ci < 0) continue;                                   // wave-uniform
+            const double e = (double)scale * dot64(f, Wt + (long long)ci * d, d, lane);
+            if (lane == c) mye = e;
+        }
     }
     // rank of each candidate among the 16: (value desc, index asc)
     int rank = 0;

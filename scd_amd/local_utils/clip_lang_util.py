@@ -111,6 +111,34 @@ def zeroshot_classifier(classnames, templates, model, names_per_batch=16):
     return out
 
 
+def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_batch=16, build=None):
+    """The vocabulary sharded over the ranks of `group` (one process per GPU): rank r builds the classifier columns of the
+    contiguous name range [r*ceil(n/W), (r+1)*ceil(n/W)) with `zeroshot_classifier`, then ONE all-gather (RCCL over xGMI;
+    name-major rows, the short last shard padded) gives every rank the full [embed_dim, n_names] matrix in the original
+    name order.  Not in the reference (it has no multi-GPU path): BASELINE config 5, 100k names x 80 prompts = 8 M text
+    forward passes, is the largest compute item once the vocabulary is open, and it shards without any other exchange.
+    `build(names, templates, model, names_per_batch)` defaults to zeroshot_classifier (a hook for the CPU gloo test)."""
+    import torch.distributed as dist
+    build = build or zeroshot_classifier
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = len(classnames)
+    per = (n + world - 1) // world
+    mine = classnames[rank * per:(rank + 1) * per]
+    local = build(mine, templates, model, names_per_batch) if len(mine) else None          # [D, n_mine]
+    dev = local.device if local is not None else torch.device("cpu")
+    dvec = torch.tensor([0 if local is None else local.shape[0]], dtype=torch.int64, device=dev)
+    dims = [torch.empty_like(dvec) for _ in range(world)]
+    dist.all_gather(dims, dvec, group=group)
+    dim = max(int(x) for x in dims)
+    dtype = local.dtype if local is not None else torch.float16
+    pad = torch.zeros((per, dim), dtype=dtype, device=dev)
+    if local is not None:
+        pad[: local.shape[1]] = local.t()
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat(parts, dim=0)[:n].t().contiguous()
+
+
 def _data_file(name):
     for root in (os.environ.get("SCD_DATA", ""), os.path.join(os.environ.get("SCD_ROOT", ""), "data")):
         p = os.path.join(root, name)

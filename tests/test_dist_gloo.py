@@ -84,3 +84,42 @@ def test_sharded_constrained_respects_global_bounds():
     cnt = np.bincount(lab_u, minlength=6)
     assert cnt.min() >= 60 and cnt.max() <= 200 and cnt.sum() == 900 - n_l
     assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+def _vocab_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scd_amd.local_utils import clip_lang_util as clu
+        names = ["name_%03d" % i for i in range(37)]                 # 37 names over 2 ranks: shards of 19 and 18
+        w = clu.zeroshot_classifier_sharded(names, ["a {}.", "the {}."], None, dist.group.WORLD, build=_stub_build)
+        q.put((rank, w.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _stub_build(names, templates, model, names_per_batch):
+    """CPU stand-in for zeroshot_classifier: a deterministic unit column per name, [8, n]."""
+    cols = []
+    for nme in names:
+        rs = np.random.RandomState(int(nme.split("_")[1]) + 1000 * len(templates))
+        v = rs.randn(8).astype(np.float32)
+        cols.append(v / np.linalg.norm(v))
+    return torch.from_numpy(np.stack(cols, axis=1)).to(torch.float16)
+
+
+def test_sharded_vocabulary_allgather_keeps_name_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_vocab_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    names = ["name_%03d" % i for i in range(37)]
+    ref = _stub_build(names, ["a {}.", "the {}."], None, 16).numpy()
+    assert res[0].shape == (8, 37) and np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
