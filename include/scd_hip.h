@@ -60,12 +60,15 @@ int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t_per, int d
                     void* stream);
 
 /* ---- K-Means: local_utils/sskm_constrained.py, gcd/methods/clustering/faster_mix_k_means_pytorch.py ---- */
-/* one-off per data set: centred, power-of-two scaled fp16 copy of X and its row norms (E-step operand) */
+/* one-off per data set: centred, power-of-two scaled fp16 copy of X and its row norms (E-step operand).  The copy carries
+ * 32 rows of padding behind row n-1 (the streaming E-step reads whole 32-row units); prep must hold
+ * scd_kmeans_prep_bytes(n, d) bytes.  X and C must be 16-byte aligned (float4 loads when d % 4 == 0). */
 size_t scd_kmeans_prep_bytes(int64_t n, int d);
 int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* prep, void* stream);
 /* E-step: labels[i] = argmin_k ||x_i - c_k||^2, ties -> lowest k, decided on float64 values
  * (torch.min(dist,1) faster_mix_k_means_pytorch.py:140,192).  refine_rows_out (device int32, may be NULL)
- * receives the number of rows re-evaluated exactly. */
+ * receives the number of rows re-evaluated exactly.  K <= 128 and D <= 768 take the single-pass streaming filter
+ * (3 launches: centre prep, filter, refine), larger shapes the tiled one; the result is the same by construction. */
 size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k);
 int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                      int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream);
