@@ -27,11 +27,15 @@ extern "C" int scd_create(int device, scd_handle* out) {
     scd_ctx* c = new scd_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
+    c->scratch = nullptr;
+    SCD_HIP(hipMalloc(&c->scratch, SCD_SCRATCH_BYTES));
+    SCD_HIP(hipMemset(c->scratch, 0, SCD_SCRATCH_BYTES));
     *out = c;
     return SCD_OK;
 }
 
 extern "C" int scd_destroy(scd_handle h) {
+    if (h && h->scratch) hipFree(h->scratch);
     delete h;
     return SCD_OK;
 }

@@ -10,7 +10,9 @@
 struct scd_ctx {
     int device;
     int n_cu;
+    void* scratch;          // 256 KB + 64 B of device memory, zero at creation: per-centre partials + ticket of scd_kmeans_finalize
 };
+#define SCD_SCRATCH_BYTES (262144 + 64)
 
 void scd_set_error(const char* fmt, ...);
 

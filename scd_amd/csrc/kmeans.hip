@@ -982,32 +982,42 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
 
 // (M-step partial sums: see mstep.hip)
 
-// centres = sums / counts; shift = (sum_k ||c_k - c_old_k||)^2.  Single block, fixed reduction order.
-__global__ void __launch_bounds__(1024) finalize_kernel(const double* sums, const long long* counts, int k, int d,
-                                                        const float* Cold, float* Cout, double* shift) {
-    __shared__ double wred[16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double tot = 0.0;
-    for (int c = wave; c < k; c += 16) {
-        const double cnt = (double)counts[c];
-        double ss = 0.0;
-        for (int j = lane; j < d; j += 64) {
-            const float v = (float)(sums[(size_t)c * d + j] / cnt);     // 0/0 -> NaN for an empty cluster
-            Cout[(size_t)c * d + j] = v;
-            if (Cold) {
-                const double df = (double)v - (double)Cold[(size_t)c * d + j];
-                ss = fma(df, df, ss);
-            }
+// centres = sums / counts; shift = (sum_k ||c_k - c_old_k||)^2.  One block per centre; the per-centre norms go to a scratch
+// array and the LAST block to arrive (ticket) adds them in index order, so the float64 result does not depend on the
+// arrival order.  (A single 1024-thread block took 31 us for K x D = 77k values.)  The scratch belongs to the handle: one
+// finalize in flight per handle.
+__global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const long long* counts, int k, int d,
+                                                       const float* Cold, float* Cout, double* shift, double* part,
+                                                       unsigned* ticket) {
+    __shared__ double wred[4];
+    __shared__ bool last;
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double cnt = (double)counts[c];
+    double ss = 0.0;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float v = (float)(sums[(size_t)c * d + j] / cnt);     // 0/0 -> NaN for an empty cluster
+        Cout[(size_t)c * d + j] = v;
+        if (Cold) {
+            const double df = (double)v - (double)Cold[(size_t)c * d + j];
+            ss = fma(df, df, ss);
         }
-        ss = wave_sum_f64(ss);
-        tot += sqrt(ss);
     }
-    if (lane == 0) wred[wave] = tot;
+    if (!shift) return;
+    ss = wave_sum_f64(ss);
+    if (lane == 0) wred[wave] = ss;
     __syncthreads();
-    if (threadIdx.x == 0 && shift) {
+    if (threadIdx.x == 0) {
+        part[c] = sqrt((wred[0] + wred[1]) + (wred[2] + wred[3]));
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)k - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
         double t = 0.0;
-        for (int i = 0; i < 16; ++i) t += wred[i];
+        for (int i = 0; i < k; ++i) t += ((volatile double*)part)[i];
         *shift = t * t;
+        *ticket = 0;
     }
 }
 
@@ -1015,7 +1025,9 @@ extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64
                                    const float* C_old, float* C_out, double* shift_out, void* stream_) {
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
-    finalize_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out);
+    SCD_REQUIRE(k <= 32768, "scd_kmeans_finalize: k=%d > 32768", k);
+    finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
+                                                         (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144));
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
