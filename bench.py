@@ -113,6 +113,47 @@ def dominant_kernel_roofline(ms, launches, flop):
             "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
 
+def secondary_rooflines(out, wt, dev):
+    """Call-level rates of the two other kernels north_star names, measured after the timed region on this run's own
+    tensors (HIP events on the current stream, 20 calls each): the similarity + top-k call (MFMA-bound) and one k-means
+    E-step call (HBM-bound: centre prep + streaming filter + refine launch).  Informational; `roofline` above stays the
+    dominant kernel of the metric."""
+    import torch
+    from scd_amd import ops
+    res = []
+
+    def timeit(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    feats = out["feats"]
+    n, d = feats.shape
+    v = wt.shape[0]
+    t = timeit(lambda: ops.sim_topk(feats, wt, 3, "softmax"), 5)
+    fl = 2.0 * n * v * d
+    res.append({"kernel": "scd_sim_topk call (sim_topk_kernel + refine), %d x %d x %d" % (n, v, d), "bound": "mfma",
+                "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4),
+                "call_us": round(t * 1e6, 1)})
+    x = feats.float()
+    c = out["kmeans"].cluster_centers_.to(torch.float32).contiguous()
+    k = int(c.shape[0])
+    data = ops.KMeansData(x)
+    t = timeit(lambda: data.estep(c))
+    dp = (d + 127) // 128 * 128
+    by = n * dp * 2 + 4 * n + 128 * dp * 2
+    res.append({"kernel": "scd_kmeans_estep call (prep_centers + estep_stream_kernel + refine), N=%d D=%d K=%d" % (n, d, k),
+                "bound": "hbm", "achieved": round(by / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / t / 8e12, 4),
+                "call_us": round(t * 1e6, 1)})
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,6 +245,7 @@ def main():
             "vote_iters": out["vote_iters"], "synthetic_name_accuracy": round(name_hits, 4),
             "roofline": roof,
         }
+        line["secondary_rooflines"] = secondary_rooflines(out, wt, dev)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
