@@ -157,7 +157,11 @@ class KMeansEngine:
         labels = be.estep(data, C)
         d2 = be.rowdist(data, C, labels)
         picks = []
-        while C.shape[0] < k:
+        m = C.shape[0]
+        if m < k:                                    # centres are appended in place (a torch.cat per centre re-copied all of C)
+            buf = torch.empty((k, x.shape[1]), dtype=torch.float32, device=x.device)
+            buf[:m] = C
+        while m < k:
             r = rs.rand()
             if dd is None:
                 idx, _ = be.kpp_draw(d2, r)
@@ -176,8 +180,10 @@ class KMeansEngine:
                 row = x.index_select(0, idx.clamp(min=0)).reshape(1, -1).contiguous()
                 if owner >= 0:
                     dd.broadcast_(row, owner)
-            C = torch.cat((C, row), dim=0)
-            be.min_update(data, row.reshape(-1), d2)
+            buf[m] = row.reshape(-1)
+            m += 1
+            C = buf[:m]
+            be.min_update(data, buf[m - 1], d2)
         if picks and bool((torch.cat([p.reshape(-1) for p in picks]) < 0).any()):
             # the reference indexes an empty nonzero() here (sskm_constrained.py:42)
             raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
