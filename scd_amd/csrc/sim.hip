@@ -61,7 +61,7 @@ template <bool SOFTMAX, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) sim_topk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
                                                           long long n, int d, long long v, float scale,
                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                          float* __restrict__ stats) {
+                                                          float* __restrict__ stats, int xmode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // 4 x 16 KB ring + 8 x 4 KB parked fragments
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) sim_topk_kernel(cons
         for (int cb = 0; cb < 4; ++cb) f[cb] = *(const half8*)(slot + off128(cb * 32 + r, 2 * k16 + hh));
     };
     auto mm = [&](const half8 (&f)[4], const half8 b) {
+        if (xmode & 2) return;                               // timing ablation: no MFMAs
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[cb], b, acc[cb], 0, 0, 0);
@@ -217,6 +218,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) sim_topk_kernel(cons
             }
             float qv = -INFINITY;
             int qi = -1;
+            if ((xmode & 1) && !last) thr = INFINITY;        // timing ablation: nothing is admitted (results are wrong)
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 if (last) {
@@ -773,13 +775,13 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else if (mode == SCD_SIM_SOFTMAX) {
-        if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
-        else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
+        else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else {
-        if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
-        else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats);
+        if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
+        else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     }
