@@ -64,8 +64,8 @@ def main():
     lab_names = [gt_names[c] for c in train_classes]
 
     def report(it, cand, u_preds):
-        sacc = float(np.mean([gt_names[int(t)] == cand[int(pp)] for t, pp in zip(u_targets, u_preds)]))
-        print(f"iter {it}: sACC_all {round(sacc * 100, 2)} with {len(cand)} candidate names")
+        sacc_avg, sacc = naming.evaluate_semantic_acc(u_targets, gt_names, u_preds, cand)
+        print(f"iter {it}: sACC_avg {round(sacc_avg * 100, 2)} | sACC_all {round(sacc * 100, 2)} with {len(cand)} candidate names")
 
     cand, u_preds, trace = naming.vote_loop_ptsup(name_idx[m], all_preds, mask_lab, clip_all[m], wt, nouns, lab_names, k,
                                                   args.topk, args.num_common_vote, args.num_common_linear, on_iter=report)

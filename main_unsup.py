@@ -55,6 +55,8 @@ def build_parser():
     p.add_argument('--synthetic', type=str2bool, default=False, help='seeded synthetic images / vocabulary')
     p.add_argument('--synthetic_images', type=int, default=8192)
     p.add_argument('--synthetic_vocab', type=int, default=21000)
+    p.add_argument('--class_names', type=str, default='', help='JSON file {class index: class name} of the data set (the '
+                   'reference takes it from its dataset objects, which are out of scope here): enables sACC on cached features')
     return p
 
 
@@ -104,6 +106,10 @@ def main():
         zw = torch.load(os.path.join(args.root_dir, 'zeroshot_weights', f'zeroshot_weights_all_{zname}_vit_b_16.pt'))
         wt = ops.transpose_f16(zw.to(dev).half())
         cidx_to_cname = None
+        if args.class_names:
+            import json
+            with open(args.class_names) as fh:
+                cidx_to_cname = {int(k): v for k, v in json.load(fh).items()}
     mask_lab = np.asarray(mask_lab, dtype=bool)
     l_feats, u_feats = all_feats[mask_lab], all_feats[~mask_lab]
     l_targets, u_targets = targets[mask_lab], targets[~mask_lab]
@@ -132,8 +138,8 @@ def main():
         a, o, n = split_cluster_acc_v2(y_true=u_targets, y_pred=u_preds, mask=mask)
         line = f"iter {it}: ACC All {round(a * 100, 2)} | Old {round(o * 100, 2)} | New {round(n * 100, 2)}"
         if cidx_to_cname is not None:
-            sacc = float(np.mean([cidx_to_cname[int(t)] == cand[int(p)] for t, p in zip(u_targets, u_preds)]))
-            line += f" | sACC_all {round(sacc * 100, 2)}"
+            sacc_avg, sacc_all = naming.evaluate_semantic_acc(u_targets, cidx_to_cname, u_preds, cand)
+            line += f" | sACC_avg {round(sacc_avg * 100, 2)} | sACC_all {round(sacc_all * 100, 2)}"
         print(line)
 
     cand, u_preds, trace = naming.vote_loop_unsup(name_idx[m], preds, clip_all[m], wt, nouns, args.n_cluster,

@@ -111,3 +111,25 @@ def vote_loop_ptsup(name_idx, all_preds, mask_lab, clip_u_feats, wt, nouns, lab_
         if on_iter:
             on_iter(len(trace), cand, trace[-1]["u_preds"])
     return cand, (trace[-1]["u_preds"] if trace else u_preds.cpu().numpy()), trace
+
+
+def evaluate_semantic_acc(u_targets, cidx_to_cname, u_preds, cand_names):
+    """main_unsup.py:149-167 (same signature and return value): sACC = fraction of unlabelled rows whose ground-truth class
+    NAME equals the name voted for their cluster, as (average over the class names that occur, overall).  The reference
+    loops over the rows in Python; here names are interned once and the rest is two bincounts."""
+    import numpy as np
+    t = np.asarray(u_targets).astype(np.int64).reshape(-1)
+    p = np.asarray(u_preds.cpu() if hasattr(u_preds, "cpu") else u_preds).astype(np.int64).reshape(-1)
+    classes = np.unique(t)
+    intern = {}
+    def nid(name):
+        return intern.setdefault(name, len(intern))
+    tname = np.array([nid(cidx_to_cname[int(c)]) for c in classes], dtype=np.int64)          # per class
+    cname = np.array([nid(n) for n in cand_names], dtype=np.int64)                           # per cluster
+    row_name = tname[np.searchsorted(classes, t)]
+    hit = (row_name == cname[p]).astype(np.float64)
+    # two classes may share a name: the reference keys its per-class lists by NAME
+    tot = np.bincount(row_name, minlength=len(intern)).astype(np.float64)
+    hits = np.bincount(row_name, weights=hit, minlength=len(intern))
+    present = tot > 0
+    return float((hits[present] / tot[present]).sum() / present.sum()), float(hit.sum() / len(hit))

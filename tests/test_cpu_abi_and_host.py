@@ -157,3 +157,21 @@ def test_c_oracle_matches_numpy_oracle():
     lib.oracle_sim_topk(P(f), P(wt), C.c_int64(50), 64, C.c_int64(333), C.c_double(100.0), 5, P(idx), P(val))
     oi, ov = no.sim_topk(f, w, 5, "raw")
     assert np.array_equal(idx, oi) and np.allclose(val, ov, rtol=1e-6)
+
+
+def test_evaluate_semantic_acc_matches_reference_restatement():
+    """scd_amd.naming.evaluate_semantic_acc (vectorised) against the loop of main_unsup.py:149-167 restated in the oracle,
+    including two classes that share one name and clusters voted the same name."""
+    from oracle import naming_oracle as no
+    from scd_amd import naming
+    rs = np.random.RandomState(5)
+    n_cls, n_clu = 17, 11
+    names = ["n%02d" % (i % 13) for i in range(n_cls)]              # classes 13..16 reuse names of 0..3
+    cidx_to_cname = {c + 100: names[c] for c in range(n_cls)}        # class ids need not be 0..C-1
+    cand = ["n%02d" % rs.randint(0, 15) for _ in range(n_clu)]
+    t = rs.randint(0, n_cls, size=4000) + 100
+    t = t[t != 105]                                                  # a class that never occurs
+    p = rs.randint(0, n_clu, size=len(t))
+    ref = no.evaluate_semantic_acc(t.astype(np.float64), cidx_to_cname, p, cand)
+    got = naming.evaluate_semantic_acc(t.astype(np.float64), cidx_to_cname, p, cand)
+    assert got[0] == pytest.approx(ref[0], rel=1e-12) and got[1] == pytest.approx(ref[1], rel=1e-12)
