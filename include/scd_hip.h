@@ -67,8 +67,8 @@ size_t scd_kmeans_prep_bytes(int64_t n, int d);
 int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* prep, void* stream);
 /* E-step: labels[i] = argmin_k ||x_i - c_k||^2, ties -> lowest k, decided on float64 values
  * (torch.min(dist,1) faster_mix_k_means_pytorch.py:140,192).  refine_rows_out (device int32, may be NULL)
- * receives the number of rows re-evaluated exactly.  K <= 128 and D <= 768 take the single-pass streaming filter
- * (3 launches: centre prep, filter, refine), larger shapes the tiled one; the result is the same by construction. */
+ * receives the number of rows re-evaluated exactly.  D <= 768 and K <= 2048 take the streaming filter (centre prep, one
+ * filter launch per 128 centres, refine), larger shapes the tiled one; the result is the same by construction. */
 size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k);
 int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                      int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream);

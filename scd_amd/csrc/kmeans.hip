@@ -113,6 +113,7 @@ extern "C" int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d
 // ------------------------------------------------------------------------------------------------
 // E-step workspace:  [0,64) EHdr | cn float[Kp] | ch half[Kp*Dp] | ct float[Dp*Kp] (centres transposed, exact)
 //                       | pair list int32[n] | pair candidates int32[n] | full list int32[n] | chf half[Kp*Dp] (fragment order)
+//                       | tkey float[3n] | tidx int32[3n] (multi-pass streaming filter, K > 128)
 struct EHdr {
     unsigned cmax_bits;   // max ||c'||
     int flag_cnt;         // rows whose exact argmin is among two known candidates
@@ -123,7 +124,7 @@ static inline int kpad(int k) { return (k + 127) / 128 * 128; }
 
 extern "C" size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k) {
     size_t kp = kpad(k), dp = dpad(d);
-    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * kp * dp) + 3 * scd_align(4 * (size_t)n) + scd_align(2 * kp * dp) + 256;
+    return 64 + scd_align(4 * kp) + scd_align(2 * kp * dp) + scd_align(4 * kp * dp) + 3 * scd_align(4 * (size_t)n) + scd_align(2 * kp * dp) + 2 * scd_align(12 * (size_t)n) + 256;
 }
 
 // one block per (padded) centre: c' = (c-mu)*scale -> fp16; cn = ||c'||^2 (float64 -> float32)
@@ -332,7 +333,12 @@ template <int NCH>
 __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
                                                            const half_t* __restrict__ ch, const float* __restrict__ cn,
                                                            EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
-                                                           long long n, int32_t* __restrict__ labels, int dbg) {
+                                                           long long n, int32_t* __restrict__ labels, int dbg, int cbase,
+                                                           int pass, float* __restrict__ tkey, int* __restrict__ tidx,
+                                                           const float* __restrict__ cn_all, int kp_all) {
+    // K > 128 runs one launch per 128-centre chunk (`ch` / `cn` point at the chunk, cbase = its first centre): every pass but
+    // the last leaves each row's three smallest (key, centre) pairs in tkey / tidx [3][n], every pass but the first merges
+    // them in; the last pass (pass & 2) takes the decisions.  pass = 1 first | 2 last.
     constexpr int DP = NCH * 128;
     constexpr int NSLOT = NCH >= 5 ? 3 : 4;
     constexpr int SLOTB = 8192 * NCH;                 // one unit: 32 rows x DP fp16
@@ -535,12 +541,11 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
 
     // decisions for all rows of the block
     float cm2 = 0.f;
-    {
-        const float v0 = cnl[lane], v1 = cnl[lane + 64];
-        if (v0 < 3.0e38f) cm2 = v0;
-        if (v1 < 3.0e38f) cm2 = fmaxf(cm2, v1);
-        cm2 = wave_max_f32(cm2);
+    for (int c = lane; c < kp_all; c += 64) {
+        const float v = cn_all[c];
+        if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
     }
+    cm2 = wave_max_f32(cm2);
     const float cmax = sqrtf(cm2) * 1.0000002f;
     const float sq = sqrtf((float)DP);
     // |s~ - s| <= A*||x'|| + B (see estep_mfma_kernel) + the key's low 7 bits: 2^-16 * (||c'||^2 + 2 ||x'|| ||c'||)
@@ -554,8 +559,33 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         const int p = tid + 256 * j;
         const long long point = (bid + (long long)(p >> 5) * G) * 32 + (p & 31);
         if (p >= nu * 32 || point >= n) continue;
-        const float m0 = res[p], m1 = res[ES_RMAX + p], m2 = res[2 * ES_RMAX + p];
-        const int j0 = (int)(__float_as_uint(m0) & 127u), j1 = (int)(__float_as_uint(m1) & 127u);
+        float m0 = res[p], m1 = res[ES_RMAX + p], m2 = res[2 * ES_RMAX + p];
+        int j0 = cbase + (int)(__float_as_uint(m0) & 127u), j1 = cbase + (int)(__float_as_uint(m1) & 127u),
+            j2 = cbase + (int)(__float_as_uint(m2) & 127u);
+        if (!(pass & 1)) {                 // merge the triple of the earlier chunks (ascending; ties keep the earlier chunk)
+            float pv[3];
+            int pi[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { pv[q] = tkey[(size_t)q * n + point]; pi[q] = tidx[(size_t)q * n + point]; }
+            float a0 = pv[0], a1 = pv[1], a2 = pv[2];
+            int i0 = pi[0], i1 = pi[1], i2 = pi[2];
+            const float nv[3] = {m0, m1, m2};
+            const int ni[3] = {j0, j1, j2};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (nv[q] < a2) {
+                    a2 = nv[q]; i2 = ni[q];
+                    if (a2 < a1) { const float tv = a1; a1 = a2; a2 = tv; const int ti = i1; i1 = i2; i2 = ti; }
+                    if (a1 < a0) { const float tv = a0; a0 = a1; a1 = tv; const int ti = i0; i0 = i1; i1 = ti; }
+                }
+            }
+            m0 = a0; m1 = a1; m2 = a2; j0 = i0; j1 = i1; j2 = i2;
+        }
+        if (!(pass & 2)) {
+            tkey[point] = m0; tkey[(size_t)n + point] = m1; tkey[2 * (size_t)n + point] = m2;
+            tidx[point] = j0; tidx[(size_t)n + point] = j1; tidx[2 * (size_t)n + point] = j2;
+            continue;
+        }
         labels[point] = j0;
         const float E = A * xn_r[j] + B;
         if (!(m1 - m0 > 2.0f * E)) {       // also catches NaN
@@ -832,13 +862,15 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     int* fcand = (int*)((char*)flags + scd_align(4 * (size_t)n));
     int* fulls = (int*)((char*)fcand + scd_align(4 * (size_t)n));
     half_t* chf = (half_t*)((char*)fulls + scd_align(4 * (size_t)n));       // centres in MFMA-fragment order (streaming path)
+    float* tkey = (float*)((char*)chf + scd_align(2 * (size_t)kp * dp));    // [3][n] keys / centres between the passes of K > 128
+    int* tidx = (int*)((char*)tkey + scd_align(12 * (size_t)n));
     const char* p = (const char*)prep;
     const PrepHdr* ph = (const PrepHdr*)p;
     const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
     const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
     static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
-    if (use_stream && kp == 128 && dp <= 768) {
-        // streaming filter (K <= 128, D <= 768): 3 launches, no memset
+    if (use_stream && kp <= 2048 && dp <= 768) {
+        // streaming filter (D <= 768): centre prep, one filter launch per 128 centres, refine; no memset
         prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
         const long long g32 = (n + 31) / 32;               // units of 32 rows
         long long grid = g32 < h->n_cu ? g32 : h->n_cu;
@@ -853,7 +885,10 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             SCD_HIP(hipFuncSetAttribute((const void*)estep_stream_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS)); \
             attr_set = true;                                                                                                 \
         }                                                                                                                    \
-        estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, chf, cn, eh, flags, fcand, fulls, n, labels_out, es_dbg); \
+        for (int cb = 0; cb < kp / 128; ++cb)                                                                                \
+            estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, chf + (size_t)cb * 128 * dp, cn + cb * 128, eh, flags, fcand, \
+                                                                          fulls, n, labels_out, es_dbg, cb * 128,           \
+                                                                          (cb == 0 ? 1 : 0) | (cb == kp / 128 - 1 ? 2 : 0), tkey, tidx, cn, kp); \
     } break;
         switch (dp / 128) {
             ES_LAUNCH(1) ES_LAUNCH(2) ES_LAUNCH(3) ES_LAUNCH(4) ES_LAUNCH(5) ES_LAUNCH(6)
@@ -1012,12 +1047,21 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
         last = atomicAdd(ticket, 1u) == (unsigned)k - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
+    if (last) {                                   // fixed order: thread t adds part[t], part[t+256], ...; then a fixed tree
+        __shared__ double tred[256];
         __threadfence();
         double t = 0.0;
-        for (int i = 0; i < k; ++i) t += ((volatile double*)part)[i];
-        *shift = t * t;
-        *ticket = 0;
+        for (int i = threadIdx.x; i < k; i += 256) t += ((volatile double*)part)[i];
+        tred[threadIdx.x] = t;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) tred[threadIdx.x] += tred[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            *shift = tred[0] * tred[0];
+            *ticket = 0;
+        }
     }
 }
 

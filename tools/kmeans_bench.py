@@ -23,7 +23,7 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 if __name__ == "__main__":
-    n, d, k = int(sys.argv[3]) if len(sys.argv) > 3 else 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, 100
+    n, d, k = int(sys.argv[3]) if len(sys.argv) > 3 else 95000, int(sys.argv[1]) if len(sys.argv) > 1 else 768, int(sys.argv[4]) if len(sys.argv) > 4 else 100
     noise = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
     x, y, cent = clustered_features(n, d, k, seed=21, center_seed=22, noise=noise)
     X = torch.from_numpy(x).cuda(); C = torch.from_numpy(cent).cuda()
@@ -33,7 +33,7 @@ if __name__ == "__main__":
         lab, ref = data.estep(cc, return_refined=True)
         us = timeit(lambda: data.estep(cc))
         dp = (d + 127) // 128 * 128
-        algo = n * dp * 2 + 4 * n + 128 * dp * 2
+        algo = n * dp * 2 + 4 * n + ((k + 127) // 128 * 128) * dp * 2
         print("estep  [%s] %8.1f us  refined rows %6d (%.2f%%)  algorithmic %.1f MB -> %.0f GB/s" % (name, us, int(ref), 100.0 * int(ref) / n, algo / 1e6, algo / us / 1e3))
     lab = data.estep(C)
     us = timeit(lambda: ops.kmeans_mstep(X, lab, C, k, 0))
