@@ -128,10 +128,11 @@ def test_estep_nan_centre_never_wins(ops):
 
 
 @pytest.mark.parametrize("n,d,k,seed", [(31, 16, 3, 11), (33, 200, 128, 12), (1000, 300, 1, 13), (2049, 512, 64, 14), (777, 640, 128, 15),
-                                        (5000, 768, 128, 16), (1025, 100, 129, 17), (600, 896, 50, 18)])
+                                        (5000, 768, 128, 16), (1025, 100, 129, 17), (600, 896, 50, 18), (1500, 256, 1000, 19), (700, 128, 2048, 20),
+                                        (900, 64, 2049, 21)])
 def test_estep_stream_kernel_shapes(ops, n, d, k, seed):
-    """Every column-chunk count of estep_stream_kernel (D <= 768: 1..6 x 128), K = 1 / 128, ragged last 32-row unit, and the
-    shapes just outside it (K = 129, D = 896: estep_mfma_kernel); centres are data points, so rows with distance 0 and
+    """Every column-chunk count of estep_stream_kernel (D <= 768: 1..6 x 128), K = 1 / 128, ragged last 32-row unit, the
+    multi-pass form (K = 129 / 1000 / 2048: 2 / 8 / 16 passes) and the shapes outside it (K = 2049, D = 896: estep_mfma_kernel); centres are data points, so rows with distance 0 and
     many small margins (both refine lists) occur."""
     x, y, cent = synth.clustered_features(n, d, max(2, min(k, 20)), seed=seed, center_seed=seed + 7, noise=0.9)
     rs = np.random.RandomState(seed)
