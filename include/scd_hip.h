@@ -114,6 +114,12 @@ int scd_vote_hist(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int 
 /* ---- host solvers (CPU, synchronous) ---- */
 /* linear_assignment (gcd/project_utils/cluster_utils.py:234-493), same tie-breaking; pairs_out [min(n,m),2] sorted */
 int scd_munkres(const int64_t* cost, int n, int m, int64_t* pairs_out, int* n_pairs_out);
+/* assign_name's solve (local_utils/clip_lang_util.py:167-178): linear_assignment(w.max() - w) for the d x d vote matrix w
+ * given by its nnz non-zero entries (rows/cols int32, vals int64; duplicates add up as `w[i, col] += v` does) - the same
+ * decisions as scd_munkres on the dense matrix, in O(d) per covered row instead of O(d^2): d reaches 10,000-20,000 at
+ * K = 1000 clusters (BASELINE configs[3]).  pairs_out [d,2] sorted by row. */
+int scd_munkres_sparse(int d, int64_t nnz, const int32_t* rows, const int32_t* cols, const int64_t* vals,
+                       int64_t* pairs_out, int* n_pairs_out);
 /* solve_min_cost_flow_graph (sskm_constrained.py:331-356) on the transportation form: cost int32 [n,k] */
 int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
                         int64_t* total_cost_out);

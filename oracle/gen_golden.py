@@ -113,8 +113,20 @@ def gen_munkres():
         x = w.max() - w
         out["cost_w_%d" % rep] = x
         out["ind_w_%d" % rep] = linear_assignment(x)
+    # assign_name-shaped instances at sizes where the sparse solver's bookkeeping (row / column classes, step 6 on the
+    # potentials) is exercised: K cluster rows with <= 4 voted names each, popular names shared between clusters (conflicts),
+    # D - K all-zero padding rows.  Stored as the non-zero entries of w; solved by the reference on w.max() - w.
+    for rep, (k, d, pool) in enumerate(((40, 160, 30), (60, 250, 45), (25, 300, 12), (90, 120, 100))):
+        w = np.zeros((d, d), dtype=np.int64)
+        for i in range(k):
+            cols = np.unique(rs.zipf(1.4, size=4) % pool)
+            w[i, cols] += rs.randint(1, 25, size=len(cols))
+        r, c = np.nonzero(w)
+        out["vote_rows_%d" % rep], out["vote_cols_%d" % rep], out["vote_vals_%d" % rep] = r, c, w[r, c]
+        out["vote_d_%d" % rep] = np.array(d)
+        out["vote_ind_%d" % rep] = linear_assignment(w.max() - w)
     np.savez_compressed(os.path.join(OUT, "munkres.npz"), **out)
-    print("munkres:", len(out) // 2, "cases")
+    print("munkres:", len([k for k in out if k.startswith("ind_") or k.startswith("vote_ind_")]), "cases")
 
 
 def gen_acc_v2():

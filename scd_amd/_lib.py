@@ -57,6 +57,7 @@ SIGNATURES = {
     "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),
     "scd_vote_hist": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "scd_munkres": (_i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
+    "scd_munkres_sparse": (_i, [_i, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "scd_transport_solve": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(_i64)]),
     "scd_encoder_create": (_i, [_vp, C.POINTER(EncoderDesc), C.POINTER(_vp), _i, C.POINTER(_vp)]),
     "scd_encoder_destroy": (_i, [_vp]),

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscd_hip.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 
-SOURCES = ["api.cpp", "munkres.cpp", "transport.cpp", "kmeans.hip", "mstep.hip", "sim.hip", "vote.hip", "gemm.hip", "encoder.hip"]
+SOURCES = ["api.cpp", "munkres.cpp", "munkres_sparse.cpp", "transport.cpp", "kmeans.hip", "mstep.hip", "sim.hip", "vote.hip", "gemm.hip", "encoder.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
          "-fno-gpu-rdc"]

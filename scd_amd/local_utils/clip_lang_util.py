@@ -175,15 +175,24 @@ def accuracy(output, target, topk=(1,)):
 
 
 def _assign(unique_name_idx, cluster_to_counter, picker):
+    """w[i, col(name)] += count; ind = linear_assignment(w.max() - w) (:167-178).  The solve runs on the non-zero entries
+    (scd_munkres_sparse: the reference's state machine and tie-breaking with implicit potentials), so D = 10,000-20,000 at
+    K = 1000 clusters costs a second instead of the O(D^3) of the dense matrix; `w` is still returned, its untouched pages
+    never materialise."""
     col = {uidx: nidx for nidx, uidx in enumerate(unique_name_idx)}
     keys = list(cluster_to_counter.keys())
     D = max(len(unique_name_idx), len(keys))
     w = np.zeros((D, D), dtype=int)
+    rows, cols, vals = [], [], []
     for i, ck in enumerate(keys):
         for k, v in picker(cluster_to_counter[ck]):
             w[i, col[k]] += v
-    ind = linear_assignment(w.max() - w)
-    return ind, w
+            rows.append(i)
+            cols.append(col[k])
+            vals.append(v)
+    if not all(isinstance(v, (int, np.integer)) for v in vals):      # assign_name_logits: float "counts" go through w's int cast
+        return linear_assignment(w.max() - w), w
+    return ops.munkres_sparse(D, rows, cols, vals), w
 
 
 def assign_name(unique_name_idx, cluster_to_counter, num_common=4):

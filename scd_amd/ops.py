@@ -217,6 +217,20 @@ def munkres(cost):
     return res
 
 
+def munkres_sparse(d, rows, cols, vals):
+    """linear_assignment(w.max() - w) for the d x d matrix w with entries w[rows, cols] += vals (assign_name,
+    clip_lang_util.py:167-178) without building it: sorted pairs [d,2]."""
+    r = np.ascontiguousarray(rows, dtype=np.int32)
+    c = np.ascontiguousarray(cols, dtype=np.int32)
+    v = np.ascontiguousarray(vals, dtype=np.int64)
+    out = np.zeros((max(1, d), 2), dtype=np.int64)
+    npairs = C.c_int(0)
+    check(_L().scd_munkres_sparse(int(d), int(r.size), ptr(r), ptr(c), ptr(v), ptr(out), C.byref(npairs)))
+    res = out[: npairs.value].astype(int)
+    res.shape = (-1, 2)
+    return res
+
+
 def transport_solve(cost, size_min, size_max):
     """Size-constrained assignment; raises Exception('There was an issue with the min cost flow input.')
     when infeasible (sskm_constrained.py:349-350)."""

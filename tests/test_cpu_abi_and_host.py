@@ -78,6 +78,67 @@ def test_munkres_matches_reference_goldens(golden):
     assert ops.munkres(np.zeros((0, 0), dtype=int)).shape == (0, 2)
 
 
+def test_munkres_sparse_matches_reference_and_dense(golden):
+    """scd_munkres_sparse (assign_name's solve on the non-zero entries of w) against (i) the reference's own
+    linear_assignment on vote-shaped instances (tests/golden/munkres.npz, vote_*), (ii) the dense state machine and the
+    oracle on random matrices with heavy ties, negative entries, full rows and empty matrices."""
+    from scd_amd import ops
+    g = golden("munkres.npz")
+    for rep in range(4):
+        d = int(g["vote_d_%d" % rep])
+        r, c, v = g["vote_rows_%d" % rep], g["vote_cols_%d" % rep], g["vote_vals_%d" % rep]
+        assert np.array_equal(ops.munkres_sparse(d, r, c, v), g["vote_ind_%d" % rep]), rep
+        w = np.zeros((d, d), dtype=np.int64)
+        w[r, c] = v
+        assert np.array_equal(ops.munkres(w.max() - w), g["vote_ind_%d" % rep]), rep
+    rs = np.random.RandomState(11)
+    for rep in range(250):
+        d = rs.randint(1, 50)
+        w = np.zeros((d, d), dtype=np.int64)
+        for i in rs.choice(d, rs.randint(0, d + 1), replace=False):
+            cols = rs.choice(d, min(rs.randint(1, 6), d), replace=False)
+            w[i, cols] += rs.randint(1, rs.choice([2, 3, 5, 40]), size=len(cols))
+            if rep % 3 == 0:
+                w[i, cols] *= rs.choice([-1, 1], size=len(cols))
+        if d > 3 and rep % 4 == 0:
+            w[rs.randint(d)] = rs.randint(1, 4, size=d)                  # a row without background entries
+        r, c = np.nonzero(w)
+        sp = ops.munkres_sparse(d, r, c, w[r, c])
+        assert np.array_equal(sp, ops.munkres(w.max() - w)), rep
+        if rep % 10 == 0:
+            assert np.array_equal(sp, no.linear_assignment(w.max() - w)), rep
+    # duplicates add up like `w[i, col] += v`
+    assert np.array_equal(ops.munkres_sparse(3, [0, 0, 1], [2, 2, 2], [1, 1, 3]), ops.munkres(3 - np.array([[0, 0, 2], [0, 0, 3], [0, 0, 0]])))
+    assert ops.munkres_sparse(0, [], [], []).shape == (0, 2)
+    assert np.array_equal(ops.munkres_sparse(4, [], [], []), np.stack([np.arange(4)] * 2, 1))
+
+
+def test_munkres_sparse_c4_size_is_fast():
+    """BASELINE configs[3]: K = 1000 clusters, num_common_vote 10 / 20 -> D = 10,000 / 20,000.  The dense machine is O(D^3)
+    (16 s already at D = 4000); the sparse one must stay around a second and agree with it where the dense one is feasible."""
+    import time
+    from scd_amd import ops
+    rs = np.random.RandomState(3)
+    for k, per, d, limit in ((300, 4, 1500, None), (1000, 2, 10000, 20.0), (1000, 4, 20000, 30.0)):
+        pop = rs.zipf(1.3, size=(k, per)) % min(d, 3 * k)
+        rr, cc, vv = [], [], []
+        for i in range(k):
+            cols = np.unique(pop[i])
+            rr += [i] * len(cols)
+            cc += cols.tolist()
+            vv += rs.randint(1, 200, size=len(cols)).tolist()
+        t0 = time.time()
+        sp = ops.munkres_sparse(d, rr, cc, vv)
+        dt = time.time() - t0
+        assert len(sp) == d and len(set(sp[:, 1].tolist())) == d            # a permutation
+        if limit is None:
+            w = np.zeros((d, d), dtype=np.int64)
+            np.add.at(w, (rr, cc), vv)
+            assert np.array_equal(sp, ops.munkres(w.max() - w))
+        else:
+            assert dt < limit, dt
+
+
 def test_split_cluster_acc_v2_notebook_kat(golden):
     from scd_amd.gcd.project_utils.cluster_and_log_utils import split_cluster_acc_v2
     g = golden("acc_v2.npz")
