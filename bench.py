@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py - images/sec of the SCD embedding-and-naming hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config c2|c4]
+  N > 1: one rank per GPU.  Launched by the driver through torch.distributed.run (WORLD_SIZE = N in the environment); started
+  bare (`python bench.py --gpus N`), it spawns that launcher itself as a child process BEFORE touching the GPU.
 
 Workload (BASELINE.json configs[1], "ImageNet-100 unsupervised, CLIP ViT-B/16 encode + 21k WordNet vocab"):
 per GPU 126,976 synthetic 224x224 images (already resident in HBM, fp16), K=100 classes, V=21,000 names;
@@ -28,6 +30,13 @@ sys.path.insert(0, ROOT)
 IMAGES_PER_GPU = 126976
 N_CLASSES = 100
 VOCAB = 21000
+# --config c4 = BASELINE configs[3]: ImageNet-1k-sized synthetic set sharded over 8 GPUs (1,281,167 / 8 images per GPU), K = 1000
+CONFIGS = {"c2": dict(images=IMAGES_PER_GPU, n_cluster=N_CLASSES,
+                      workload="ImageNet-100 unsupervised (BASELINE configs[1]): CLIP ViT-B/16 encode + V=%d vocab + SSKM k=100 "
+                               "(10 restarts x 10 iters) + vote loop"),
+           "c4": dict(images=160146, n_cluster=1000,
+                      workload="ImageNet-1k synthetic shard (BASELINE configs[3], 1,281,167 images / 8 GPUs): CLIP ViT-B/16 encode + "
+                               "V=%d vocab + SSKM k=1000 (10 restarts x 10 iters) + vote loop")}
 PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 17563453440        # CLIP ViT-B/16 visual tower
@@ -38,11 +47,31 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--images", type=int, default=IMAGES_PER_GPU, help="images per GPU (default = BASELINE config)")
+    p.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    p.add_argument("--images", type=int, default=None, help="images per GPU (default = the config's)")
+    p.add_argument("--n-cluster", type=int, default=None, help="classes / clusters (default = the config's)")
     p.add_argument("--batch", type=int, default=665)   # 665*197 rows = 512 GEMM row tiles: every GEMM fills the 256 CUs exactly
     p.add_argument("--vocab", type=int, default=VOCAB)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    return p.parse_args()
+    a = p.parse_args()
+    a.images = a.images or CONFIGS[a.config]["images"]
+    a.n_cluster = a.n_cluster or CONFIGS[a.config]["n_cluster"]
+    return a
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process (never an
+    exec, and before this process has made any HIP call) and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(seed=0):
@@ -156,9 +185,13 @@ def secondary_rooflines(out, wt, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     local_rank = local_rank % torch.cuda.device_count()     # (debug: several ranks may share a GPU with SCD_DIST_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
@@ -168,12 +201,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("SCD_DIST_BACKEND", "nccl"), rank=rank, world_size=world)   # nccl == RCCL on ROCm
         group = dist.group.WORLD
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank)
 
     import scd_amd.clip as clip
     from scd_amd import pipeline
+    n_cls = args.n_cluster
+    clip.allow_synthetic()          # random-init weights + hash tokenizer: there is no checkpoint offline (`data: synthetic`)
     model, _ = clip.load("ViT-B/16", device="cuda")
-    images, y, base = pipeline.synthetic_images(args.images, N_CLASSES, seed=rank, device=dev)
+    images, y, base = pipeline.synthetic_images(args.images, n_cls, seed=rank, device=dev)
     wt, nouns = pipeline.synthetic_vocab(model, base, args.vocab, 0, dev)
     if world > 1:
         # the open-vocabulary part of W is a real, SHARDED text-tower build: every rank encodes its contiguous range of
@@ -182,9 +218,9 @@ def main():
         from scd_amd.local_utils import clip_lang_util as clu
         w_text = clu.zeroshot_classifier_sharded(nouns, ["a photo of a {}.", "a {}."], model, group, names_per_batch=256)
         wt_text = w_text.t().contiguous()
-        wt_text[:N_CLASSES] = wt[:N_CLASSES]
+        wt_text[:n_cls] = wt[:n_cls]
         wt = wt_text
-    mask_lab = pipeline.labelled_split(y, N_CLASSES, seed=5 + rank)
+    mask_lab = pipeline.labelled_split(y, n_cls, seed=5 + rank)
     l_targets = y[torch.as_tensor(mask_lab, device=dev)]
 
     def barrier():
@@ -198,7 +234,7 @@ def main():
 
     def step(i, timed):
         timers = [] if timed else None
-        out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, N_CLASSES, topk=3, num_common_vote=10,
+        out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, n_cls, topk=3, num_common_vote=10,
                            num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers)
         if timed:
             torch.cuda.synchronize()
@@ -233,12 +269,11 @@ def main():
         enc_s = stage_ms.get("encode", 0.0) / 1e3 / args.steps
         line = {
             "metric": "images/sec end-to-end (encode+sim+k-means) on 224^2 synth, 21k vocab",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ImageNet-100 unsupervised (BASELINE configs[1]): CLIP ViT-B/16 encode + V=%d vocab + SSKM k=100 "
-                                   "(10 restarts x 10 iters) + vote loop" % args.vocab,
-                       "images_per_gpu": args.images, "vocab": args.vocab, "n_cluster": N_CLASSES, "encode_batch": args.batch,
+            "config": {"workload": CONFIGS[args.config]["workload"] % args.vocab,
+                       "images_per_gpu": args.images, "vocab": args.vocab, "n_cluster": n_cls, "encode_batch": args.batch,
                        "weights": "random-init (seeded), no checkpoint offline", "parallelism": "dp%d" % world},
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},
             "encode_tflops": round(args.images * FLOP_PER_IMAGE / max(enc_s, 1e-9) / 1e12, 1),

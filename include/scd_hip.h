@@ -54,6 +54,10 @@ int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_t c, void* 
 /* out[i,:] = Wt[idx[i],:]  (the `zeroshot_weights[:, nouns.index(n)]` gather, main_unsup.py:601-602) */
 int scd_gather_rows_f16(scd_handle h, const void* Wt, const int64_t* idx, int64_t m, int d, void* out, void* stream);
 
+/* out = fp16((a + b) / 2) over n_elems fp16 values (n_elems % 8 == 0): the textual-enhancement feature of BASELINE configs[4],
+ * `100 * (f @ W + t @ W) / 2` (commented at main_unsup.py:518,523,604,609) = 100 * mean(f, t) @ W -> scd_sim_topk on the mean. */
+int scd_mean2_f16(scd_handle h, const void* a, const void* b, int64_t n_elems, void* out, void* stream);
+
 /* zeroshot_classifier pooling (local_utils/clip_lang_util.py:103-107): emb fp16 [n_names*t_per, d] prompt embeddings ->
  * per name normalise, mean, normalise; written as columns col0.. of out fp16 [d, ld_out] (torch.stack(dim=1) layout). */
 int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t_per, int d, int64_t col0, int64_t ld_out, void* out,
@@ -87,9 +91,18 @@ int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const 
                      int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes,
                      void* stream);
 /* centres = sums / counts (empty -> NaN, as torch mean of an empty selection); shift_out (device double, may be NULL)
- * = (sum_k ||c_k - c_old_k||_2)^2  (sskm_constrained.py:135-136) */
+ * = (sum_k ||c_k - c_old_k||_2)^2  (shift_mode 0: sskm_constrained.py:135-136) or sum_k ||c_k - c_old_k||^2 (shift_mode 1:
+ * sklearn's center_shift_tot, the `--cluster KM` path of main_unsup.py:362) */
 int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old,
-                        float* C_out, double* shift_out, void* stream);
+                        float* C_out, double* shift_out, int shift_mode, void* stream);
+/* sklearn.cluster.KMeans pieces (main_unsup.py:362, main_ptsup.py:381 `KMeans(n_clusters, random_state=0).fit(u_feats)`):
+ * out (device int64) = number of rows whose label changed (strict convergence, `np.array_equal(labels, labels_old)`); */
+int scd_labels_changed(scd_handle h, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, void* stream);
+/* the greedy k-means++ candidate draw: idx_out[l] = searchsorted(cumsum_f64(d2), u[l] * float32(sum d2)) clipped to n-1 for
+ * l < n_draws (u: device doubles, the host RandomState's uniforms); pot_out (device double, may be NULL) = sum d2.
+ * ws: scd_kpp_draw_ws_bytes(n). */
+int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, const double* u, int n_draws, int64_t* idx_out,
+                         double* pot_out, void* ws, size_t ws_bytes, void* stream);
 /* incremental k-means++ (kpp, sskm_constrained.py:28-44): d2 = min(d2, ||x - c_new||^2) */
 int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int64_t n, int d, float* d2_inout,
                           void* stream);

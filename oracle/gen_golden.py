@@ -194,6 +194,32 @@ def gen_kmeans():
     np.savez_compressed(os.path.join(OUT, "kmeans_sskm.npz"), **out)
 
 
+def gen_sklearn_kmeans():
+    """sklearn.cluster.KMeans as the reference calls it for --cluster KM (main_unsup.py:362), pinned the way SURVEY.md 8c says:
+    this container's scikit-learn with explicit init, n_init=1, algorithm='lloyd', so that only the Lloyd arithmetic is compared."""
+    import sklearn
+    from sklearn.cluster import KMeans
+    from oracle import synth
+    out = {"sklearn_version": np.array(sklearn.__version__)}
+    cases = [("a", 600, 8, 5, 1, 0.8), ("b", 2500, 64, 12, 2, 0.9), ("c", 4000, 768, 20, 3, 0.8), ("e", 900, 16, 6, 4, 0.7)]
+    for tag, n, d, k, seed, noise in cases:
+        x, y, cent = synth.clustered_features(n, d, k, seed=seed, center_seed=seed + 40, noise=noise)
+        rs = np.random.RandomState(seed)
+        init = x[rs.choice(n, k, replace=False)].copy()
+        if tag == "e":
+            init[2] = 50.0                       # a centre nobody is closest to: exercises _relocate_empty_clusters_dense
+        km = KMeans(n_clusters=k, init=init, n_init=1, algorithm="lloyd", random_state=0).fit(x)
+        out["%s_shape" % tag] = np.array([n, d, k, seed])
+        out["%s_noise" % tag] = np.array(noise)
+        out["%s_init" % tag] = init
+        out["%s_labels" % tag] = km.labels_
+        out["%s_centers" % tag] = km.cluster_centers_
+        out["%s_inertia" % tag] = np.array(float(km.inertia_))
+        out["%s_n_iter" % tag] = np.array(int(km.n_iter_))
+        print("sklearn KMeans", tag, "inertia", km.inertia_, "n_iter", km.n_iter_)
+    np.savez_compressed(os.path.join(OUT, "kmeans_sklearn.npz"), **out)
+
+
 def gen_constrained():
     import sskm_constrained as con           # local_utils/sskm_constrained.py
     out = {}
@@ -341,6 +367,30 @@ def gen_naming():
         out["vp_voted_%d" % i], out["vp_ind_%d" % i], out["vp_cand_%d" % i] = vo, ind, cand
         out["vp_preds_%d" % i], out["vp_unlab_%d" % i] = up, uc
     print("ptsup vote loop iterations:", len(trace2))
+
+    # ---- missing-name matching (row a7): the reference's own lines with a stand-in text classifier of the missing names.
+    # Vocabulary = the 400 names above; 9 "class names": 4 are in the vocabulary, 5 are missing and sit near vocabulary columns
+    # (two of them near the SAME column, so that the greedy top-5 of :459-469 has to move to a second choice).
+    rs = np.random.RandomState(36)
+    near = [20, 21, 300, 20, 77]
+    mw = np.stack([w[:, c] + 0.35 * rs.randn(dclip).astype(np.float32) / np.sqrt(dclip) for c in near], axis=1)
+    mw = (mw / np.linalg.norm(mw, axis=0, keepdims=True)).astype(np.float32)
+    class_cols = [5, 9, 130, 399]                                  # class names that ARE vocabulary names
+    miss_names = ["miss_%d" % i for i in range(len(near))]
+    original_names = [nouns[c] for c in class_cols] + miss_names
+    base = dict(torch=torch, zeroshot_classifier=lambda names, templates, model: torch.from_numpy(mw), imagenet_templates=None,
+                model=None, zeroshot_weights=torch.from_numpy(w), nouns=nouns, miss_names=miss_names, print=lambda *a, **k: None)
+    n1 = dict(base)
+    exec(ref_lines("main_unsup.py", 402, 406), n1)                                        # cifar / aircraft: top-1 over all nouns
+    n2 = dict(base, nouns_truncated=[n for n in nouns if n not in original_names])
+    exec(ref_lines("main_unsup.py", 487, 491), n2)                                        # cub: top-1 over nouns_truncated
+    n3 = dict(base, nouns_truncated=[n for n in nouns if n not in original_names])
+    exec(ref_lines("main_unsup.py", 459, 469), n3)                                        # sdogs: greedy de-duplicated top-5
+    out["mm_w"], out["mm_miss_w"], out["mm_class_cols"] = w, mw, np.array(class_cols)
+    out["mm_top1_full"] = np.array([nouns.index(n) for n in n1["matched_names"]])
+    out["mm_top1_trunc"] = np.array([nouns.index(n) for n in n2["matched_names"]])
+    out["mm_greedy5_trunc"] = np.array([nouns.index(n) for n in n3["matched_names"]])
+    print("missing names:", out["mm_top1_full"], out["mm_top1_trunc"], out["mm_greedy5_trunc"])
     np.savez_compressed(os.path.join(OUT, "naming.npz"), **out)
 
 
@@ -435,9 +485,9 @@ def main():
         sys.exit(2)
     os.makedirs(OUT, exist_ok=True)
     install_stubs(NxMinCostFlow)
-    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "constrained", "naming", "encoders"]
+    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "constrained", "naming", "encoders"]
     for w in which:
-        dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, constrained=gen_constrained,
+        dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, sklearn=gen_sklearn_kmeans, constrained=gen_constrained,
              naming=gen_naming, encoders=gen_encoders)[w]()
 
 

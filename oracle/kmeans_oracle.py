@@ -224,3 +224,77 @@ class K_Means:
 
     def fit_mix(self, u, l, l_targets):
         self._run(self.fit_mix_once, u, l, l_targets)
+
+
+# ----------------------------------------------------------------------------- sklearn.cluster.KMeans (--cluster KM)
+def sklearn_tolerance(x, tol):
+    """sklearn/cluster/_kmeans.py `_tolerance`: mean(var(X, axis=0)) * tol."""
+    return float(np.mean(np.var(np.asarray(x, dtype=F64), axis=0)) * tol)
+
+
+def sklearn_lloyd(x, init, max_iter=300, tol=1e-4):
+    """`_kmeans_single_lloyd` of scikit-learn 1.7.2 (third-party; call site /root/reference/main_unsup.py:362) from an explicit
+    init, with the decision semantics of this oracle (float64 distances, ties to the lowest index): E-step, centre update with
+    `_relocate_empty_clusters_dense`, strict / tol convergence, final E-step when the stop was not strict.
+    Returns (labels int32, inertia, centres float32, n_iter).  Pinned by tests/golden/kmeans_sklearn.npz (sklearn's own output)."""
+    x = np.asarray(x, dtype=F32)
+    n = x.shape[0]
+    centers = np.asarray(init, dtype=F32).copy()
+    k = centers.shape[0]
+    tol_abs = sklearn_tolerance(x, tol)
+    labels_old = np.full(n, -1, dtype=np.int64)
+    strict = False
+    it = 0
+    for it in range(max_iter):
+        labels, _, dmat = estep(x, centers)
+        x64 = x.astype(F64)
+        sums = np.zeros((k, x.shape[1]), dtype=F64)
+        np.add.at(sums, labels, x64)
+        cnt = np.bincount(labels, minlength=k).astype(np.int64)
+        empty = np.nonzero(cnt == 0)[0]
+        if empty.size:
+            dist = dmat[np.arange(n), labels].astype(F32)
+            far = np.argpartition(dist, -empty.size)[:-empty.size - 1:-1]
+            for j, e in enumerate(empty):
+                old = labels[far[j]]
+                sums[old] -= x64[far[j]]
+                sums[e] = x64[far[j]]
+                cnt[e] = 1
+                cnt[old] -= 1
+        new = (sums / cnt[:, None]).astype(F32)
+        shift = float(((new.astype(F64) - centers.astype(F64)) ** 2).sum())
+        centers = new
+        if np.array_equal(labels, labels_old):
+            strict = True
+            break
+        if shift <= tol_abs:
+            break
+        labels_old = labels
+    if not strict:
+        labels, _, dmat = estep(x, centers)
+    inertia = float(pairwise_distance64(x, centers)[np.arange(n), labels].astype(F32).astype(F64).sum())
+    return labels.astype(np.int32), inertia, centers, it + 1
+
+
+def sklearn_kpp(x, k, random_state):
+    """`_kmeans_plusplus` of scikit-learn 1.7.2 with this oracle's arithmetic: closest distances are float32(float64 exact),
+    the potential is float32(float64 sum) (sklearn: a float32 BLAS dot), candidates = searchsorted(cumsum_f64(d2), u * pot),
+    the candidate with the smallest new potential (float64 sum) wins.  RandomState consumption as in sklearn: one
+    choice(n, p=uniform), then uniform(size=2 + int(log k)) per added centre.  Returns the chosen row indices."""
+    rs = check_random_state(random_state)
+    x = np.asarray(x, dtype=F32)
+    n = x.shape[0]
+    trials = 2 + int(np.log(k))
+    p = np.ones(n, dtype=F32)
+    picks = [int(rs.choice(n, p=p / p.sum()))]
+    d2 = pairwise_distance64(x, x[picks[0]][None])[:, 0].astype(F32)
+    for _ in range(1, k):
+        pot = F32(d2.astype(F64).sum())
+        rv = rs.uniform(size=trials) * F64(pot)
+        cand = np.searchsorted(np.cumsum(d2.astype(F64)), rv)
+        np.clip(cand, None, n - 1, out=cand)
+        dc = np.minimum(d2[None, :], pairwise_distance64(x[cand], x).astype(F32))
+        best = int(np.argmin(dc.astype(F64).sum(axis=1)))
+        picks.append(int(cand[best]))
+        d2 = dc[best]
+    return np.array(picks)

@@ -307,3 +307,28 @@ def evaluate_semantic_acc(u_targets, cidx_to_cname, u_preds, cand_names):
         hit_all.append(h)
     acc = {n: sum(v) / float(len(v)) for n, v in per.items()}
     return float(sum(acc.values())) / len(acc), sum(hit_all) / float(len(hit_all))
+
+
+# ----------------------------------------------------------------------------- missing class names (row a7)
+def match_missing_names(miss_w, w, nouns, nouns_truncated=None, mode="top1"):
+    """main_unsup.py:402-406 (top-1 over the vocabulary), :487-491 (top-1 over nouns_truncated), :459-469 (greedy
+    de-duplicated top-5 over nouns_truncated): miss_w [D, m] classifier of the missing names, w [D, V]."""
+    f = np.asarray(miss_w, dtype=F64).T
+    if nouns_truncated is None:
+        pool, wp = nouns, np.asarray(w, dtype=F64)
+    else:
+        pool = nouns_truncated
+        wp = np.stack([np.asarray(w, dtype=F64)[:, nouns.index(n)] for n in nouns_truncated], axis=1)
+    lg = 100.0 * (f @ wp)
+    if mode == "top1":
+        return [pool[i] for i in topk_desc(lg, 1)[:, 0]]
+    top5 = topk_desc(lg, 5)
+    matched = []
+    for i in range(f.shape[0]):
+        j = 0
+        idx = top5[i, j]
+        while pool[idx] in matched:
+            j += 1
+            idx = top5[i, j]
+        matched.append(pool[idx])
+    return matched

@@ -113,3 +113,33 @@ class K_Means(ko.K_Means):
         d2 = ko.pairwise_distance(x, centers)
         labels, inertia, _ = labels_constrained(d2, self.size_min, self.size_max)
         return labels.astype(np.int64), inertia
+
+
+def check_optimal(cost_i32, labels, size_min, size_max):
+    """Independent optimality certificate for a FEASIBLE assignment, without an LP: the assignment is optimal iff the residual
+    graph has no negative cycle.  Cluster-level form: arc a -> b with weight min_{i in a} (c[i,b] - c[i,a]) (move the cheapest
+    point of a to b), plus a node Z with 0-weight arcs Z -> a for clusters above size_min (may lose a point) and b -> Z for
+    clusters below size_max (may gain one).  Bellman-Ford over K + 1 nodes.  Returns True when no improving move exists."""
+    c = np.asarray(cost_i32, dtype=np.int64)
+    n, k = c.shape
+    labels = np.asarray(labels)
+    cnt = np.bincount(labels, minlength=k)
+    big = np.int64(1) << 60
+    w = np.full((k + 1, k + 1), big, dtype=np.int64)
+    for a in range(k):
+        rows = np.nonzero(labels == a)[0]
+        if rows.size:
+            w[a, :k] = (c[rows] - c[rows, a][:, None]).min(axis=0)
+        w[a, a] = big
+        if cnt[a] > size_min:
+            w[k, a] = 0
+        if cnt[a] < size_max:
+            w[a, k] = 0
+    dist = np.zeros(k + 1, dtype=np.int64)               # virtual source to every node
+    for _ in range(k + 2):
+        cand = (dist[:, None] + np.where(w >= big, big, w)).min(axis=0)
+        new = np.minimum(dist, cand)
+        if np.array_equal(new, dist):
+            return True
+        dist = new
+    return False

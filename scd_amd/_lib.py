@@ -40,6 +40,7 @@ SIGNATURES = {
     "scd_sim_topk": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scd_transpose_f16": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scd_gather_rows_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_mean2_f16": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "scd_prompt_pool": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp]),
     "scd_kmeans_prep_bytes": (_sz, [_i64, _i]),
     "scd_kmeans_prepare": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
@@ -49,7 +50,9 @@ SIGNATURES = {
     "scd_kmeans_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "scd_kmeans_mstep_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kmeans_mstep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "scd_labels_changed": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "scd_kpp_searchsorted": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "scd_kmeans_min_update": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "scd_kpp_draw_ws_bytes": (_sz, [_i64]),
     "scd_kpp_draw": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

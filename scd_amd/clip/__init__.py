@@ -2,9 +2,11 @@
 
 Mirrors the third-party openai/CLIP package API used by the reference
 (main_unsup.py:237 `clip.load("ViT-B/16")`; clip_lang_util.py:101 `clip.tokenize`).
-Checkpoints: `load` looks for a state dict at $SCD_ROOT/clip/ViT-B-16.pt (torch.save of the
-openai state dict); without one it builds seeded random-init weights and says so
-(`model.synthetic == True`) - there is no network in the build/benchmark environment.
+Checkpoints: `load` looks for $SCD_ROOT/clip/ViT-B-16.pt - the openai download as it is (a TorchScript archive) or a
+torch.save of its state dict.  Without one it RAISES: random-init weights (and the hash tokenizer that stands in for the BPE
+merges file) produce meaningless features, so they must be asked for explicitly - `load(..., synthetic=True)`,
+`clip.allow_synthetic()` or SCD_SYNTHETIC=1 - as bench.py, smoke(), the --synthetic mode of the mains and the tests do
+(there is no network in the build/benchmark environment).
 """
 import gzip
 import html
@@ -42,18 +44,45 @@ def _preprocess(n_px):
     return run
 
 
-def load(name="ViT-B/16", device=None, jit=False, download_root=None, seed=0):
+_allow_synthetic = False
+
+
+def allow_synthetic(flag=True):
+    """Opt in to seeded random-init weights / the hash tokenizer when the real files are absent (benchmarks, tests)."""
+    global _allow_synthetic
+    _allow_synthetic = bool(flag)
+
+
+def _synthetic_ok(explicit=None):
+    if explicit is not None:
+        return bool(explicit)
+    return _allow_synthetic or os.environ.get("SCD_SYNTHETIC", "") not in ("", "0")
+
+
+def _read_checkpoint(path):
+    """State dict of an openai/CLIP checkpoint: the stock download is a TorchScript archive, a converted one a pickle."""
+    try:
+        return torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        return sd.state_dict() if hasattr(sd, "state_dict") else sd
+
+
+def load(name="ViT-B/16", device=None, jit=False, download_root=None, seed=0, synthetic=None):
     if name not in _MODELS:
         raise RuntimeError("Model %s not found; available models = %s" % (name, available_models()))
     root = download_root or os.environ.get("SCD_ROOT", "")
     path = os.path.join(root, "clip", name.replace("/", "-") + ".pt") if root else ""
     if path and os.path.exists(path):
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.state_dict() if hasattr(sd, "state_dict") else sd
+        sd = {k: v for k, v in _read_checkpoint(path).items() if k not in ("input_resolution", "context_length", "vocab_size")}
         synthetic = False
-    else:
+    elif _synthetic_ok(synthetic):
         sd = weights.synthetic_clip_state_dict(seed=seed)
         synthetic = True
+    else:
+        raise FileNotFoundError("CLIP checkpoint %s not found: put the openai ViT-B-16.pt under $SCD_ROOT/clip/ (or pass "
+                                "download_root); seeded random-init weights must be requested explicitly with "
+                                "load(..., synthetic=True), clip.allow_synthetic() or SCD_SYNTHETIC=1" % (path or "$SCD_ROOT/clip/ViT-B-16.pt"))
     model = CLIP(sd)
     model.synthetic = synthetic
     if device is None or str(device).startswith("cuda"):
@@ -156,9 +185,13 @@ def _get_tokenizer():
         path = next((p for p in cands if p and os.path.exists(p)), None)
         if path:
             _tokenizer = SimpleTokenizer(path)
-        else:
+        elif _synthetic_ok():
             warnings.warn("CLIP BPE merges file not found ($SCD_CLIP_BPE); using the synthetic hash tokenizer")
             _tokenizer = HashTokenizer()
+        else:
+            raise FileNotFoundError("CLIP BPE merges file bpe_simple_vocab_16e6.txt.gz not found ($SCD_CLIP_BPE or $SCD_ROOT/clip/); "
+                                    "the hash tokenizer stand-in must be requested explicitly (clip.allow_synthetic() or "
+                                    "SCD_SYNTHETIC=1)")
     return _tokenizer
 
 

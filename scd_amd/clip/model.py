@@ -156,7 +156,11 @@ class DinoViT:
     def eval(self):
         return self
 
-    def __call__(self, x):
+    def features(self, x, normalize=False):
+        """[B,3,224,224] -> float32 [B,768]; normalize=True fuses F.normalize(dim=-1) into the encoder's last kernel."""
         if self._enc is None:
             self.cuda()
-        return self._enc.encode_image(x.to(self._enc.device)).float()
+        return self._enc.encode_image(x.to(self._enc.device), normalize=normalize).float()
+
+    def __call__(self, x):
+        return self.features(x)

@@ -1,0 +1,154 @@
+"""`KMeans` with the call surface and the algorithm of sklearn.cluster.KMeans as the reference uses it for `--cluster KM`
+(/root/reference/main_unsup.py:362, main_ptsup.py:381: `KMeans(n_clusters=args.n_cluster, random_state=0).fit(u_feats).labels_`,
+the default of scripts/evaluate_unsupervised.sh), on the HIP k-means kernels instead of the host's Cython/OpenMP Lloyd.
+
+Restated from scikit-learn 1.7.2 (third-party, not under /root/reference; sklearn/cluster/_kmeans.py):
+  * `_kmeans_plusplus`: first centre `random_state.choice(n, p=uniform)`, then per centre 2 + floor(ln k) candidates drawn with
+    `uniform(size=L) * pot` -> searchsorted on the cumulative closest distances; the candidate with the smallest new potential wins.
+    The RandomState is consumed exactly as sklearn consumes it (one choice, then L uniforms per centre);
+  * `_kmeans_single_lloyd`: E-step, centre update, empty clusters re-seeded with the points farthest from their centres
+    (`_relocate_empty_clusters_dense`), stop on unchanged labels (strict) or `sum_k ||dc_k||^2 <= tol * mean(var(X))`, and one more
+    E-step when the stop was not strict; n_init='auto' -> 1 run for k-means++, max_iter 300, tol 1e-4.
+sklearn subtracts the column means from a float32 X first, for the accuracy of its float32 GEMM-form distances; distances here are
+decided on float64 values (DESIGN.md "decision semantics"), which are translation invariant, so X is used as it is.
+
+Parity: Lloyd from an explicit `init` array is pinned label-for-label against sklearn 1.7.2 (tests/golden/kmeans_sklearn.npz).
+The seeding cannot be bit-pinned to sklearn's: its potentials are float32 BLAS dot products whose summation order decides
+which row a uniform lands on once in ~1/(N * 1e-7) draws; the algorithm and the random stream are the same.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .kmeans import check_random_state
+
+
+class KMeans:
+    def __init__(self, n_clusters=8, *, init="k-means++", n_init="auto", max_iter=300, tol=1e-4, verbose=0, random_state=None,
+                 copy_x=True, algorithm="lloyd"):
+        if algorithm not in ("lloyd", "auto", "full"):
+            raise ValueError("only algorithm='lloyd' is implemented on the HIP path (got %r)" % (algorithm,))
+        self.n_clusters = n_clusters
+        self.init = init
+        self.n_init = n_init
+        self.max_iter = max_iter
+        self.tol = tol
+        self.verbose = verbose
+        self.random_state = random_state
+        self.copy_x = copy_x
+        self.algorithm = algorithm
+
+    # ------------------------------------------------------------------ seeding (sklearn `_kmeans_plusplus`)
+    def _kpp(self, data, rs):
+        x = data.x
+        n, k = x.shape[0], self.n_clusters
+        n_local_trials = 2 + int(np.log(k))
+        p = np.ones(n, dtype=np.float32)
+        first = int(rs.choice(n, p=p / p.sum()))
+        centers = torch.empty((k, x.shape[1]), dtype=torch.float32, device=x.device)
+        centers[0] = x[first]
+        d2 = torch.full((n,), float("inf"), dtype=torch.float32, device=x.device)
+        data.min_update(centers[0], d2)
+        tmp = torch.empty((n_local_trials, n), dtype=torch.float32, device=x.device)
+        for c in range(1, k):
+            cand, _ = ops.kpp_searchsorted(d2, rs.uniform(size=n_local_trials))
+            rows = x.index_select(0, cand)
+            pots = []
+            for t in range(n_local_trials):
+                tmp[t].copy_(d2)
+                data.min_update(rows[t], tmp[t])
+                pots.append(ops.sum_f32(tmp[t]))
+            best = torch.argmin(torch.cat(pots))          # first minimum, like np.argmin
+            centers[c] = rows.index_select(0, best.reshape(1))[0]
+            d2 = tmp.index_select(0, best.reshape(1))[0].clone()
+        return centers
+
+    # ------------------------------------------------------------------ sklearn `_kmeans_single_lloyd`
+    def _lloyd(self, data, centers, tol_abs):
+        x = data.x
+        n, k = x.shape[0], self.n_clusters
+        labels_old = torch.full((n,), -1, dtype=torch.int32, device=x.device)
+        strict = False
+        it = 0
+        for it in range(self.max_iter):
+            labels = data.estep(centers)
+            sums, counts, _ = ops.kmeans_mstep(x, labels, None, k, 0)
+            flags = torch.cat([(counts == 0).sum().reshape(1), ops.labels_changed(labels, labels_old)]).cpu().numpy()
+            if flags[0] > 0:
+                self._relocate_empty(data, centers, labels, sums, counts, int(flags[0]))
+            new_centers, shift = ops.kmeans_finalize(sums, counts, centers, shift_mode=1)
+            centers = new_centers
+            if flags[1] == 0:
+                strict = True
+                break
+            if float(shift.item()) <= tol_abs:
+                break
+            labels_old = labels
+        if not strict:
+            labels = data.estep(centers)
+        inertia = float(ops.sum_f32(data.rowdist(centers, labels)).item())
+        return labels, inertia, centers, it + 1
+
+    @staticmethod
+    def _relocate_empty(data, centers_old, labels, sums, counts, n_empty):
+        """`_relocate_empty_clusters_dense`: the n_empty points farthest from their centres each become the only member of one
+        empty cluster (their labels stay as they are this iteration, as in sklearn)."""
+        dist = data.rowdist(centers_old, labels).cpu().numpy()
+        far = np.argpartition(dist, -n_empty)[:-n_empty - 1:-1]
+        empty = torch.nonzero(counts == 0).reshape(-1)
+        lab = labels.cpu().numpy()
+        for j in range(n_empty):
+            row = data.x[int(far[j])].double()
+            old = int(lab[far[j]])
+            sums[old] -= row
+            sums[empty[j]] = row
+            counts[empty[j]] = 1
+            counts[old] -= 1
+
+    def fit(self, X, y=None, sample_weight=None):
+        if sample_weight is not None:
+            raise ValueError("sample_weight is not supported on the HIP path")
+        xt = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32) if not torch.is_tensor(X) else X)
+        if not xt.is_cuda:
+            xt = xt.cuda()
+        data = ops.KMeansData(xt.float())
+        x = data.x
+        n, d = x.shape
+        if n < self.n_clusters:
+            raise ValueError(f"n_samples={n} should be >= n_clusters={self.n_clusters}.")
+        rs = check_random_state(self.random_state)
+        # _tolerance: mean(var(X, axis=0)) * tol = inertia of X around its column means / (n d) * tol
+        zeros = torch.zeros(n, dtype=torch.int32, device=x.device)
+        s1, c1, _ = ops.kmeans_mstep(x, zeros, None, 1, 0)
+        mu, _ = ops.kmeans_finalize(s1, c1, None)
+        _, _, tot = ops.kmeans_mstep(x, zeros, mu, 1, 0)
+        tol_abs = float(tot.sum().item()) / (n * d) * self.tol
+        explicit = not isinstance(self.init, str)
+        n_init = self.n_init
+        if n_init == "auto":
+            n_init = 1 if (explicit or self.init == "k-means++") else 10
+        if explicit:
+            n_init = 1
+        best = None
+        for _ in range(n_init):
+            if explicit:
+                centers = torch.as_tensor(np.asarray(self.init, dtype=np.float32)).to(x.device).contiguous()
+            elif self.init == "k-means++":
+                centers = self._kpp(data, rs)
+            elif self.init == "random":
+                seeds = rs.choice(n, size=self.n_clusters, replace=False)
+                centers = x[torch.as_tensor(seeds, device=x.device)].contiguous()
+            else:
+                raise ValueError("init must be 'k-means++', 'random' or an array")
+            labels, inertia, centers, n_iter = self._lloyd(data, centers, tol_abs)
+            if best is None or inertia < best[1]:
+                best = (labels, inertia, centers, n_iter)
+        self.labels_ = best[0].cpu().numpy().astype(np.int32)
+        self.inertia_ = best[1]
+        self.cluster_centers_ = best[2].cpu().numpy()
+        self.n_iter_ = best[3]
+        self.n_features_in_ = d
+        return self
+
+    def fit_predict(self, X, y=None, sample_weight=None):
+        return self.fit(X, sample_weight=sample_weight).labels_

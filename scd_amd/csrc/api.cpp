@@ -1,6 +1,9 @@
 // Handle management and error reporting for libscd_hip.so.
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -9,6 +12,25 @@ void scd_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int scd_set_max_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    SCD_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, fn})) return SCD_OK;
+    SCD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, fn});
+    return SCD_OK;
+}
+
+int scd_check_device(const scd_ctx* h, const char* who) {
+    int dev = -1;
+    SCD_HIP(hipGetDevice(&dev));
+    SCD_REQUIRE(h && dev == h->device, "%s: the handle belongs to device %d but the current device is %d", who, h ? h->device : -1, dev);
+    return SCD_OK;
 }
 
 extern "C" int scd_version(void) { return 100; }

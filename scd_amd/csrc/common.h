@@ -15,6 +15,11 @@ struct scd_ctx {
 #define SCD_SCRATCH_BYTES (262144 + 64)
 
 void scd_set_error(const char* fmt, ...);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the attribute is per device, so a
+// process-wide `static bool` would leave a second device without it (api.cpp; mutex-protected)
+int scd_set_max_lds(const void* fn, int bytes);
+// the handle's device must be the current one: every launch below goes to the current device
+int scd_check_device(const struct scd_ctx* h, const char* who);
 
 #define SCD_REQUIRE(cond, ...)                                  \
     do {                                                        \

@@ -874,11 +874,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         if (rc) return rc;
         static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
         if (d.tokens > 192 && d.tokens <= 224 && !causal && attn_persist) {
-            static bool attr = false;
-            if (!attr) {
-                SCD_HIP(hipFuncSetAttribute((const void*)attention_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 224 * 128));
-                attr = true;
-            }
+            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel, 2 * 2 * 224 * 128); if (rc_) return rc_; }
             const int items = bp * d.heads;
             attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items, attn_xmode());
         } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
@@ -974,6 +970,7 @@ static int run_head(const scd_encoder* e, const EncWs& w, const EncPad& pad, boo
 extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const void* pixels, int dtype, int batch, void* out,
                                     int normalize, void* ws, size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && e && pixels && out && ws && batch > 0, "scd_vit_encode_image: bad arguments");
+    { const int rc_ = scd_check_device(h, "scd_vit_encode_image"); if (rc_) return rc_; }
     SCD_REQUIRE(e->d.kind == 0 || e->d.kind == 2, "scd_vit_encode_image: encoder is not a visual tower");
     SCD_REQUIRE(dtype == SCD_F32 || dtype == SCD_F16, "scd_vit_encode_image: bad dtype %d", dtype);
     SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_vit_encode_image: workspace too small");
@@ -1004,6 +1001,7 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
 extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
                                     void* ws, size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && e && tokens && out && ws && batch > 0, "scd_clip_encode_text: bad arguments");
+    { const int rc_ = scd_check_device(h, "scd_clip_encode_text"); if (rc_) return rc_; }
     SCD_REQUIRE(e->d.kind == 1, "scd_clip_encode_text: encoder is not a text tower");
     SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_clip_encode_text: workspace too small");
     hipStream_t st = (hipStream_t)stream_;

@@ -1405,11 +1405,7 @@ static int launch_w8(const half_t* A, const half_t* W, const float* bias, const 
                      const scd_gemm_ln* ln, hipStream_t st) {
     constexpr int LDS = 2 * 65536 + 16384;
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)gemm_w8_kernel<ACT, B, RR, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w8_kernel<ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
     static const int xenv = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;
@@ -1429,11 +1425,7 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
                      const scd_gemm_ln* ln, hipStream_t st) {
     constexpr int LDS = 2 * 65536 + 16384;
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
     static const int xenv = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;   // -1: by size
@@ -1490,11 +1482,7 @@ template <int BM, int ACT, bool B, bool RR>
 static int launch_dma(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                       hipStream_t st) {
     constexpr int LDS = BM == 256 ? 4 * (256 * 64 + 16384) + 8 * 4096 : 3 * (128 * 64 + 16384) + 4 * 2048;   // 160 KB / 80 KB
-    static bool attr = false;
-    if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)gemm_dma_kernel<BM, ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = true;
-    }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_dma_kernel<BM, ACT, B, RR>, LDS); if (rc_) return rc_; }
     const int tiles_n = N / 256, total = (M / BM) * tiles_n;
     const int resident = BM == 256 ? 256 : 512;
     const int grid = total < resident ? (total >= 8 ? total / 8 * 8 : total) : resident;
@@ -1505,11 +1493,7 @@ static int launch_dma(const half_t* A, const half_t* W, const float* bias, const
     if (BM == 256 && mfma_sel == 4) return launch_w4<8, ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
     if (BM == 256 && mfma_sel == 8) return launch_w8<ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
     if (BM == 256 && mfma16) {
-        static bool attr16 = false;
-        if (!attr16) {
-            SCD_HIP(hipFuncSetAttribute((const void*)gemm_dma16_kernel<ACT, B, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-            attr16 = true;
-        }
+        { const int rc_ = scd_set_max_lds((const void*)gemm_dma16_kernel<ACT, B, RR>, 163840); if (rc_) return rc_; }
         gemm_dma16_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
         return SCD_OK;
     }

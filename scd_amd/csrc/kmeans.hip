@@ -849,6 +849,7 @@ __global__ void refine_count_kernel(const EHdr* eh, int32_t* out) { *out = eh->f
 extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                                 int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && X && prep && C && labels_out && ws, "scd_kmeans_estep: null argument");
+    { const int rc_ = scd_check_device(h, "scd_kmeans_estep"); if (rc_) return rc_; }
     SCD_REQUIRE(n > 0 && d > 0 && k > 0 && k < 32768 && n < (1ll << 31), "scd_kmeans_estep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     SCD_REQUIRE(ws_bytes >= scd_kmeans_estep_ws_bytes(n, d, k), "scd_kmeans_estep: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
@@ -880,11 +881,7 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
         static const int es_dbg = getenv("SCD_ESTEP_DBG") ? atoi(getenv("SCD_ESTEP_DBG")) : 0;
 #define ES_LAUNCH(NCH)                                                                                                       \
     case NCH: {                                                                                                              \
-        static bool attr_set = false;                                                                                        \
-        if (!attr_set) {                                                                                                     \
-            SCD_HIP(hipFuncSetAttribute((const void*)estep_stream_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, ES_LDS)); \
-            attr_set = true;                                                                                                 \
-        }                                                                                                                    \
+        { const int rc_ = scd_set_max_lds((const void*)estep_stream_kernel<NCH>, ES_LDS); if (rc_) return rc_; }                                                                                                                    \
         for (int cb = 0; cb < kp / 128; ++cb)                                                                                \
             estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, chf + (size_t)cb * 128 * dp, cn + cb * 128, eh, flags, fcand, \
                                                                           fulls, n, labels_out, es_dbg, cb * 128,           \
@@ -1023,7 +1020,7 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
 // finalize in flight per handle.
 __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const long long* counts, int k, int d,
                                                        const float* Cold, float* Cout, double* shift, double* part,
-                                                       unsigned* ticket) {
+                                                       unsigned* ticket, int shift_mode) {
     __shared__ double wred[4];
     __shared__ bool last;
     const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1042,7 +1039,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
     if (lane == 0) wred[wave] = ss;
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[c] = sqrt((wred[0] + wred[1]) + (wred[2] + wred[3]));
+        const double sq = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+        part[c] = shift_mode ? sq : sqrt(sq);
         __threadfence();
         last = atomicAdd(ticket, 1u) == (unsigned)k - 1;
     }
@@ -1059,19 +1057,40 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            *shift = tred[0] * tred[0];
+            *shift = shift_mode ? tred[0] : tred[0] * tred[0];
             *ticket = 0;
         }
     }
 }
 
 extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d,
-                                   const float* C_old, float* C_out, double* shift_out, void* stream_) {
+                                   const float* C_old, float* C_out, double* shift_out, int shift_mode, void* stream_) {
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
     SCD_REQUIRE(k <= 32768, "scd_kmeans_finalize: k=%d > 32768", k);
     finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
-                                                         (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144));
+                                                         (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// number of positions where two label vectors differ (sklearn's strict-convergence test `np.array_equal(labels, labels_old)`,
+// sklearn/cluster/_kmeans.py `_kmeans_single_lloyd`): one atomic per block into *out, which the caller zeroed.
+__global__ void __launch_bounds__(256) labels_changed_kernel(const int* __restrict__ a, const int* __restrict__ b, long long n,
+                                                             unsigned long long* out) {
+    long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q, i += 256)
+        if (i < n) c += a[i] != b[i];
+    c = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_sum_f32((float)c));     // <= 256 per wave: exact in float
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+extern "C" int scd_labels_changed(scd_handle h, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, void* stream_) {
+    SCD_REQUIRE(h && a && b && out && n > 0, "scd_labels_changed: bad arguments");
+    SCD_HIP(hipMemsetAsync(out, 0, 8, (hipStream_t)stream_));
+    labels_changed_kernel<<<(unsigned)scd_cdiv(n, 1024), 256, 0, (hipStream_t)stream_>>>(a, b, n, (unsigned long long*)out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
@@ -1240,6 +1259,81 @@ extern "C" int scd_kpp_draw(scd_handle h, const float* d2, int64_t n, float r, c
     if (!total) kpp_tile_sum_kernel<<<nb, 1024, 0, st>>>(d2, n, bsum);
     kpp_tile_prob_kernel<<<nb, 1024, 0, st>>>(d2, n, bsum, nb, total, psum);
     kpp_pick_kernel<<<1, 1024, 0, st>>>(d2, n, r, bsum, psum, nb, total, prefix, (long long*)idx_out, probsum_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sklearn's k-means++ candidate draw (sklearn/cluster/_kmeans.py `_kmeans_plusplus`):
+//     rand_vals = random_state.uniform(size=L) * current_pot;  ids = searchsorted(stable_cumsum(closest_dist_sq), rand_vals)
+// for L uniforms in one launch: block l finds the first i with cumsum_f64(d2)[i] >= u[l] * pot, clipped to n - 1, where
+// pot = float32(sum d2) as sklearn's float32 `closest_dist_sq @ sample_weight`.  pot_out (may be NULL) receives the float64 sum.
+__global__ void __launch_bounds__(1024) kpp_search_kernel(const float* __restrict__ d2, long long n, const double* __restrict__ u,
+                                                          const double* __restrict__ bsum, int nb, long long* idx_out,
+                                                          double* pot_out) {
+    __shared__ double sh[32];
+    __shared__ long long best;
+    __shared__ int owner;
+    __shared__ double owner_pre;
+    if (threadIdx.x == 0) {
+        double pot = 0.0;
+        for (int b = 0; b < nb; ++b) pot += bsum[b];
+        if (pot_out && blockIdx.x == 0) *pot_out = pot;
+        const double rv = u[blockIdx.x] * (double)(float)pot;
+        double run = 0.0;
+        int ow = -1;
+        double opre = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double nxt = run + bsum[b];
+            if (ow < 0 && nxt >= rv) { ow = b; opre = run; }
+            run = nxt;
+        }
+        owner = ow;
+        owner_pre = opre;
+        best = 0x7fffffffffffffffll;
+        sh[31] = rv;
+    }
+    __syncthreads();
+    const double rv = sh[31];
+    if (owner < 0) {
+        if (threadIdx.x == 0) idx_out[blockIdx.x] = n - 1;
+        return;
+    }
+    double pre = owner_pre;
+    for (int b = owner; b < nb; ++b) {
+        const long long i0 = (long long)b * KPP_TILE + threadIdx.x * 4;
+        float pv[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pv[q] = (i0 + q < n) ? d2[i0 + q] : 0.f;
+            s += (double)pv[q];
+        }
+        double tot;
+        double run = pre + block_scan_excl_1024(s, sh, &tot);
+        long long found = 0x7fffffffffffffffll;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += (double)pv[q];
+            if (found == 0x7fffffffffffffffll && i0 + q < n && run >= rv) found = i0 + q;
+        }
+        if (found != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&best, (unsigned long long)found);
+        __syncthreads();
+        if (best != 0x7fffffffffffffffll) break;
+        pre += tot;
+    }
+    if (threadIdx.x == 0) idx_out[blockIdx.x] = (best == 0x7fffffffffffffffll) ? n - 1 : best;
+}
+
+extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, const double* u, int n_draws, int64_t* idx_out,
+                                    double* pot_out, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(h && d2 && u && idx_out && n > 0 && n_draws > 0 && ws, "scd_kpp_searchsorted: bad arguments");
+    SCD_REQUIRE(ws_bytes >= scd_kpp_draw_ws_bytes(n), "scd_kpp_searchsorted: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const int nb = (int)scd_cdiv(n, KPP_TILE);
+    double* bsum = (double*)ws;
+    kpp_tile_sum_kernel<<<nb, 1024, 0, st>>>(d2, n, bsum);
+    kpp_search_kernel<<<n_draws, 1024, 0, st>>>(d2, n, u, bsum, nb, (long long*)idx_out, pot_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

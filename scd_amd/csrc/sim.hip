@@ -736,7 +736,11 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     SCD_REQUIRE(mode == SCD_SIM_RAW || mode == SCD_SIM_SOFTMAX, "scd_sim_topk: bad mode %d", mode);
     SCD_REQUIRE(scale > 0.f, "scd_sim_topk: scale must be positive");
     SCD_REQUIRE(ws_bytes >= scd_sim_topk_ws_bytes(n, d, v, k), "scd_sim_topk: workspace too small");
+    { const int rc_ = scd_check_device(h, "scd_sim_topk"); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream_;
+    // slots no pass fills (a row whose logits are NaN has no ordered candidates) read as index -1 / value NaN, never as garbage
+    SCD_HIP(hipMemsetAsync(idx_out, 0xFF, (size_t)n * k * 8, st));
+    SCD_HIP(hipMemsetAsync(val_out, 0xFF, (size_t)n * k * 4, st));
     char* w = (char*)ws;
     SimHdr* hdr = (SimHdr*)w;
     const size_t csz = scd_align((size_t)n * 2 * TOPM * 4);
@@ -749,23 +753,15 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     SCD_HIP(hipMemsetAsync(hdr, 0, 64, st));
     wmax_kernel<<<256, 256, 0, st>>>(wt, v, d, &hdr->wmax2_bits);
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
-    static bool attr = false;
-    if (!attr) {
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 32768));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16384));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 16384));
-        attr = true;
-    }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 4>, 65536 + 16384); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 4>, 65536 + 16384); if (rc_) return rc_; }
     static const int use_w4 = getenv("SCD_SIM_W4") ? atoi(getenv("SCD_SIM_W4")) : 0;
     static const int sim_x = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
     static const int sim_nw = getenv("SCD_SIM_NW") ? atoi(getenv("SCD_SIM_NW")) : 8;
-    static bool attr4 = false;
-    if (use_w4 && !attr4) {
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        SCD_HIP(hipFuncSetAttribute((const void*)sim_topk_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr4 = true;
-    }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_w4_kernel<true>, 131072); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)sim_topk_w4_kernel<false>, 131072); if (rc_) return rc_; }
     if (use_w4 && mode == SCD_SIM_SOFTMAX) {
         sim_topk_w4_kernel<true><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
@@ -809,6 +805,27 @@ extern "C" int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_
     SCD_REQUIRE(h && in && out && r > 0 && c > 0, "scd_transpose_f16: bad arguments");
     transpose_f16_kernel<<<dim3((unsigned)scd_cdiv(c, 64), (unsigned)scd_cdiv(r, 64)), 256, 0, (hipStream_t)stream_>>>(
         (const half_t*)in, r, c, (half_t*)out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// out = fp16((a + b) / 2), elementwise: the "textual enhancement" feature of BASELINE configs[4] - the reference leaves
+// `logits = 100. * (clip_batch_feat @ zeroshot_weights + closed_text_feat @ zeroshot_weights) / 2` commented at
+// main_unsup.py:518,523,604,609; by linearity that is 100 * ((f + t) / 2) @ W, so the re-ranking is scd_sim_topk on the mean.
+__global__ void __launch_bounds__(256) mean2_f16_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, long long n8,
+                                                        half_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const half8 x = *(const half8*)(a + i * 8), y = *(const half8*)(b + i * 8);
+    half8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (half_t)(((float)x[q] + (float)y[q]) * 0.5f);
+    *(half8*)(out + i * 8) = o;
+}
+extern "C" int scd_mean2_f16(scd_handle h, const void* a, const void* b, int64_t n_elems, void* out, void* stream_) {
+    SCD_REQUIRE(h && a && b && out && n_elems > 0 && n_elems % 8 == 0, "scd_mean2_f16: bad arguments (n_elems must be a multiple of 8)");
+    mean2_f16_kernel<<<(unsigned)scd_cdiv(n_elems / 8, 256), 256, 0, (hipStream_t)stream_>>>((const half_t*)a, (const half_t*)b,
+                                                                                           n_elems / 8, (half_t*)out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

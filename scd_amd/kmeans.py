@@ -115,6 +115,8 @@ class KMeansEngine:
         self.pairwise_batch_size = pairwise_batch_size
         self.backend = backend
         self.group = group
+        if max_iterations < 1:
+            raise ValueError("max_iterations must be >= 1 (got %r)" % (max_iterations,))
         self.stats = {"estep_calls": 0, "refined_rows": 0}
 
     # ------------------------------------------------------------------ helpers
@@ -168,18 +170,20 @@ class KMeansEngine:
                 row = x.index_select(0, idx.clamp(min=0)).reshape(1, -1)
                 picks.append(idx)
             else:
-                tot = dd.allreduce_(be.sum_f32(d2))
+                # three dependent exchanges per centre (sum -> normalised prefix -> row), each ONE small all-gather, and no
+                # host synchronisation: prob = d2 / float32(total) needs the global total before the shard's probability
+                # mass, the pick needs every earlier shard's mass, and the next sum needs the picked row.
+                tot = dd.allgather(be.sum_f32(d2)).reshape(-1).sum().reshape(1)              # fixed rank order: same bits everywhere
                 _, ps = be.kpp_draw(d2, r, total=tot, want_idx=False, want_probsum=True)
                 allps = dd.allgather(ps).reshape(-1)
                 prefix = allps[: dd.rank].sum().reshape(1) if dd.rank > 0 else torch.zeros_like(ps)
                 idx, _ = be.kpp_draw(d2, r, total=tot, prefix=prefix.contiguous())
-                hits = dd.allgather(idx).reshape(-1)
-                owners = torch.nonzero(hits >= 0)
-                owner = int(owners[0]) if owners.numel() else -1
-                picks.append(torch.tensor([-1 if owner < 0 else 0], device=idx.device))
-                row = x.index_select(0, idx.clamp(min=0)).reshape(1, -1).contiguous()
-                if owner >= 0:
-                    dd.broadcast_(row, owner)
+                cand = x.index_select(0, idx.clamp(min=0)).reshape(-1)
+                pack = dd.allgather(torch.cat([(idx >= 0).to(torch.float32), cand]))          # [world, 1 + D]: (hit flag | row)
+                hit = pack[:, 0] > 0
+                firsthit = (hit & (torch.cumsum(hit.to(torch.int32), 0) == 1)).to(torch.int64)   # one-hot of the first owner
+                row = pack[:, 1:].index_select(0, firsthit.argmax().reshape(1))
+                picks.append(torch.where(hit.any(), 0, -1).reshape(1))
             buf[m] = row.reshape(-1)
             m += 1
             C = buf[:m]
@@ -248,6 +252,9 @@ class KMeansEngine:
         if data is None:
             data = be.prepare(X)
         x = data.x
+        if self.init != "k-means++" and self.group is not None:
+            # rows would be drawn from the LOCAL shard: every rank would start from different centres
+            raise NotImplementedError("init=%r is not shard-aware; use init='k-means++' with a process group" % (self.init,))
         if self.init == "k-means++":
             centers = self.kpp(x, k=self.k, random_state=random_state, data=data)
         elif self.init == "random":

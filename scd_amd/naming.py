@@ -30,6 +30,13 @@ def full_vocab_topk(clip_feats, zeroshot_weights, topk, softmax, wt=None):
     return ops.sim_topk(clip_feats, wt, topk, "softmax" if softmax else "raw", 100.0)
 
 
+def full_vocab_topk_te(clip_feats, text_feats, wt, topk, softmax):
+    """Top-k with textual enhancement (BASELINE configs[4]; README "Ours w/TE"): the released mains keep only the commented
+    formula `logits = 100. * (clip_batch_feat @ W + closed_text_feat @ W) / 2` (main_unsup.py:518,523).  By linearity it is
+    the plain similarity of the mean feature, so the same kernel re-ranks: one elementwise mean, then scd_sim_topk."""
+    return ops.sim_topk(ops.mean2_f16(clip_feats, text_feats), wt, topk, "softmax" if softmax else "raw", 100.0)
+
+
 def cluster_counters(name_idx, top_k, u_preds, clusters, m, known=None):
     keys, counts = ops.vote_hist(name_idx, top_k, u_preds, clusters, m, known)
     keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
@@ -133,3 +140,179 @@ def evaluate_semantic_acc(u_targets, cidx_to_cname, u_preds, cand_names):
     hits = np.bincount(row_name, weights=hit, minlength=len(intern))
     present = tot > 0
     return float((hits[present] / tot[present]).sum() / present.sum()), float(hit.sum() / len(hit))
+
+
+# ----------------------------------------------------------------------------- missing class names
+def match_missing_names(miss_names, nouns, wt, model, mode="top1", nouns_truncated=None, templates=None, miss_weights=None):
+    """Closest vocabulary name for every data-set class name that is not in the vocabulary.
+
+    mode "top1", nouns_truncated None   main_unsup.py:402-406 (cifar / aircraft): top-1 over the whole vocabulary
+    mode "top1", nouns_truncated given  main_unsup.py:487-491 (cub): top-1 over the names that are not class names
+    mode "greedy_top5"                  main_unsup.py:459-469 (sdogs + wikidog): top-5 over nouns_truncated, each class takes
+                                        its best name that no earlier class has taken
+    (the same code at main_ptsup.py:419-423, 477-487, 505-509).  wt = zeroshot_weights.T [V,512] fp16 on the device;
+    the text classifier of the missing names is built by zeroshot_classifier on the HIP text tower unless `miss_weights`
+    ([512, m]) is given.  Returns the list of matched names, one per missing name."""
+    if len(miss_names) == 0:
+        return []
+    if miss_weights is None:
+        from .local_utils.clip_lang_util import imagenet_templates, zeroshot_classifier
+        miss_weights = zeroshot_classifier(list(miss_names), templates or imagenet_templates, model)
+    f = miss_weights.t().contiguous().to(device=wt.device, dtype=torch.float16)                  # [m, 512]
+    if nouns_truncated is None:
+        pool, w_pool = nouns, wt
+    else:
+        first = _first_index(nouns)                                                                # nouns.index(n)
+        cols = torch.tensor([first[n] for n in nouns_truncated], dtype=torch.int64, device=wt.device)
+        pool, w_pool = nouns_truncated, ops.gather_rows_f16(wt, cols)
+    if mode == "top1":
+        idx, _ = ops.sim_topk(f, w_pool, 1, "raw", 100.0)
+        return [pool[i] for i in idx[:, 0].cpu().numpy().tolist()]
+    if mode != "greedy_top5":
+        raise ValueError("mode must be 'top1' or 'greedy_top5'")
+    top5 = ops.sim_topk(f, w_pool, 5, "raw", 100.0)[0].cpu().numpy()
+    matched = []
+    for i in range(len(miss_names)):
+        j = 0
+        idx = int(top5[i, j])
+        while pool[idx] in matched:
+            j += 1
+            idx = int(top5[i, j])                          # IndexError past the fifth name, like the reference
+        matched.append(pool[idx])
+    return matched
+
+
+def class_names_with_matches(class_to_idx, miss_names, matched_names):
+    """cidx_to_cname of main_unsup.py:407-412: a class keeps its name when the vocabulary has it, else the matched one."""
+    miss_names = list(miss_names)
+    out = {}
+    for name, idx in class_to_idx.items():
+        out[idx] = name if name not in miss_names else matched_names[miss_names.index(name)]
+    return out
+
+
+def resolve_class_names(dataset_name, corpus, class_to_idx, nouns, wt, model):
+    """The data-set branches of main_unsup.py:398-502 that need the text tower: `class_to_idx` {original class name: index}
+    (what the reference reads off its dataset objects) -> cidx_to_cname with every name inside the vocabulary."""
+    names = list(class_to_idx.keys())
+    miss = [n for n in names if n not in nouns]
+    if dataset_name in ('cifar10', 'cifar100', 'aircraft'):
+        matched = match_missing_names(miss, nouns, wt, model, "top1")
+    elif dataset_name == 'sdogs' and corpus == 'wikidog':
+        trunc = [n for n in nouns if n not in names]
+        matched = match_missing_names(miss, nouns, wt, model, "greedy_top5", nouns_truncated=trunc)
+    elif dataset_name == 'cub':
+        trunc = [n for n in nouns if n not in names]
+        matched = match_missing_names(miss, nouns, wt, model, "top1", nouns_truncated=trunc)
+    else:                                                   # imagenet_*: names come from the WordNet ids, none is missing
+        return {idx: name for name, idx in class_to_idx.items()}
+    print(f'Missed {len(miss)} names and matched {len(set(matched))} names ... ')
+    return class_names_with_matches(class_to_idx, miss, matched)
+
+
+# ----------------------------------------------------------------------------- zero-shot bounds of main_ptsup.py
+def _as_wt(zeroshot_weights):
+    """[512, V] classifier (any float dtype, host or device) -> name-major fp16 [V, 512] on the device."""
+    w = torch.as_tensor(zeroshot_weights)
+    if not w.is_cuda:
+        w = w.cuda()
+    return ops.transpose_f16(w.to(torch.float16).contiguous())
+
+
+def _as_feats(clip_feats):
+    f = torch.as_tensor(clip_feats)
+    if not f.is_cuda:
+        f = f.cuda()
+    return f.to(torch.float16).contiguous()
+
+
+def get_clip_preds_fast(clip_feats, targets, cidx_to_cname, nouns, zeroshot_weights):
+    """main_ptsup.py:78-99: argmax_name 100 * f @ W for every row (the targets only feed a tensor the reference never uses,
+    but an unknown class name still raises like its nouns.index)."""
+    first = _first_index(nouns)
+    for t in np.unique(np.asarray(targets)):
+        if cidx_to_cname[t] not in first:
+            raise ValueError("%r is not in list" % (cidx_to_cname[t],))
+    idx, _ = ops.sim_argmax(_as_feats(clip_feats), _as_wt(zeroshot_weights))
+    return idx
+
+
+def evaluate_semantic_acc_ub_lb(clip_feats, targets, cidx_to_cname, nouns, zeroshot_weights, return_top5=False):
+    """main_ptsup.py:102-129: top-1 accuracy (%) of the zero-shot classifier `zeroshot_weights` ([512, len(nouns)]) against
+    the vocabulary index of each row's class name - the lower bound with the full vocabulary, the upper bound with the
+    ground-truth names only (call sites :550-561)."""
+    first = _first_index(nouns)
+    t = np.asarray(targets)
+    tgt = torch.tensor([first[cidx_to_cname[x]] if cidx_to_cname[x] in first else nouns.index(cidx_to_cname[x]) for x in t],
+                       dtype=torch.int64).cuda()
+    wt = _as_wt(zeroshot_weights)
+    k = min(5, wt.shape[0])
+    idx, _ = ops.sim_topk(_as_feats(clip_feats), wt, k, "raw", 100.0)
+    hit = idx == tgt.view(-1, 1)
+    n = float(len(t))
+    top1 = float(hit[:, 0].sum().item()) / n * 100
+    if return_top5:
+        return top1, float(hit.sum().item()) / n * 100
+    return top1
+
+
+# ----------------------------------------------------------------------------- soft sACC (SURVEY.md 8f row N4)
+def calucate_dis_between_names(pred_name, target_name, wnid_to_synset, name_to_wnids):
+    """main_unsup.py:170-188 (the reference's spelling): max Leacock-Chodorow similarity over the synsets of two names."""
+    pred_wnids = name_to_wnids[pred_name]
+    target_wnids = name_to_wnids[target_name]
+    if 0 == len(pred_wnids):
+        print(f"pred_name: {pred_name}, {pred_wnids}")
+        return
+    elif 0 == len(target_wnids):
+        print(f"pred_name: {target_name}, {target_wnids}")
+        return
+    return max(wnid_to_synset[t].lch_similarity(wnid_to_synset[p]) for p in pred_wnids for t in target_wnids)
+
+
+def evaluate_soft_semantic_acc(u_targets, cidx_to_cname, u_preds, cand_names, wnid_to_synset, name_to_wnids, return_score=False,
+                               cache=None):
+    """main_unsup.py:191-199 / main_ptsup.py:208-219.  The reference walks WordNet once per SAMPLE (and the mains call this
+    three times per vote iteration); the score depends only on the (predicted name, target name) pair, so each distinct
+    pair - at most n_cluster x n_classes of them - is scored once and looked up per row.  `cache` (a dict) may be shared
+    between calls: the voting loop re-scores mostly the same pairs every iteration."""
+    t = np.asarray(u_targets)
+    p = np.asarray(u_preds.cpu() if hasattr(u_preds, "cpu") else u_preds).astype(np.int64).reshape(-1)
+    cache = {} if cache is None else cache
+    classes, t_inv = np.unique(t, return_inverse=True)
+    pair = t_inv.astype(np.int64) * len(cand_names) + p
+    upair, inv = np.unique(pair, return_inverse=True)
+    score = np.empty(len(upair), dtype=object)
+    for i, q in enumerate(upair.tolist()):
+        key = (cand_names[q % len(cand_names)], cidx_to_cname[classes[q // len(cand_names)]])
+        if key not in cache:
+            cache[key] = calucate_dis_between_names(key[0], key[1], wnid_to_synset, name_to_wnids)
+        score[i] = cache[key]
+    matched_all = score[inv]
+    matched_all = np.array(list(matched_all)) / max(matched_all)          # a missing synset (None) fails here, as in the reference
+    semantic_acc_all = sum(matched_all) / float(len(matched_all))
+    if not return_score:
+        return semantic_acc_all
+    return semantic_acc_all, matched_all
+
+
+# ----------------------------------------------------------------------------- feature extraction (row a2)
+def extract_feature(model, loader, args):
+    """main_unsup.py:114-147: loader yields (images, label, uq_idx, mask_lab) batches; features are L2-normalised inside the
+    encoder's last kernel and leave the device once, at the end (the reference copies and np.appends per batch)."""
+    train_classes = set(int(c) for c in args.train_classes)
+    feats, targets, mask_lab = [], [], []
+    for images, label, _, mask_lab_ in loader:
+        images = images.cuda()
+        if args.feat_model == 'clip':
+            f = model.visual.enc.encode_image(images, normalize=True)
+        elif hasattr(model, "features"):
+            f = model.features(images, normalize=True)
+        else:
+            f = ops.l2norm_rows(model(images).float())
+        feats.append(f)
+        targets.append(np.asarray(label.cpu().numpy() if hasattr(label, "cpu") else label, dtype=np.float64))
+        mask_lab.append(np.asarray(mask_lab_.cpu().numpy() if hasattr(mask_lab_, "cpu") else mask_lab_).astype(bool))
+    targets = np.concatenate(targets) if targets else np.array([])
+    return dict(all_feats=torch.cat(feats).cpu().numpy(), mask_lab=np.concatenate(mask_lab).astype(bool),
+                mask_cls=np.array([int(x) in train_classes for x in targets], dtype=bool), targets=targets)

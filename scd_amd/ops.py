@@ -10,15 +10,31 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, handle, ptr, stream_ptr, SCD_F16, SCD_F32, SIM_RAW, SIM_SOFTMAX
+from ._lib import check, ptr, SCD_F16, SCD_F32, SIM_RAW, SIM_SOFTMAX
 
 _L = _lib.load
+_dev = [None]           # device of the tensors of the op being issued: the handle and the stream follow the DATA, not torch's current device
 
 
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.ScdError(_lib.SCD_EINVAL, "tensor must live on the HIP device (got %s)" % t.device)
+    for t in ts:
+        if t is not None:
+            _dev[0] = t.device.index
+            break
+
+
+def handle():
+    return _lib.handle(_dev[0])
+
+
+def stream_ptr():
+    if _dev[0] is not None and _dev[0] != torch.cuda.current_device():
+        raise _lib.ScdError(_lib.SCD_EINVAL, "tensors live on cuda:%d but the current device is cuda:%d (use torch.cuda.device / "
+                            "set_device: kernels are launched on the current device's stream)" % (_dev[0], torch.cuda.current_device()))
+    return _lib.stream_ptr()
 
 
 def _ws(nbytes, device):
@@ -50,6 +66,16 @@ def gather_rows_f16(wt, idx):
     idx = idx.to(torch.int64).contiguous()
     out = torch.empty((idx.numel(), wt.shape[1]), dtype=torch.float16, device=wt.device)
     check(_L().scd_gather_rows_f16(handle(), ptr(wt), ptr(idx), idx.numel(), wt.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+def mean2_f16(a, b):
+    """fp16((a + b) / 2): the textual-enhancement feature (main_unsup.py:518 commented formula)."""
+    _need_cuda(a, b)
+    a, b = a.to(torch.float16).contiguous(), b.to(torch.float16).contiguous()
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    check(_L().scd_mean2_f16(handle(), ptr(a), ptr(b), a.numel(), ptr(out), stream_ptr()))
     return out
 
 
@@ -106,6 +132,7 @@ class KMeansData:
         return w
 
     def estep(self, centers, return_refined=False):
+        _need_cuda(self.x)
         k = centers.shape[0]
         centers = centers.to(torch.float32).contiguous()
         labels = torch.empty(self.n, dtype=torch.int32, device=self.x.device)
@@ -117,6 +144,7 @@ class KMeansData:
         return (labels, ref) if return_refined else labels
 
     def rowdist(self, centers, labels):
+        _need_cuda(self.x)
         centers = centers.to(torch.float32).contiguous()
         out = torch.empty(self.n, dtype=torch.float32, device=self.x.device)
         check(_L().scd_kmeans_rowdist(handle(), ptr(self.x), ptr(centers), ptr(labels), self.n, self.d, centers.shape[0],
@@ -124,10 +152,12 @@ class KMeansData:
         return out
 
     def min_update(self, c_new, d2):
+        _need_cuda(self.x)
         c_new = c_new.to(torch.float32).contiguous()
         check(_L().scd_kmeans_min_update(handle(), ptr(self.x), ptr(c_new), self.n, self.d, ptr(d2), stream_ptr()))
 
     def dist(self, centers, sqrt=False, with_cost=False):
+        _need_cuda(self.x)
         centers = centers.to(torch.float32).contiguous()
         k = centers.shape[0]
         out = torch.empty((self.n, k), dtype=torch.float32, device=self.x.device)
@@ -151,12 +181,38 @@ def kmeans_mstep(x, labels32, c_old, k, split=0):
     return sums, counts, inertia
 
 
-def kmeans_finalize(sums, counts, c_old=None):
+def kmeans_finalize(sums, counts, c_old=None, shift_mode=0):
+    """shift_mode 0: (sum_k ||dc_k||)^2 (the reference's SSKM test); 1: sum_k ||dc_k||^2 (sklearn's center_shift_tot)."""
+    _need_cuda(sums)
     k, d = sums.shape
     c = torch.empty((k, d), dtype=torch.float32, device=sums.device)
     shift = torch.zeros(1, dtype=torch.float64, device=sums.device)
-    check(_L().scd_kmeans_finalize(handle(), ptr(sums), ptr(counts), k, d, ptr(c_old), ptr(c), ptr(shift), stream_ptr()))
+    check(_L().scd_kmeans_finalize(handle(), ptr(sums), ptr(counts), k, d, ptr(c_old), ptr(c), ptr(shift), int(shift_mode),
+                                   stream_ptr()))
     return c, shift
+
+
+def labels_changed(a, b):
+    """Number of rows where two int32 label vectors differ (device int64[1])."""
+    _need_cuda(a, b)
+    out = torch.empty(1, dtype=torch.int64, device=a.device)
+    check(_L().scd_labels_changed(handle(), ptr(a), ptr(b), a.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+def kpp_searchsorted(d2, u):
+    """sklearn's k-means++ candidate draw: searchsorted(cumsum_f64(d2), u * float32(sum d2)) for every uniform in u (host
+    floats).  Returns (idx int64 [L] on the device, pot float64[1])."""
+    _need_cuda(d2)
+    uu = torch.as_tensor(np.asarray(u, dtype=np.float64)).to(d2.device)
+    idx = torch.empty(uu.numel(), dtype=torch.int64, device=d2.device)
+    pot = torch.empty(1, dtype=torch.float64, device=d2.device)
+    nb = _L().scd_kpp_draw_ws_bytes(d2.numel())
+    ws = _kpp_ws.get((d2.device, nb))
+    if ws is None:
+        ws = _kpp_ws[(d2.device, nb)] = _ws(nb, d2.device)
+    check(_L().scd_kpp_searchsorted(handle(), ptr(d2), d2.numel(), ptr(uu), uu.numel(), ptr(idx), ptr(pot), ptr(ws), nb, stream_ptr()))
+    return idx, pot
 
 
 def kpp_draw(d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
@@ -261,6 +317,7 @@ class Encoder:
     def __init__(self, desc, weights):
         self.desc = desc
         self.weights = weights              # list of tensors / None in the C order
+        _need_cuda(next(w for w in weights if w is not None))
         arr = (C.c_void_p * len(weights))(*[None if w is None else w.data_ptr() for w in weights])
         enc = C.c_void_p()
         d = _lib.EncoderDesc(**desc)

@@ -72,11 +72,14 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
                 kmeans=km)
 
 
-def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50):
-    """main_unsup.py:568-614 over row shards: the histogram is global (rows in (rank, row) = global order), so every
-    rank votes on the gathered int tables and re-classifies only its own rows."""
+def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50, be=None):
+    """main_unsup.py:568-614 over row shards.  The histogram is global, with rows in (rank, row) = global order, so the int64
+    top-k table is all-gathered once and the int predictions once per iteration (N_u * 8 B); every rank then computes the same
+    histograms and the same Munkres assignment (identical inputs -> identical names, no broadcast needed) and re-classifies
+    only its own rows.  `be` = the op set (default scd_amd.ops; tests/test_dist_gloo.py passes an oracle-backed stand-in)."""
     import copy
     from .local_utils.clip_lang_util import assign_name
+    be = be or ops
     g_idx, lens = _allgather_rows(name_idx, group)
     first = {}
     for j, n in enumerate(nouns):
@@ -88,7 +91,9 @@ def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, n
     while set(cur) != set(prev) and len(trace) < max_iter:
         g_preds, _ = _allgather_rows(u_preds, group)
         clusters = list(set(g_preds.cpu().numpy().tolist()))
-        c2c = naming.cluster_counters(g_idx, top_k, g_preds, clusters, m)
+        keys, counts = be.vote_hist(g_idx, top_k, g_preds, clusters, m)
+        keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
+        c2c = {c: naming.TopCounter(keys[i], counts[i]) for i, c in enumerate(clusters)}
         voted = []
         for i in clusters:
             voted += [c[0] for c in c2c[i].most_common(ncv)]
@@ -98,8 +103,8 @@ def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, n
         cur = [nouns[voted[x[1]]] for x in ind[:n_cluster]]
         cand = copy.deepcopy(cur)
         cols = torch.tensor([first[n] for n in cand], dtype=torch.int64, device=name_idx.device)
-        u_preds, _ = ops.sim_argmax(f_u, ops.gather_rows_f16(wt, cols))
-        trace.append(dict(cand=cols.cpu().numpy()))
+        u_preds, _ = be.sim_argmax(f_u, be.gather_rows_f16(wt, cols))
+        trace.append(dict(voted=np.array(voted, dtype=np.int64), ind=ind, cand=cols.cpu().numpy(), u_preds=u_preds.cpu().numpy()))
     return cand, u_preds.cpu().numpy(), trace
 
 

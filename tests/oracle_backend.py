@@ -75,3 +75,26 @@ class OracleBackend:
     def transport(self, cost, size_min, size_max):
         from scd_amd import ops
         return ops.transport_solve(cost, size_min, size_max)      # host C++ solver (no device needed)
+
+
+class OracleNamingOps:
+    """TEST-ONLY stand-in for the three naming ops pipeline.vote_loop_unsup_sharded calls (scd_amd.ops.vote_hist,
+    gather_rows_f16, sim_argmax), on the numpy oracle - so that the row-sharded vote can run under gloo on CPU."""
+
+    def vote_hist(self, name_idx, top_k, preds, clusters, m, known=None):
+        from oracle import naming_oracle as no
+        ref = no.cluster_counters(name_idx.numpy(), preds.numpy(), clusters, top_k, known=known)
+        keys = np.full((len(clusters), m), -1, dtype=np.int64)
+        counts = np.zeros((len(clusters), m), dtype=np.int32)
+        for i, c in enumerate(clusters):
+            for j, (a, b) in enumerate(ref[c].most_common(m)):
+                keys[i, j], counts[i, j] = a, b
+        return torch.from_numpy(keys), torch.from_numpy(counts)
+
+    def gather_rows_f16(self, wt, idx):
+        return wt[idx]
+
+    def sim_argmax(self, f, wsel_t, scale=100.0):
+        from oracle import naming_oracle as no
+        i, v = no.sim_argmax(f.numpy(), wsel_t.numpy().T, scale)
+        return torch.from_numpy(i), torch.from_numpy(v)

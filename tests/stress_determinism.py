@@ -4,6 +4,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scd_amd.clip as clip
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+clip.allow_synthetic()
 model, _ = clip.load("ViT-B/16", device="cuda")
 x = torch.randn(665, 3, 224, 224, generator=torch.Generator().manual_seed(11)).half().cuda()
 ref = model.encode_image(x).clone()

@@ -236,3 +236,41 @@ def test_evaluate_semantic_acc_matches_reference_restatement():
     ref = no.evaluate_semantic_acc(t.astype(np.float64), cidx_to_cname, p, cand)
     got = naming.evaluate_semantic_acc(t.astype(np.float64), cidx_to_cname, p, cand)
     assert got[0] == pytest.approx(ref[0], rel=1e-12) and got[1] == pytest.approx(ref[1], rel=1e-12)
+
+
+def test_soft_semantic_acc_memoised_equals_per_sample_loop():
+    """naming.evaluate_soft_semantic_acc scores each distinct (predicted name, target name) pair once; the
+    result must equal the reference's per-sample loop (main_unsup.py:170-199, restated here with a fake WordNet whose
+    lch_similarity counts its calls)."""
+    from scd_amd import naming
+    calls = {"n": 0}
+
+    class Syn:
+        def __init__(self, depth):
+            self.depth = depth
+
+        def lch_similarity(self, other):
+            calls["n"] += 1
+            return 3.6 - 0.1 * abs(self.depth - other.depth) - 0.01 * min(self.depth, other.depth)
+    rs = np.random.RandomState(9)
+    names = ["n%02d" % i for i in range(30)]
+    name_to_wnids = {n: ["w%s_%d" % (n, j) for j in range(1 + i % 3)] for i, n in enumerate(names)}
+    wnid_to_synset = {wid: Syn(rs.randint(1, 20)) for ws in name_to_wnids.values() for wid in ws}
+    cidx_to_cname = {float(c): names[c] for c in range(12)}
+    cand = [names[rs.randint(30)] for _ in range(15)]
+    t = rs.randint(0, 12, size=5000).astype(np.float64)
+    p = rs.randint(0, 15, size=5000)
+    # the reference's loop
+    ref = []
+    for ut, up in zip(t, p):
+        pn, tn = cand[up], cidx_to_cname[ut]
+        ref.append(max(wnid_to_synset[b].lch_similarity(wnid_to_synset[a]) for a in name_to_wnids[pn] for b in name_to_wnids[tn]))
+    ref = np.array(ref) / max(ref)
+    loop_calls, calls["n"] = calls["n"], 0
+    cache = {}
+    acc, scores = naming.evaluate_soft_semantic_acc(t, cidx_to_cname, p, cand, wnid_to_synset, name_to_wnids, return_score=True, cache=cache)
+    assert acc == pytest.approx(ref.sum() / len(ref), rel=1e-12) and np.allclose(scores.astype(float), ref)
+    assert calls["n"] < loop_calls / 10 and len(cache) <= 12 * 15
+    calls["n"] = 0
+    assert naming.evaluate_soft_semantic_acc(t[:100], cidx_to_cname, p[:100], cand, wnid_to_synset, name_to_wnids, cache=cache) > 0
+    assert calls["n"] == 0                                     # a second call over the same pairs walks nothing

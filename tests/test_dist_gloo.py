@@ -123,3 +123,61 @@ def test_sharded_vocabulary_allgather_keeps_name_order():
     names = ["name_%03d" % i for i in range(37)]
     ref = _stub_build(names, ["a {}.", "the {}."], None, 16).numpy()
     assert res[0].shape == (8, 37) and np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
+
+
+def _vote_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle_backend import OracleNamingOps
+        from scd_amd import pipeline
+        f, w, nouns, idx, preds0, k = _vote_case()
+        cut = 700                                                    # uneven row shards
+        sl = slice(0, cut) if rank == 0 else slice(cut, None)
+        cand, up, tr = pipeline.vote_loop_unsup_sharded(torch.from_numpy(idx[sl]), torch.from_numpy(preds0[sl]), torch.from_numpy(f[sl]),
+                                                        torch.from_numpy(np.ascontiguousarray(w.T)), nouns, k, 10, 2, dist.group.WORLD,
+                                                        be=OracleNamingOps())
+        q.put((rank, cand, up, [(t["voted"], t["ind"], t["cand"]) for t in tr]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _vote_case():
+    from oracle import naming_oracle as no, synth
+    n, d, k, v = 1200, 64, 12, 400
+    x, y, cent = synth.clustered_features(n, d, k, seed=31, center_seed=32, noise=0.9)
+    w = synth.vocabulary(v, d, cent, seed=33, jitter=0.5)
+    f = x.astype(np.float16)
+    idx, _ = no.sim_topk(f, w, 5, "softmax")
+    rs = np.random.RandomState(35)
+    preds0 = np.where(rs.rand(n) < 0.8, (y * 7 + 2) % k, rs.randint(0, k, size=n))
+    return f, w, synth.nouns_list(v), idx, preds0, k
+
+
+def test_sharded_vote_loop_equals_single_process():
+    """pipeline.vote_loop_unsup_sharded over two row shards = the single-process oracle loop (main_unsup.py:568-614): same voted
+    lists, assignments and candidate names on every iteration, and each rank's re-classified rows are its slice of the global
+    predictions."""
+    from oracle import naming_oracle as no
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_vote_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, cand, up, tr = q.get(timeout=300)
+        res[r] = (cand, up, tr)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f, w, nouns, idx, preds0, k = _vote_case()
+    otr = no.vote_loop_unsup(idx, preds0, f, w, nouns, k, 5, 10, 2)
+    assert res[0][0] == res[1][0] == [nouns[c] for c in otr[-1]["cand"]]
+    assert len(res[0][2]) == len(res[1][2]) == len(otr)
+    for r in (0, 1):
+        for (voted, ind, cand), o in zip(res[r][2], otr):
+            assert np.array_equal(voted, o["voted"]) and np.array_equal(ind, o["ind"]) and np.array_equal(cand, o["cand"])
+    assert np.array_equal(np.concatenate([res[0][1], res[1][1]]), otr[-1]["u_preds"])

@@ -284,11 +284,37 @@ def test_sskm_matches_reference_golden(ops, golden, tag):
     assert abs(float(km2.inertia_) - float(g[tag + "_fit_inertia"])) <= 1e-5 * float(g[tag + "_fit_inertia"])
 
 
-def test_constrained_matches_reference_golden(ops, golden):
+def _record_transport(monkeypatch):
+    """Record every (cost, size bounds, labels, total) the constrained E-step hands to scd_transport_solve."""
+    from scd_amd import ops as o
+    calls = []
+    real = o.transport_solve
+
+    def spy(cost, size_min, size_max):
+        lab, tot = real(cost, size_min, size_max)
+        calls.append((np.array(cost, copy=True), size_min, size_max, lab.copy(), tot))
+        return lab, tot
+    monkeypatch.setattr(o, "transport_solve", spy)
+    return calls
+
+
+def _unique_optimum(cost, smin, smax, labels, ops):
+    """True when three random tie-breaking perturbations of the costs (cost * 4096 + r, r < 8) all give `labels` back:
+    the optimum is then unique (with overwhelming probability), so every exact solver must return these labels."""
+    for seed in range(3):
+        r = np.random.RandomState(100 + seed).randint(0, 8, size=cost.shape)
+        lab, _ = ops.transport_solve((cost.astype(np.int64) * 4096 + r).astype(np.int32), smin, smax)
+        if not np.array_equal(lab, labels):
+            return False
+    return True
+
+
+def test_constrained_matches_reference_golden(ops, golden, monkeypatch):
     from scd_amd.local_utils.sskm_constrained import K_Means, _labels_constrained
     g = golden("kmeans_constrained.npz")
     n, d, k, seed = g["m_shape"].tolist()
     x, y, mask_lab = synth.blob_case(n, d, k, seed)
+    calls = _record_transport(monkeypatch)
     km = K_Means(k=k, tolerance=1e-4, max_iterations=5, init="k-means++", size_min=30, size_max=80, n_init=2,
                  random_state=5, n_jobs=None, pairwise_batch_size=128)
     km.fit_mix(dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab]))
@@ -296,7 +322,18 @@ def test_constrained_matches_reference_golden(ops, golden):
     cnt = np.bincount(lab[mask_lab.sum():], minlength=k)
     assert cnt.min() >= 30 and cnt.max() <= 80
     assert abs(float(km.inertia_) - float(g["m_inertia"])) <= 1e-3 * float(g["m_inertia"])
-    assert (lab != g["m_labels"]).mean() < 0.02                   # flow optimum is not unique under cost ties
+    # every flow problem of the run (one per Lloyd iteration and restart) was solved EXACTLY: feasible, total cost equal to the
+    # LP optimum, no improving move left; where the optimum is unique the labels are the LP's labels too.  (The reference's
+    # OR-Tools labels are unpinned - third-party solver absent - and its optimum is not unique under integer cost ties.)
+    assert len(calls) >= 2
+    n_unique = 0
+    for cost, smin, smax, labs, tot in calls:
+        ok, tot_chk = to.check_assignment(cost, labs, smin, smax)
+        lp_lab, lp_tot = to.solve_lp(cost, smin, smax)
+        assert ok and tot == tot_chk == lp_tot and to.check_optimal(cost, labs, smin, smax)
+        if _unique_optimum(cost, smin, smax, labs, ops):
+            n_unique += 1
+            assert np.array_equal(labs, lp_lab)
     # the 6-point docstring example of the vendored estimator (k_means_constrained_.py:777-793)
     km6 = K_Means(k=2, size_min=2, size_max=5, random_state=0, n_init=10, max_iterations=100)
     km6.fit(dev(g["kat_x"]))
@@ -308,6 +345,56 @@ def test_constrained_matches_reference_golden(ops, golden):
     assert int(cost[np.arange(len(lab2)), lab2].sum()) == int(g["a_total"])
     with pytest.raises(Exception, match="min cost flow"):
         _labels_constrained(None, None, np.ones((5, 2), dtype=np.float32), 3, 5, np.zeros(5, dtype=np.float32))
+
+
+def test_constrained_tie_free_instance_labels_equal_oracle(ops, monkeypatch):
+    """Label parity where it is well defined: features scaled by 400 spread the integer costs round(1000 * dist) over ~1e6
+    values, so every flow problem of the run has a unique optimum (checked by perturbation) and the HIP path must return the
+    oracle's (LP) labels on every iteration - hence the same centres, inertia and final labels."""
+    from scd_amd.local_utils.sskm_constrained import K_Means
+    x, y, mask_lab = synth.blob_case(420, 12, 5, 33)
+    x = (x * 400.0).astype(np.float32)
+    calls = _record_transport(monkeypatch)
+    km = K_Means(k=5, tolerance=1e-4, max_iterations=6, init="k-means++", size_min=60, size_max=75, n_init=2, random_state=3,
+                 pairwise_batch_size=128)
+    km.fit_mix(dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab]))
+    for cost, smin, smax, labs, tot in calls:
+        assert _unique_optimum(cost, smin, smax, labs, ops)
+        assert np.array_equal(labs, to.solve_lp(cost, smin, smax)[0])
+    okm = to.K_Means(k=5, tolerance=1e-4, max_iterations=6, size_min=60, size_max=75, n_init=2, random_state=3)
+    okm.fit_mix(x[~mask_lab], x[mask_lab], y[mask_lab])
+    assert np.array_equal(km.labels_.cpu().numpy(), okm.labels_)
+    assert np.array_equal(km.cluster_centers_.cpu().numpy(), okm.cluster_centers_)
+    assert float(km.inertia_) == float(okm.inertia_)
+    cnt = np.bincount(km.labels_.cpu().numpy()[mask_lab.sum():], minlength=5)
+    assert cnt.min() >= 60 and cnt.max() <= 75 and ((cnt == 60).any() or (cnt == 75).any())      # the bounds bind
+
+
+def test_constrained_c3_size(ops, monkeypatch):
+    """BASELINE configs[2] (Stanford Dogs pt-sup): N_l = 3k + N_u = 9k rows, D = 768, K = 120, size_min / size_max = 50 / 1000
+    (main_ptsup.py:239-240).  Every flow problem solved exactly (feasible + no negative residual cycle), sizes within bounds,
+    labelled rows keep their classes."""
+    from scd_amd.local_utils.sskm_constrained import K_Means
+    n, d, k = 12000, 768, 120
+    x, y, _ = synth.clustered_features(n, d, k, seed=61, center_seed=62, noise=0.9)
+    mask_lab = (y < k // 2) & (np.random.RandomState(63).rand(n) < 0.5)
+    order = np.concatenate([np.nonzero(mask_lab)[0], np.nonzero(~mask_lab)[0]])
+    x, y = x[order], y[order]
+    n_l = int(mask_lab.sum())
+    calls = _record_transport(monkeypatch)
+    km = K_Means(k=k, tolerance=1e-4, max_iterations=3, init="k-means++", size_min=50, size_max=1000, n_init=1, random_state=0,
+                 pairwise_batch_size=1024)
+    km.fit_mix(dev(x[n_l:]), dev(x[:n_l]), dev(y[:n_l]))
+    lab = km.labels_.cpu().numpy()
+    assert len(calls) >= 1 and calls[0][0].shape == (n - n_l, k)
+    for cost, smin, smax, labs, tot in calls:
+        ok, tot_chk = to.check_assignment(cost, labs, smin, smax)
+        assert ok and tot == tot_chk and to.check_optimal(cost, labs, smin, smax)
+    cnt = np.bincount(lab[n_l:], minlength=k)
+    assert cnt.min() >= 50 and cnt.max() <= 1000
+    classes = np.unique(y[:n_l])
+    assert np.array_equal(lab[:n_l], np.searchsorted(classes, y[:n_l]))
+    assert (lab[n_l:][y[n_l:] < k // 2] == y[n_l:][y[n_l:] < k // 2]).mean() > 0.9     # old classes land on their class ids
 
 
 # ----------------------------------------------------------------------------------------------- similarity / vote
@@ -457,6 +544,7 @@ def test_zeroshot_classifier_pooling(ops):
     from scd_amd.clip import weights as W
     from scd_amd.clip.model import CLIP
     import scd_amd.clip as clip
+    clip.allow_synthetic()
     sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(t_layers=2), visual=False)
     model = CLIP(sd).cuda()
     names = ["red_fox", "tabby", "kit_fox", "zebra", "grey_whale"]
@@ -508,9 +596,373 @@ def test_main_unsup_and_ptsup_synthetic(ops, monkeypatch):
     mu = importlib.import_module("main_unsup")
     cand, u_preds = mu.main()
     assert len(cand) == 8 and set(int(c.split("_")[1]) for c in cand) == set(range(8))      # the planted names are found
+    # the shipped default of scripts/evaluate_unsupervised.sh: --cluster KM, on the device (no host sklearn)
+    cand, u_preds = mu.main(["--synthetic", "true", "--synthetic_images", "1536", "--synthetic_vocab", "600", "--n_cluster", "8",
+                             "--cluster", "KM", "--topk", "3", "--num_common_vote", "10", "--num_common_linear", "2"])
+    assert set(int(c.split("_")[1]) for c in cand) == set(range(8))
     monkeypatch.setattr(sys, "argv", ["main_ptsup.py", "--synthetic", "true", "--synthetic_images", "1536", "--synthetic_vocab", "600",
                                       "--n_cluster", "8", "--cluster", "ConSSKM", "--cluster_size_min", "50", "--cluster_size_max", "400",
                                       "--topk", "5", "--num_common_vote", "10", "--num_common_linear", "2"])
     mp_ = importlib.import_module("main_ptsup")
     cand, u_preds = mp_.main()
     assert set(int(c.split("_")[1]) for c in cand) == set(range(8))
+
+
+# ----------------------------------------------------------------------------------------------- --cluster KM (sklearn KMeans)
+@pytest.mark.parametrize("tag", ["a", "b", "c", "e"])
+def test_sklearn_kmeans_lloyd_matches_sklearn(ops, golden, tag):
+    """scd_amd.cluster.KMeans from an explicit init against scikit-learn 1.7.2's own labels (golden) and the oracle."""
+    from scd_amd.cluster import KMeans
+    g = golden("kmeans_sklearn.npz")
+    n, d, k, seed = g[tag + "_shape"].tolist()
+    x, _, _ = synth.clustered_features(n, d, k, seed=seed, center_seed=seed + 40, noise=float(g[tag + "_noise"]))
+    km = KMeans(n_clusters=k, init=g[tag + "_init"], n_init=1, algorithm="lloyd", random_state=0).fit(x)
+    assert km.labels_.dtype == np.int32 and np.array_equal(km.labels_, g[tag + "_labels"])
+    assert km.n_iter_ == int(g[tag + "_n_iter"])
+    assert abs(km.inertia_ - float(g[tag + "_inertia"])) <= 1e-5 * float(g[tag + "_inertia"])
+    assert np.allclose(km.cluster_centers_, g[tag + "_centers"], rtol=1e-5, atol=1e-6)
+    olab, oin, ocent, oit = ko.sklearn_lloyd(x, g[tag + "_init"])
+    assert np.array_equal(km.labels_, olab) and np.array_equal(km.cluster_centers_, ocent) and km.n_iter_ == oit
+
+
+def test_sklearn_kmeans_seeding_and_default_call(ops):
+    """`KMeans(n_clusters, random_state=0).fit(u_feats).labels_` (main_unsup.py:362): the greedy k-means++ consumes the
+    RandomState like sklearn and picks the oracle's rows; the full call recovers planted blobs."""
+    from scd_amd.cluster import KMeans
+    from scd_amd import ops as o
+    x, y, _ = synth.clustered_features(3000, 64, 12, seed=71, center_seed=72, noise=0.7)
+    km = KMeans(n_clusters=12, random_state=0)
+    data = o.KMeansData(dev(x))
+    cent = km._kpp(data, ko.check_random_state(0)).cpu().numpy()
+    picks = ko.sklearn_kpp(x, 12, 0)
+    assert np.array_equal(cent, x[picks])
+    labels = KMeans(n_clusters=12, random_state=0).fit(x).labels_
+    from oracle import naming_oracle as no_
+    acc, _, _ = no_.split_cluster_acc_v2(y, labels, y < 6)
+    assert acc > 0.95
+    sk = None
+    try:
+        from sklearn.cluster import KMeans as SK
+        sk = SK(n_clusters=12, random_state=0, n_init=1).fit(x)
+    except Exception:
+        pass
+    if sk is not None:                                   # same algorithm, same stream: the host's sklearn finds the same partition
+        assert abs(sk.inertia_ - KMeans(n_clusters=12, random_state=0).fit(x).inertia_) <= 0.05 * sk.inertia_
+
+
+# ----------------------------------------------------------------------------------------------- pt-sup vote loop
+def test_vote_loop_ptsup_matches_reference_trace(ops, golden):
+    """naming.vote_loop_ptsup (HIP) on the vp_* inputs of the golden: per iteration voted / ind / cand / u_preds /
+    unlab_cluster_idx equal the oracle's on the same fp16-rounded inputs, and the reference's own trace at convergence
+    (main_ptsup.py:629-676).  set-of-str order (:664) depends on the hash seed the golden was recorded under: replay there."""
+    import subprocess
+    import sys
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        env = dict(os.environ, PYTHONHASHSEED="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k", "test_vote_loop_ptsup_matches_reference_trace"],
+                           env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return
+    from scd_amd import naming
+    g = golden("naming.npz")
+    k, n_lab, topk, ncv, ncl = g["vp_cfg"].tolist()
+    f, w = g["tk_x"].astype(np.float16), g["tk_w"].astype(np.float16)
+    nouns = synth.nouns_list(w.shape[1])
+    mask_lab = g["vp_mask_lab"]
+    lab_names = [nouns[c] for c in range(n_lab)]
+    wt = ops.transpose_f16(dev(w))
+    fh = dev(f)
+    idx, _ = naming.full_vocab_topk(fh, None, 5, False, wt=wt)                      # TOP_K = 5, raw logits (:526-545)
+    oidx, _ = no.sim_topk(f, w, 5, "raw")
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    m = dev(~mask_lab)
+    cand, up, tr = naming.vote_loop_ptsup(idx[m], g["vp_all_preds0"], mask_lab, fh[m], wt, nouns, lab_names, k, topk, ncv, ncl)
+    otr = no.vote_loop_ptsup(oidx[~mask_lab], g["vp_all_preds0"], mask_lab, f[~mask_lab], w, nouns, lab_names, k, topk, ncv, ncl)
+    assert len(tr) == len(otr) >= 1
+    for a, b in zip(tr, otr):
+        for key in ("voted", "ind", "cand", "u_preds", "unlab_cluster_idx"):
+            assert np.array_equal(a[key], b[key]), key
+    last = int(g["vp_iters"]) - 1
+    assert set(tr[-1]["cand"].tolist()) == set(g["vp_cand_%d" % last].tolist())
+    assert (tr[-1]["u_preds"] == g["vp_preds_%d" % last]).mean() > 0.995
+
+
+# ----------------------------------------------------------------------------------------------- BASELINE configs[3] / [4] shapes
+@pytest.mark.parametrize("ncv,ncl", [(10, 2), (20, 4)])
+def test_c4_shape_vote_k1000(ops, ncv, ncl):
+    """BASELINE configs[3] per-GPU shard: N = 160,146 rows, D = 512, K = 1000 clusters, V = 21,000 names; num_common_vote 10 / 20
+    -> assign_name on D = 10,000-20,000 (scd_munkres_sparse).  Checked per vote iteration: the device histograms equal the
+    oracle's Counters on sampled clusters, the voted list equals the oracle's, the assignment is a permutation whose weight is
+    the optimum (scipy on the K x names block), the re-classification equals the oracle on sampled rows."""
+    import time
+    from scipy.optimize import linear_sum_assignment
+    from scd_amd import naming
+    n, d, k, v = 160146, 512, 1000, 21000
+    x, y, cent = synth.clustered_features(n, d, k, seed=81, center_seed=82, noise=1.0)
+    w = synth.vocabulary(v, d, cent, seed=83, jitter=0.6)
+    nouns = synth.nouns_list(v)
+    f16 = x.astype(np.float16)
+    fh, wt = dev(f16), ops.transpose_f16(dev(w))
+    idx, _ = naming.full_vocab_topk(fh, None, 3, True, wt=wt)
+    rs = np.random.RandomState(84)
+    preds0 = np.where(rs.rand(n) < 0.85, y, rs.randint(0, k, size=n))
+    seen = []
+
+    def on_iter(it, cand, u_preds):
+        seen.append(time.time())
+    t0 = time.time()
+    cand, up, tr = naming.vote_loop_unsup(idx, preds0, fh, wt, nouns, k, ncv, ncl, on_iter=on_iter, max_iter=6)
+    assert len(tr) >= 1 and (time.time() - t0) / len(tr) < 30.0                 # Munkres at D = 10k-20k is not an Amdahl wall
+    name_idx = idx.cpu().numpy()
+    u_prev = preds0
+    for t in tr[:2]:
+        clusters = list(set(u_prev.tolist()))
+        sample = clusters[:: max(1, len(clusters) // 40)]
+        ref = no.cluster_counters(name_idx, u_prev, sample, 5)
+        keys, counts = ops.vote_hist(idx, 3, dev(u_prev), sample, max(ncv, ncl))
+        keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
+        for i, c in enumerate(sample):
+            got = [(int(a), int(b)) for a, b in zip(keys[i], counts[i]) if a >= 0]
+            assert got == [(int(a), int(b)) for a, b in ref[c].most_common(max(ncv, ncl))], c
+        full = naming.cluster_counters(idx, 3, dev(u_prev), clusters, max(ncv, ncl))
+        voted = []
+        for c in clusters:
+            voted += [a for a, _ in full[c].most_common(ncv)]
+        voted = list(set(voted))
+        assert np.array_equal(t["voted"], np.array(voted, dtype=np.int64))
+        dd = max(len(voted), len(clusters))
+        ind = t["ind"]
+        assert ind.shape == (dd, 2) and np.array_equal(ind[:, 0], np.arange(dd)) and len(set(ind[:, 1].tolist())) == dd
+        col = {u: j for j, u in enumerate(voted)}
+        wsm = np.zeros((len(clusters), dd), dtype=np.int64)
+        for i, c in enumerate(clusters):
+            for a, b in full[c].most_common(ncl):
+                wsm[i, col[a]] += b
+        r_, c_ = linear_sum_assignment(wsm, maximize=True)
+        assert int(wsm[np.arange(len(clusters)), ind[:len(clusters), 1]].sum()) == int(wsm[r_, c_].sum())
+        rows = rs.choice(n, 1024, replace=False)
+        oi, _ = no.sim_argmax(f16[rows], w[:, t["cand"]])
+        assert np.array_equal(t["u_preds"][rows], oi)
+        u_prev = t["u_preds"]
+    names_found = len(set(int(c.split("_")[1]) for c in cand) & set(range(k)))
+    assert names_found > 0.9 * k
+
+
+def test_sim_topk_v100k(ops):
+    """BASELINE configs[4]: V = 100,000 names.  256 rows against the oracle; then the C2-sized image set (126,976 rows) through
+    size-independent properties: sampled rows equal the oracle, values sorted, planted names found."""
+    v, d, k = 100000, 512, 100
+    x, y, cent = synth.clustered_features(126976, d, k, seed=91, center_seed=92, noise=0.9)
+    w = synth.vocabulary(v, d, cent, seed=93, jitter=0.4)
+    f16 = x.astype(np.float16)
+    wt = ops.transpose_f16(dev(w))
+    for mode in ("raw", "softmax"):
+        idx, val = ops.sim_topk(dev(f16[:256]), wt, 5, mode)
+        oi, ov = no.sim_topk(f16[:256], w, 5, mode)
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.allclose(val.cpu().numpy(), ov, rtol=2e-4, atol=1e-6)
+    idx, val, fb = ops.sim_topk(dev(f16), wt, 5, "raw", return_fallback=True)
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert (np.diff(val, axis=1) <= 0).all() and idx.min() >= 0 and idx.max() < v
+    assert (idx[:, 0] == y).mean() > 0.98 and int(fb.item()) < len(x) // 100
+    rows = np.random.RandomState(0).choice(len(x), 300, replace=False)
+    oi, _ = no.sim_topk(f16[rows], w, 5, "raw")
+    assert np.array_equal(idx[rows], oi)
+
+
+def test_textual_enhancement_rerank(ops):
+    """BASELINE configs[4] 'textual-enhancement re-ranking': logits = 100 * (f @ W + t @ W) / 2 (the formula the reference
+    leaves commented at main_unsup.py:518,523,604,609) = 100 * mean(f, t) @ W: one elementwise mean (fp16, rounded once), then
+    the same exact top-k."""
+    from scd_amd import naming
+    v, d, k = 5000, 512, 40
+    x, y, cent = synth.clustered_features(3000, d, k, seed=95, center_seed=96, noise=1.1)
+    t, _, _ = synth.clustered_features(3000, d, k, seed=95, center_seed=96, noise=0.5)       # same classes, cleaner features
+    w = synth.vocabulary(v, d, cent, seed=98, jitter=0.5)
+    f16, t16 = x.astype(np.float16), t.astype(np.float16)
+    wt = ops.transpose_f16(dev(w))
+    g16 = ((f16.astype(np.float32) + t16.astype(np.float32)) * np.float32(0.5)).astype(np.float16)
+    assert np.array_equal(ops.mean2_f16(dev(f16), dev(t16)).cpu().numpy(), g16)
+    for softmax in (False, True):
+        idx, val = naming.full_vocab_topk_te(dev(f16), dev(t16), wt, 5, softmax=softmax)
+        oi, ov = no.sim_topk(g16, w, 5, "softmax" if softmax else "raw")
+        assert np.array_equal(idx.cpu().numpy(), oi)
+        assert np.allclose(val.cpu().numpy(), ov, rtol=2e-4, atol=1e-6)
+    plain, _ = naming.full_vocab_topk(dev(f16), None, 5, False, wt=wt)
+    assert (idx[:, 0].cpu().numpy() == y).mean() >= (plain[:, 0].cpu().numpy() == y).mean()      # the text term helps
+
+
+# ----------------------------------------------------------------------------------------------- a7, zero-shot bounds, caches
+def test_match_missing_names_golden_and_oracle(ops, golden):
+    """Row a7 (main_unsup.py:402-406, 487-491, 459-469): HIP path = oracle on the same fp16 inputs = the reference's own lines
+    (golden, fp32 inputs) - top-1 over the vocabulary, top-1 over the truncated vocabulary, greedy de-duplicated top-5."""
+    from scd_amd import naming
+    g = golden("naming.npz")
+    w, mw = g["mm_w"].astype(np.float16), g["mm_miss_w"].astype(np.float16)
+    nouns = synth.nouns_list(w.shape[1])
+    wt = ops.transpose_f16(dev(w))
+    miss = ["miss_%d" % i for i in range(mw.shape[1])]
+    original = [nouns[c] for c in g["mm_class_cols"].tolist()] + miss
+    trunc = [n for n in nouns if n not in original]
+    got = [naming.match_missing_names(miss, nouns, wt, None, "top1", miss_weights=dev(mw)),
+           naming.match_missing_names(miss, nouns, wt, None, "top1", nouns_truncated=trunc, miss_weights=dev(mw)),
+           naming.match_missing_names(miss, nouns, wt, None, "greedy_top5", nouns_truncated=trunc, miss_weights=dev(mw))]
+    want = [no.match_missing_names(mw, w, nouns, None, "top1"), no.match_missing_names(mw, w, nouns, trunc, "top1"),
+            no.match_missing_names(mw, w, nouns, trunc, "greedy_top5")]
+    assert got == want
+    for names, key in zip(got, ("mm_top1_full", "mm_top1_trunc", "mm_greedy5_trunc")):
+        assert [nouns.index(n) for n in names] == g[key].tolist(), key
+    assert got[2][3] != got[0][3] and len(set(got[2])) == len(got[2])          # the fourth class had to take its second choice
+    cidx = naming.class_names_with_matches({n: i for i, n in enumerate(original)}, miss, got[0])
+    assert [cidx[i] for i in range(len(original))] == original[:4] + got[0]
+    # a duplicate vocabulary entry: `nouns.index` semantics (first occurrence) when the truncated columns are gathered
+    nouns2 = list(nouns)
+    nouns2[21] = nouns2[3]
+    trunc2 = [n for n in nouns2 if n not in original]
+    assert naming.match_missing_names(miss, nouns2, wt, None, "top1", nouns_truncated=trunc2, miss_weights=dev(mw)) == \
+        no.match_missing_names(mw, w, nouns2, trunc2, "top1")
+
+
+def test_match_missing_names_through_text_tower(ops):
+    """The same call with the classifier of the missing names built on the HIP text tower (zeroshot_classifier, 80 templates)."""
+    from scd_amd import naming
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    import scd_amd.clip as clip
+    from scd_amd.local_utils import clip_lang_util as clu
+    clip.allow_synthetic()
+    model = CLIP(W.synthetic_clip_state_dict(seed=0, cfg=dict(t_layers=2), visual=False)).cuda()
+    nouns = ["red_fox", "tabby", "kit_fox", "zebra", "grey_whale", "ox", "heron", "pug", "lynx", "newt"]
+    zw = clu.zeroshot_classifier(nouns, clu.imagenet_templates, model)
+    wt = ops.transpose_f16(zw)
+    miss = ["arctic_fox", "sea_lion"]
+    got = naming.match_missing_names(miss, nouns, wt, model, "top1")
+    mw = clu.zeroshot_classifier(miss, clu.imagenet_templates, model)
+    assert got == no.match_missing_names(mw.cpu().numpy(), zw.cpu().numpy(), nouns, None, "top1")
+    cidx = naming.resolve_class_names("cifar10", "wordnet", {"zebra": 0, "arctic_fox": 1, "sea_lion": 2}, nouns, wt, model)
+    assert cidx == {0: "zebra", 1: got[0], 2: got[1]}
+
+
+def test_zero_shot_bounds_and_cidx_names(ops):
+    from scd_amd import naming
+    v, d, k = 700, 512, 9
+    x, y, cent = synth.clustered_features(1500, d, k, seed=41, center_seed=42, noise=1.0)
+    w = synth.vocabulary(v, d, cent, seed=43, jitter=0.6)
+    nouns = synth.nouns_list(v)
+    cidx = {c: nouns[c] for c in range(k)}
+    f16 = x.astype(np.float16)
+    lg = 100.0 * f16.astype(np.float64) @ w.astype(np.float64)
+    t_idx = np.array([nouns.index(cidx[int(t)]) for t in y])
+    want1 = no.accuracy(lg, t_idx, topk=(1, 5))
+    top1, top5 = naming.evaluate_semantic_acc_ub_lb(f16, y.astype(np.float64), {float(c): n for c, n in cidx.items()}, nouns, w, return_top5=True)
+    assert top1 == pytest.approx(want1[0] / len(y) * 100) and top5 == pytest.approx(want1[1] / len(y) * 100)
+    cand = [nouns[c] for c in range(k)]
+    wsel = w[:, :k]
+    ub = naming.evaluate_semantic_acc_ub_lb(dev(f16), y, cidx, cand, dev(wsel))
+    assert ub == pytest.approx(float((lg[:, :k].argmax(1) == y).mean() * 100))
+    preds = naming.get_clip_preds_fast(f16, y, cidx, nouns, w).cpu().numpy()
+    assert np.array_equal(preds, lg.argmax(1))
+
+
+def _write_cache_tree(root, n=1600, k=8, v=500, seed=51):
+    """The reference's on-disk boundary: feature dicts (main_unsup.py:141-146), the [512, V] classifier
+    (:389-394), the vocabulary file get_nouns reads (clip_lang_util.py:139-149), a class-name table and a CLIP checkpoint."""
+    import json
+    from scd_amd.clip import weights as W
+    x, y, cent = synth.clustered_features(n, 512, k, seed=seed, center_seed=seed + 1, noise=0.9)
+    perm, mask_lab = synth.labelled_split(y, k, prop=0.5, seed=seed + 2)
+    x, y = x[perm], y[perm]
+    w = synth.vocabulary(v, 512, cent, seed=seed + 3, jitter=0.4)
+    nouns = ["noun-%03d" % i for i in range(v)]                   # get_nouns output is lower-cased and '-' -> '_' by the mains
+    os.makedirs(os.path.join(root, "extracted_features"))
+    os.makedirs(os.path.join(root, "zeroshot_weights"))
+    os.makedirs(os.path.join(root, "data"))
+    os.makedirs(os.path.join(root, "clip"))
+    feats = dict(all_feats=x.astype(np.float32), mask_lab=mask_lab, mask_cls=(y < k // 2), targets=y.astype(np.float64))
+    torch.save(feats, os.path.join(root, "extracted_features", "dino_vit_cifar10_all.pt"))
+    torch.save(dict(feats, all_feats=x.astype(np.float16)), os.path.join(root, "extracted_features", "clip_cifar10_all.pt"))
+    torch.save(torch.from_numpy(w), os.path.join(root, "zeroshot_weights", "zeroshot_weights_all_nouns_vit_b_16.pt"))
+    with open(os.path.join(root, "data", "wordnet_all_noun.txt"), "w") as f:
+        f.write("\n".join(nouns) + "\n")
+    # classes 0..k-2 carry vocabulary names, the last one a name the vocabulary lacks (row a7 runs on the text tower)
+    class_to_idx = {("noun_%03d" % c if c < k - 1 else "not_a_noun"): c for c in range(k)}
+    with open(os.path.join(root, "class_names.json"), "w") as f:
+        json.dump(class_to_idx, f)
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=1, t_layers=1))
+    torch.save({kk: (vv.half() if vv.dim() >= 2 else vv) for kk, vv in sd.items()}, os.path.join(root, "clip", "ViT-B-16.pt"))
+    return x, y, mask_lab, w
+
+
+def test_mains_run_on_reference_cache_files(ops, tmp_path, monkeypatch, capsys):
+    """Real-data mode of both entry points on the reference's cache-file formats: features + classifier + vocabulary are read
+    from disk, the cluster dict is written with the reference's keys and read back, class names missing from the vocabulary go
+    through the text tower, --cluster KM runs on the device."""
+    import importlib
+    import scd_amd.clip as clip
+    root = str(tmp_path)
+    x, y, mask_lab, w = _write_cache_tree(root)
+    monkeypatch.setenv("SCD_ROOT", root)
+    monkeypatch.setenv("SCD_DATA", os.path.join(root, "data"))
+    clip.allow_synthetic(False)
+    monkeypatch.setenv("SCD_SYNTHETIC", "")
+    mu = importlib.import_module("main_unsup")
+    common = ["--root_dir", root, "--dataset_name", "cifar10", "--n_cluster", "8", "--topk", "3", "--num_common_vote", "10",
+              "--num_common_linear", "2", "--class_names", os.path.join(root, "class_names.json")]
+    with pytest.raises(FileNotFoundError, match="BPE"):          # the real tokenizer file is absent: no silent stand-in
+        mu.main(common + ["--feat_model", "dino_vit", "--cluster", "KM", "--run_cluster", "true"])
+    monkeypatch.setenv("SCD_SYNTHETIC", "1")                     # opt in to the hash tokenizer (weights come from the checkpoint)
+    cand, u_preds = mu.main(common + ["--feat_model", "dino_vit", "--cluster", "KM", "--run_cluster", "true", "--save_cluster", "true"])
+    out = capsys.readouterr().out
+    assert "KM Accuracies" in out and "sACC_avg" in out and "IoU" in out and "Missed 1 names" in out
+    saved = torch.load(os.path.join(root, "cluster", "KM_dino_vit_cifar10_8.pt"), weights_only=False)
+    assert set(saved) == {"all_preds", "u_preds", "u_targets", "mask"} and saved["all_preds"] is None
+    assert saved["u_preds"].shape == ((~mask_lab).sum(),) and saved["u_preds"].dtype == np.int32
+    assert np.array_equal(saved["u_targets"], y[~mask_lab].astype(np.float64))
+    truth = set("noun_%03d" % c for c in range(7))
+    assert len(truth & set(cand)) >= 6
+    cand2, u_preds2 = mu.main(common + ["--feat_model", "dino_vit", "--cluster", "KM"])            # cluster cache read back
+    assert cand2 == cand and np.array_equal(u_preds2, u_preds)
+    mp_ = importlib.import_module("main_ptsup")
+    pc = common + ["--feat_model", "clip", "--cluster", "SSKM", "--topk", "5"]
+    cand3, u_preds3 = mp_.main(pc + ["--run_cluster", "true", "--save_cluster", "true"])
+    out = capsys.readouterr().out
+    assert "sACC lower bound" in out and "sACC upper bound" in out and "IoU" in out
+    saved = torch.load(os.path.join(root, "cluster", "SSKM_clip_cifar10.pt"), weights_only=False)
+    assert saved["all_preds"].shape == (len(y),) and set(saved) == {"all_preds", "u_preds", "u_targets", "mask"}
+    lab_names = ["noun_%03d" % c for c in range(4)]
+    assert set(lab_names) <= set(cand3) and len(cand3) == 8
+    cand4, u_preds4 = mp_.main(pc)
+    assert cand4 == cand3 and np.array_equal(u_preds4, u_preds3)
+    with pytest.raises(SystemExit, match="KM"):
+        mp_.main(common + ["--feat_model", "clip", "--cluster", "KM", "--run_cluster", "true"])
+
+
+def test_extract_feature_writes_reference_dict(ops, tmp_path):
+    """Row a2: naming.extract_feature over (images, label, uq_idx, mask_lab) batches = the dict of main_unsup.py:141-146; the
+    fused normalise of the encoder's last kernel against the fp32 oracle."""
+    import argparse
+    from scd_amd import naming
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP, DinoViT
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=2, t_layers=1))
+    model = CLIP(sd).cuda()
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(10, 3, 224, 224, generator=g)
+    labels = torch.tensor([0, 1, 2, 3, 4, 0, 1, 2, 3, 4])
+    mlab = torch.tensor([1, 1, 0, 0, 0, 1, 0, 0, 0, 0])
+    loader = [(imgs[:6], labels[:6], None, mlab[:6]), (imgs[6:], labels[6:], None, mlab[6:])]
+    d = naming.extract_feature(model, loader, argparse.Namespace(feat_model="clip", train_classes=range(2)))
+    assert set(d) == {"all_feats", "mask_lab", "mask_cls", "targets"}
+    assert d["all_feats"].shape == (10, 512) and d["all_feats"].dtype == np.float16
+    assert d["mask_lab"].dtype == bool and np.array_equal(d["mask_lab"], mlab.numpy().astype(bool))
+    assert np.array_equal(d["mask_cls"], labels.numpy() < 2) and d["targets"].dtype == np.float64
+    sd16 = {k: (v.half().float() if v.dim() >= 2 and "positional" not in k and "class_emb" not in k else v) for k, v in sd.items()}
+    ref = torch.nn.functional.normalize(co.clip_encode_image(sd16, imgs.half().float()), dim=-1)
+    assert _cos(torch.from_numpy(d["all_feats"]).float(), ref).min().item() > 1 - 1e-3
+    assert np.allclose(np.linalg.norm(d["all_feats"].astype(np.float32), axis=1), 1.0, atol=2e-3)
+    dsd = W.synthetic_dino_state_dict(seed=1, layers=2)
+    dd = naming.extract_feature(DinoViT(dsd).cuda(), loader, argparse.Namespace(feat_model="dino_vit", train_classes=[0, 1]))
+    assert dd["all_feats"].shape == (10, 768) and dd["all_feats"].dtype == np.float32
+    dsd16 = {k: (v.half().float() if v.dim() >= 2 and "pos_embed" not in k and "cls_token" not in k else v) for k, v in dsd.items()}
+    dref = torch.nn.functional.normalize(co.dino_forward(dsd16, imgs.half().float()), dim=-1)
+    assert _cos(torch.from_numpy(dd["all_feats"]), dref).min().item() > 1 - 1e-3

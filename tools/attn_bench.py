@@ -2,6 +2,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scd_amd.clip as clip
+clip.allow_synthetic()
 model, _ = clip.load("ViT-B/16", device="cuda")
 x = torch.randn(512, 3, 224, 224, device="cuda").half()
 enc = model.visual.enc

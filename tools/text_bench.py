@@ -3,6 +3,7 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scd_amd.clip as clip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+clip.allow_synthetic()
 model, _ = clip.load("ViT-B/16", device="cuda")
 g = torch.Generator().manual_seed(0)
 tok = torch.zeros(B, 77, dtype=torch.int32)
