@@ -137,6 +137,20 @@ int scd_munkres_sparse(int d, int64_t nnz, const int32_t* rows, const int32_t* c
 int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
                         int64_t* total_cost_out);
 
+/* ---- multi-GPU exchanges over RCCL (one process per GPU, one communicator per handle).  The reference is a
+ * single process; these are the two collectives the sharded hot path needs.  librccl is dlopen'ed by the first call.
+ *   rank 0: scd_comm_unique_id(id) -> ship the scd_comm_unique_id_bytes() bytes to every rank (file, socket, MPI ...)
+ *   all   : scd_comm_init(h, rank, world, id) ... scd_comm_destroy(h)
+ * scd_allreduce_centroids: in-place float64 sum of the packed M-step partials [sums k*d | counts k | inertia 2] (what
+ *   scd_kmeans_mstep produces, counts converted to float64) - ONE collective per Lloyd iteration;
+ * scd_allgather_text: w_full [world * shard_elems] fp16 <- every rank's w_shard (name-major classifier rows, equal shards). */
+size_t scd_comm_unique_id_bytes(void);
+int scd_comm_unique_id(void* id_out);
+int scd_comm_init(scd_handle h, int rank, int world, const void* unique_id);
+int scd_comm_destroy(scd_handle h);
+int scd_allreduce_centroids(scd_handle h, double* packed, int64_t count, void* stream);
+int scd_allgather_text(scd_handle h, const void* w_shard, int64_t shard_elems, void* w_full, void* stream);
+
 /* ---- encoders: CLIP ViT-B/16 visual / text (third-party `clip`, call sites main_unsup.py:127,
  *      clip_lang_util.py:101-102) and DINO ViT-B/16 (gcd/models/vision_transformer.py:135-219) ---- */
 typedef struct scd_encoder_desc {

@@ -62,6 +62,12 @@ SIGNATURES = {
     "scd_munkres": (_i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
     "scd_munkres_sparse": (_i, [_i, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "scd_transport_solve": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(_i64)]),
+    "scd_comm_unique_id_bytes": (_sz, []),
+    "scd_comm_unique_id": (_i, [_vp]),
+    "scd_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "scd_comm_destroy": (_i, [_vp]),
+    "scd_allreduce_centroids": (_i, [_vp, _vp, _i64, _vp]),
+    "scd_allgather_text": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "scd_encoder_create": (_i, [_vp, C.POINTER(EncoderDesc), C.POINTER(_vp), _i, C.POINTER(_vp)]),
     "scd_encoder_destroy": (_i, [_vp]),
     "scd_encoder_ws_bytes": (_sz, [_vp, _i]),

@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscd_hip.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 
-SOURCES = ["api.cpp", "munkres.cpp", "munkres_sparse.cpp", "transport.cpp", "kmeans.hip", "mstep.hip", "sim.hip", "vote.hip", "gemm.hip", "encoder.hip"]
+SOURCES = ["api.cpp", "munkres.cpp", "munkres_sparse.cpp", "transport.cpp", "comm.cpp", "kmeans.hip", "mstep.hip", "sim.hip", "vote.hip", "gemm.hip", "encoder.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
          "-fno-gpu-rdc"]
@@ -63,7 +63,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print("[scd_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

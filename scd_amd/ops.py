@@ -301,6 +301,41 @@ def transport_solve(cost, size_min, size_max):
     return labels, total.value
 
 
+# ----------------------------------------------------------------------------- RCCL exchanges through the C ABI
+class Comm:
+    """One RCCL communicator on this rank's handle (scd_comm_*): the collectives of the sharded hot path for callers that do
+    not go through torch.distributed.  `unique_id` = bytes from Comm.unique_id() on rank 0, shipped to every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_L().scd_comm_unique_id_bytes())
+        check(_L().scd_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, rank, world, unique_id, device=None):
+        _dev[0] = torch.cuda.current_device() if device is None else device
+        self.h = handle()
+        self.rank, self.world = rank, world
+        check(_L().scd_comm_init(self.h, rank, world, C.c_char_p(unique_id)))
+
+    def allreduce_centroids(self, sums, counts, inertia):
+        """In-place sum over ranks of the M-step partials; returns (sums, counts int64, inertia)."""
+        packed = torch.cat([sums.reshape(-1), counts.to(torch.float64), inertia.reshape(-1)]).contiguous()
+        check(_L().scd_allreduce_centroids(self.h, ptr(packed), packed.numel(), _lib.stream_ptr()))
+        kd, k = sums.numel(), counts.numel()
+        return packed[:kd].reshape(sums.shape), packed[kd:kd + k].round().to(torch.int64), packed[kd + k:]
+
+    def allgather_text(self, wt_shard):
+        """wt_shard fp16 [v_shard, d] (equal shards) -> [world * v_shard, d]."""
+        wt_shard = wt_shard.to(torch.float16).contiguous()
+        out = torch.empty((self.world * wt_shard.shape[0],) + tuple(wt_shard.shape[1:]), dtype=torch.float16, device=wt_shard.device)
+        check(_L().scd_allgather_text(self.h, ptr(wt_shard), wt_shard.numel(), ptr(out), _lib.stream_ptr()))
+        return out
+
+    def close(self):
+        check(_L().scd_comm_destroy(self.h))
+
+
 # ----------------------------------------------------------------------------- encoders
 def gemm_f16(a, w, bias=None, residual=None, act=0):
     _need_cuda(a, w)

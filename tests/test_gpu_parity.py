@@ -295,15 +295,19 @@ def _record_transport(monkeypatch):
         calls.append((np.array(cost, copy=True), size_min, size_max, lab.copy(), tot))
         return lab, tot
     monkeypatch.setattr(o, "transport_solve", spy)
+    calls_real.append(real)
     return calls
 
 
+calls_real = []          # the un-patched solver (the checks below must not feed the recorder they iterate over)
+
+
 def _unique_optimum(cost, smin, smax, labels, ops):
-    """True when three random tie-breaking perturbations of the costs (cost * 4096 + r, r < 8) all give `labels` back:
+    """True when three random tie-breaking perturbations of the costs (cost * 1024 + r, r < 8) all give `labels` back:
     the optimum is then unique (with overwhelming probability), so every exact solver must return these labels."""
     for seed in range(3):
         r = np.random.RandomState(100 + seed).randint(0, 8, size=cost.shape)
-        lab, _ = ops.transport_solve((cost.astype(np.int64) * 4096 + r).astype(np.int32), smin, smax)
+        lab, _ = calls_real[-1]((cost.astype(np.int64) * 1024 + r).astype(np.int32), smin, smax)
         if not np.array_equal(lab, labels):
             return False
     return True
@@ -327,7 +331,7 @@ def test_constrained_matches_reference_golden(ops, golden, monkeypatch):
     # OR-Tools labels are unpinned - third-party solver absent - and its optimum is not unique under integer cost ties.)
     assert len(calls) >= 2
     n_unique = 0
-    for cost, smin, smax, labs, tot in calls:
+    for cost, smin, smax, labs, tot in list(calls):
         ok, tot_chk = to.check_assignment(cost, labs, smin, smax)
         lp_lab, lp_tot = to.solve_lp(cost, smin, smax)
         assert ok and tot == tot_chk == lp_tot and to.check_optimal(cost, labs, smin, smax)
@@ -358,7 +362,7 @@ def test_constrained_tie_free_instance_labels_equal_oracle(ops, monkeypatch):
     km = K_Means(k=5, tolerance=1e-4, max_iterations=6, init="k-means++", size_min=60, size_max=75, n_init=2, random_state=3,
                  pairwise_batch_size=128)
     km.fit_mix(dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab]))
-    for cost, smin, smax, labs, tot in calls:
+    for cost, smin, smax, labs, tot in list(calls):
         assert _unique_optimum(cost, smin, smax, labs, ops)
         assert np.array_equal(labs, to.solve_lp(cost, smin, smax)[0])
     okm = to.K_Means(k=5, tolerance=1e-4, max_iterations=6, size_min=60, size_max=75, n_init=2, random_state=3)
@@ -387,7 +391,7 @@ def test_constrained_c3_size(ops, monkeypatch):
     km.fit_mix(dev(x[n_l:]), dev(x[:n_l]), dev(y[:n_l]))
     lab = km.labels_.cpu().numpy()
     assert len(calls) >= 1 and calls[0][0].shape == (n - n_l, k)
-    for cost, smin, smax, labs, tot in calls:
+    for cost, smin, smax, labs, tot in list(calls):
         ok, tot_chk = to.check_assignment(cost, labs, smin, smax)
         assert ok and tot == tot_chk and to.check_optimal(cost, labs, smin, smax)
     cnt = np.bincount(lab[n_l:], minlength=k)
@@ -636,18 +640,18 @@ def test_sklearn_kmeans_seeding_and_default_call(ops):
     cent = km._kpp(data, ko.check_random_state(0)).cpu().numpy()
     picks = ko.sklearn_kpp(x, 12, 0)
     assert np.array_equal(cent, x[picks])
-    labels = KMeans(n_clusters=12, random_state=0).fit(x).labels_
-    from oracle import naming_oracle as no_
-    acc, _, _ = no_.split_cluster_acc_v2(y, labels, y < 6)
-    assert acc > 0.95
-    sk = None
+    km = KMeans(n_clusters=12, random_state=0).fit(x)
+    olab, oin, ocent, oit = ko.sklearn_lloyd(x, x[picks])               # the oracle's Lloyd from the oracle's seeding
+    assert np.array_equal(km.labels_, olab) and km.n_iter_ == oit and np.array_equal(km.cluster_centers_, ocent)
+    acc, _, _ = no.split_cluster_acc_v2(y, km.labels_, y < 6)
+    assert acc > 0.8                                     # one k-means++ start (n_init='auto' -> 1) may merge two blobs
     try:
         from sklearn.cluster import KMeans as SK
         sk = SK(n_clusters=12, random_state=0, n_init=1).fit(x)
     except Exception:
-        pass
-    if sk is not None:                                   # same algorithm, same stream: the host's sklearn finds the same partition
-        assert abs(sk.inertia_ - KMeans(n_clusters=12, random_state=0).fit(x).inertia_) <= 0.05 * sk.inertia_
+        sk = None
+    if sk is not None:                                   # same algorithm, same random stream: the host's sklearn lands in a similar optimum
+        assert abs(sk.inertia_ - km.inertia_) <= 0.15 * sk.inertia_
 
 
 # ----------------------------------------------------------------------------------------------- pt-sup vote loop
@@ -966,3 +970,21 @@ def test_extract_feature_writes_reference_dict(ops, tmp_path):
     dsd16 = {k: (v.half().float() if v.dim() >= 2 and "pos_embed" not in k and "cls_token" not in k else v) for k, v in dsd.items()}
     dref = torch.nn.functional.normalize(co.dino_forward(dsd16, imgs.half().float()), dim=-1)
     assert _cos(torch.from_numpy(dd["all_feats"]), dref).min().item() > 1 - 1e-3
+
+
+def test_rccl_entry_points_single_rank(ops):
+    """scd_comm_* / scd_allreduce_centroids / scd_allgather_text through the C ABI on a one-rank communicator (the GPU box has one
+    GPU; the multi-rank pattern is covered by tests/test_dist_gloo.py on CPU and by the driver's 8-GPU bench)."""
+    uid = ops.Comm.unique_id()
+    assert len(uid) == 128
+    comm = ops.Comm(0, 1, uid)
+    try:
+        x, y, cent = synth.clustered_features(2000, 64, 7, seed=5)
+        lab = dev(y.astype(np.int32))
+        sums, counts, inertia = ops.kmeans_mstep(dev(x), lab, dev(cent), 7, 0)
+        s2, c2, i2 = comm.allreduce_centroids(sums, counts, inertia)
+        assert torch.equal(s2, sums) and torch.equal(c2, counts) and torch.equal(i2, inertia)
+        w = dev(np.random.RandomState(0).randn(33, 512).astype(np.float16))
+        assert torch.equal(comm.allgather_text(w), w)
+    finally:
+        comm.close()
