@@ -11,12 +11,37 @@
 // could reach rank k given the accumulation error bound; uncertified rows take an exact full-row pass.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define TOPM 8
 
 __device__ __forceinline__ void topm_insert(float (&lv)[TOPM], int (&li)[TOPM], float v, int idx) {
 #pragma unroll
     for (int j = TOPM - 1; j >= 1; --j) {
+        const bool up = v > lv[j - 1];
+        const bool here = v > lv[j];
+        lv[j] = up ? lv[j - 1] : (here ? v : lv[j]);
+        li[j] = up ? li[j - 1] : (here ? idx : li[j]);
+    }
+    if (v > lv[0]) {
+        lv[0] = v;
+        li[0] = idx;
+    }
+}
+
+// compile-time loop: f(std::integral_constant<int, S>) for S = B .. E-1 (asm immediates need constant expressions)
+template <int B, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void topm_insert_n(float (&lv)[TM], int (&li)[TM], float v, int idx) {
+#pragma unroll
+    for (int j = TM - 1; j >= 1; --j) {
         const bool up = v > lv[j - 1];
         const bool here = v > lv[j];
         lv[j] = up ? lv[j - 1] : (here ? v : lv[j]);
@@ -510,6 +535,294 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
     emit(1, lv1, li1, sm_m1, sm_z1);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Row-block kernel (d == 512, the CLIP embedding width; default).  Same outputs as the kernels above, different schedule:
+//   * one wave per SIMD (256 threads, 512 registers); wave w owns 64 images (two 32-image sets) whose 2 x 32 B fragments live
+//     in 256 AGPRs and feed the MFMAs directly;
+//   * the unit of work is a block of 32 NAMES with its whole K = 512: 32 rows x 1 KB of W^T = 32 KB, ONE 1-KB LDS-DMA
+//     instruction per row (whole contiguous rows; 16-B chunk c of row r lands at chunk c ^ (r & 15), applied on the DMA source
+//     address and on the ds_read address: conflict-free A-fragment reads).  A unit is 32 k16 steps x 2 image sets = 64 MFMAs on
+//     ONE accumulator pair (2 x 16 registers), so the accumulators of unit u-1 are complete while unit u is being computed:
+//   * the epilogue of unit u-1 is dealt over the 32 MFMA steps of unit u (two accumulator pairs alternate) instead of running
+//     behind a barrier with the matrix pipe idle (the eight-wave kernel spends 46 % of its wave time parked), and it is
+//     BRANCH-FREE in the common case: each of a lane's 16 values becomes a key (low 4 mantissa bits = position in the unit), a
+//     max / med3 network keeps the two largest keys, the largest is widened to a double whose low mantissa word carries the
+//     name index and pushed through a min / max chain over the lane's sorted list of TM doubles (no index arrays, no compares).
+//     Only when a lane's SECOND key also beats its list (the first units, then ~3 % of the unit-sets) a loop admits the rest;
+//   * a 4-slot ring of units: one barrier per unit (64 MFMAs per wave).  At the barrier of unit u the fills of unit u+1 have
+//     landed (counted vmcnt), so the first fragments of u+1 are read at the end of u and no MFMA waits behind a barrier for
+//     LDS latency; the fills of unit u+3 go into the slot unit u-1 just left, one per 4 k16 steps.
+// MFMAs, fragment reads, waits and the min / max / med3 of the selection are asm (AGPR B operands; counted lgkmcnt that carries
+// the fragment registers; no IEEE canonicalisation in front of every max).  Hazard the compiler cannot see: an accumulator
+// pair is first read >= 2 steps (4 MFMAs, >= 128 cycles) after its last MFMA was issued.
+__device__ __forceinline__ float rb_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float rb_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ double rb_max64(double a, double b) { double d; asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ double rb_min64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#define RB_NEG -3.0e38f                    /* masks padded names: finite, so that widening + index bits stays a number */
+
+template <bool SOFTMAX, int TM>
+__global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
+                                                          long long v, float scale, float* __restrict__ cand_val,
+                                                          int* __restrict__ cand_idx, float* __restrict__ stats) {
+    constexpr int D = 512, UB = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    half8 bf[2][32];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
+        const half_t* frow = F + (img < n ? img : n - 1) * D + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) bf[q][s] = *(const half8*)(frow + 16 * s);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(bf[q][s]));       // resident in AGPRs from here on
+
+    double L[2][TM];                                           // per image set: the lane's TM best (key | name index), descending
+    float thr[2] = {-INFINITY, -INFINITY};                     // float view of L[q][TM-1]
+    float m1[2], m2[2], smm[2] = {-INFINITY, -INFINITY}, smz[2] = {0.f, 0.f}, nmc[2];
+    double tk[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) L[q][j] = -INFINITY;
+    const float c2 = scale * 1.4426950408889634f;              // exp((a - m) * scale) = exp2((a - m) * c2)
+
+    const int nunits = (int)((v + 31) / 32);
+    // ring fill: wave w stages rows 8w .. 8w+7 of a unit, one 1-KB instruction per row; lane l fetches source chunk l ^ (row & 15)
+    unsigned foff[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = 8 * wave + p;
+        foff[p] = (unsigned)(row * 1024 + ((lane ^ (row & 15)) << 4));
+    }
+    auto fill = [&](int unit, int p) {
+        const half_t* base = Wt + (size_t)unit * 32 * D;                        // wave-uniform: scalar arithmetic
+        unsigned off = foff[p];
+        if (unit == nunits - 1) {                                               // padded names re-read row v-1; masked in the epilogue
+            const int row = 8 * wave + p;
+            long long vr = (long long)unit * 32 + row;
+            vr = vr < v ? vr : v - 1;
+            off = (unsigned)((int)(vr - (long long)unit * 32) * 1024 + ((lane ^ (row & 15)) << 4));
+        }
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(sbase + (unit & 3) * UB + (8 * wave + p) * 1024), "v"(off), "s"(base) : "memory");
+    };
+    // A fragment of k16 step s: row r, source chunk 2s + hh -> LDS chunk (2s + hh) ^ (r & 15); with j = s & 7 the byte offset is
+    // (s >> 3) * 256 + ((32 j) ^ (16 (hh ^ (r & 15)))): eight per-lane addresses + an immediate
+    unsigned fa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = sbase + (unsigned)(r * 1024 + ((32 * j) ^ (16 * (hh ^ (r & 15)))));
+
+#define RB_RD(DST, J, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[J]), "n"(IMM))
+#define RB_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
+#define RB_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define RB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "a"(B))
+
+    // ---- epilogue pieces of one finished unit -------------------------------------------------------------------------------
+    auto key = [](float a, int i) { return __uint_as_float((__float_as_uint(a) & 0xfffffff0u) | (unsigned)i); };
+    auto name_of = [&](int unit, int i) { return unit * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh; };
+    auto p_top2 = [&](const f32x16& a, int q, int i0) {        // four values into the running (largest, second) key pair
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) {
+            const float k = key(a[i], i);
+            if (i == 0) {
+                m1[q] = k;
+                m2[q] = -INFINITY;
+            } else {
+                const float n1 = rb_max(m1[q], k);
+                m2[q] = rb_med3(m1[q], m2[q], k);
+                m1[q] = n1;
+            }
+        }
+    };
+    auto widen = [&](float k, int unit) {                      // double(key) with the name index in the low mantissa word
+        const int i = (int)(__float_as_uint(k) & 15u);
+        return __hiloint2double(__double2hiint((double)k), name_of(unit, i));
+    };
+    auto p_ins = [&](int q, int j0, int j1) {                  // tk[q] sinks through list entries j0 .. j1-1
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            const double hi = rb_max64(L[q][j], tk[q]);
+            if (j + 1 < TM) tk[q] = rb_min64(L[q][j], tk[q]);
+            L[q][j] = hi;
+        }
+        if (j1 == TM) thr[q] = (float)L[q][TM - 1];
+    };
+    auto p_rest = [&](const f32x16& a, int q, int unit) {      // rare: the lane's second key beats its list as well
+        if (!__any(m2[q] > thr[q])) return;
+        float bound = m1[q];
+        for (;;) {
+            float c = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float k = key(a[i], i);
+                c = (k < bound && k > c) ? k : c;
+            }
+            if (!__any(c > thr[q])) break;
+            if (c > thr[q]) {
+                tk[q] = widen(c, unit);
+                p_ins(q, 0, TM);
+            }
+            bound = c;
+        }
+    };
+    auto p_sm_begin = [&](int q) {                             // new reference maximum, old sum rescaled to it
+        const float mref = rb_max(smm[q], m1[q]);
+        smz[q] = smz[q] * __builtin_amdgcn_exp2f((smm[q] - mref) * c2);          // first unit: 0 * exp2(-inf) = 0
+        smm[q] = mref;
+        nmc[q] = -mref * c2;
+    };
+    auto p_sm_add = [&](const f32x16& a, int q, int i0) {      // two values per call
+        smz[q] += __builtin_amdgcn_exp2f(fmaf(a[i0], c2, nmc[q])) + __builtin_amdgcn_exp2f(fmaf(a[i0 + 1], c2, nmc[q]));
+    };
+    constexpr int IS = TM == 4 ? 2 : 3;                        // steps one list insertion is dealt over
+    constexpr int JA = TM == 4 ? 2 : 3, JB = TM == 4 ? 4 : 6;  // list entries per step
+    constexpr int SM0 = 11 + 2 * IS;                           // first softmax step
+
+    // ---- one unit: 32 k16 steps x 2 MFMAs into acc[P][], the epilogue of the previous unit (acc[1-P][]) in their shadow -------
+    // (the accumulators are indexed with compile-time constants only: handed to a lambda by reference, hipcc keeps them in scratch)
+    f32x16 acc[2][2];
+    half8 fr[3];
+    auto body = [&](auto has_prev, auto parity, int u) {
+        constexpr int P = decltype(parity)::value;
+        // my fills of unit u+1 have landed (those of u+2 may fly); after the barrier everybody's have, and slot (u-1)&3 is free
+        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = u + 1 < nunits;
+        static_for<0, 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            // fragment read two steps ahead (steps 30 / 31: the first two fragments of unit u+1, whose slot is published)
+            if (s == 30) {
+                const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[j] += delta;
+            }
+            if constexpr (s < 30) RB_RD(fr[(s + 2) % 3], (s + 2) & 7, ((s + 2) >> 3) * 256);
+            else if (more) RB_RD(fr[(s + 2) % 3], (s + 2 - 32) & 7, 0);
+            if (s < 30 || more) RB_WAIT(2, fr[s % 3]);
+            else if (s == 30) RB_WAIT(1, fr[s % 3]);
+            else RB_WAIT(0, fr[s % 3]);
+            if (s == 0) {
+                RB_MFMA0(acc[P][0], fr[s % 3], bf[0][s]);
+                RB_MFMA0(acc[P][1], fr[s % 3], bf[1][s]);
+            } else {
+                RB_MFMA(acc[P][0], fr[s % 3], bf[0][s]);
+                RB_MFMA(acc[P][1], fr[s % 3], bf[1][s]);
+            }
+            if ((s & 3) == 3 && u + 3 < nunits) fill(u + 3, s >> 2);
+            if constexpr (decltype(has_prev)::value) {          // epilogue piece of unit u-1 hidden behind this step
+                if constexpr (s >= 2 && s < 6) p_top2(acc[1 - P][0], 0, 4 * (s - 2));
+                else if constexpr (s >= 6 && s < 10) p_top2(acc[1 - P][1], 1, 4 * (s - 6));
+                else if constexpr (s == 10) { tk[0] = widen(m1[0], u - 1); tk[1] = widen(m1[1], u - 1); }
+                else if constexpr (s == 11) p_ins(0, 0, JA);
+                else if constexpr (s == 12) p_ins(0, JA, IS == 2 ? TM : JB);
+                else if constexpr (IS == 3 && s == 13) p_ins(0, JB, TM);
+                else if constexpr (s == 11 + IS) p_ins(1, 0, JA);
+                else if constexpr (s == 12 + IS) p_ins(1, JA, IS == 2 ? TM : JB);
+                else if constexpr (IS == 3 && s == 13 + IS) p_ins(1, JB, TM);
+                if constexpr (s == SM0 - 1) {
+                    p_rest(acc[1 - P][0], 0, u - 1);
+                    p_rest(acc[1 - P][1], 1, u - 1);
+                    if (SOFTMAX) { p_sm_begin(0); p_sm_begin(1); }
+                }
+                if constexpr (SOFTMAX && s >= SM0 && s < SM0 + 8) {     // 2 + 2 values of each image set per step
+                    p_sm_add(acc[1 - P][0], 0, 2 * (s - SM0));
+                    p_sm_add(acc[1 - P][1], 1, 2 * (s - SM0));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // prologue: units 0..2 in flight, the first two fragments of unit 0
+#pragma unroll 1
+    for (int pre = 0; pre < 3; ++pre)
+        if (pre < nunits)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) fill(pre, p);
+    if (nunits > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // unit 0 has landed
+    else if (nunits > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RB_RD(fr[0], 0, 0);
+    RB_RD(fr[1], 1, 0);
+
+    body(no{}, P0{}, 0);
+    int u = 1;
+    for (; u + 1 < nunits; u += 2) {
+        body(yes{}, P1{}, u);
+        body(yes{}, P0{}, u + 1);
+    }
+    const bool odd_tail = u < nunits;
+    if (odd_tail) body(yes{}, P1{}, u);
+    // epilogue of the last unit (the only one with padded names), not hidden behind anything
+    {
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // MFMA -> VALU read
+        const int lu = nunits - 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x16 la = odd_tail ? acc[1][q] : acc[0][q];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((long long)name_of(lu, i) >= v) la[i] = RB_NEG;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) p_top2(la, q, i);
+            tk[q] = widen(m1[q], lu);
+            p_ins(q, 0, TM);
+            p_rest(la, q, lu);
+            if (SOFTMAX) {
+                p_sm_begin(q);
+#pragma unroll
+                for (int i = 0; i < 16; i += 2)
+                    if ((long long)name_of(lu, i) < v) {       // positions i, i+1 are names 4hh + {0,1} / {2,3} (+8..): mask per value
+                        const float e0 = __builtin_amdgcn_exp2f(fmaf(la[i], c2, nmc[q]));
+                        const float e1 = (long long)name_of(lu, i + 1) < v ? __builtin_amdgcn_exp2f(fmaf(la[i + 1], c2, nmc[q])) : 0.f;
+                        smz[q] += e0 + e1;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
+        if (img < n) {
+            float* cv = cand_val + (img * 2 + hh) * TM;
+            int* ci = cand_idx + (img * 2 + hh) * TM;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int idx = __double2loint(L[q][j]);
+                const bool ok = L[q][j] > -INFINITY && (long long)idx < v;
+                cv[j] = ok ? (float)L[q][j] * scale : -INFINITY;
+                ci[j] = ok ? idx : -1;
+            }
+            if (SOFTMAX) {
+                stats[(img * 2 + hh) * 2] = smm[q] * scale;
+                stats[(img * 2 + hh) * 2 + 1] = smz[q];
+            }
+        }
+    }
+#undef RB_RD
+#undef RB_WAIT
+#undef RB_MFMA
+#undef RB_MFMA0
+}
+
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
 __global__ void __launch_bounds__(256) wmax_kernel(const half_t* __restrict__ Wt, long long v, int d, unsigned* out_bits) {
     __shared__ float red[4];
@@ -547,8 +860,8 @@ __device__ __forceinline__ double dot64(const half_t* f, const half_t* w, int d,
     return wave_sum_f64(s);
 }
 
-// pass 2: one wave per image
-template <bool SOFTMAX>
+// pass 2: one wave per image (TOPM = entries per half list: 8, or 4 for k <= 3)
+template <bool SOFTMAX, int TM>
 __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
                                                          long long n, int d, long long v, float scale, int k,
                                                          const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
@@ -561,27 +874,27 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
     // lanes 0..15 own one candidate each
     int myi = -1;
     float mya = -INFINITY;
-    if (lane < 2 * TOPM) {
-        myi = cand_idx[img * 2 * TOPM + lane];
-        mya = cand_val[img * 2 * TOPM + lane];
+    if (lane < 2 * TM) {
+        myi = cand_idx[img * 2 * TM + lane];
+        mya = cand_val[img * 2 * TM + lane];
     }
     double mye = -INFINITY;
     if (d <= 512) {
         // all 16 candidate rows are requested before the first is consumed (a loop with one load per iteration paid one
         // L2 latency per candidate); lane l owns columns 8l .. 8l+7 of the image row and of every candidate row
-        half8 fv, wv[2 * TOPM];
+        half8 fv, wv[2 * TM];
         const bool act = lane * 8 < d;
 #pragma unroll
         for (int q = 0; q < 8; ++q) fv[q] = (half_t)0.f;
         if (act) fv = *(const half8*)(f + lane * 8);
 #pragma unroll
-        for (int c = 0; c < 2 * TOPM; ++c) {
+        for (int c = 0; c < 2 * TM; ++c) {
             const int ci = __shfl(myi, c, 64);
             wv[c] = fv;
             if (act && ci >= 0) wv[c] = *(const half8*)(Wt + (long long)ci * d + lane * 8);
         }
 #pragma unroll
-        for (int c = 0; c < 2 * TOPM; ++c) {
+        for (int c = 0; c < 2 * TM; ++c) {
             double sacc = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) sacc = fma((double)(float)fv[q], (double)(float)wv[c][q], sacc);
@@ -589,7 +902,7 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
             if (lane == c && myi >= 0) mye = e;
         }
     } else {
-        for (int c = 0; c < 2 * TOPM; ++c) {
+        for (int c = 0; c < 2 * TM; ++c) {
             const int ci = __shfl(myi, c, 64);
             if (ci < 0) continue;                                   // wave-uniform
             const double e = (double)scale * dot64(f, Wt + (long long)ci * d, d, lane);
@@ -598,14 +911,14 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
     }
     // rank of each candidate among the 16: (value desc, index asc)
     int rank = 0;
-    for (int c = 0; c < 2 * TOPM; ++c) {
+    for (int c = 0; c < 2 * TM; ++c) {
         const double oe = __shfl(mye, c, 64);
         const int oi = __shfl(myi, c, 64);
         if (oi >= 0 && (oe > mye || (oe == mye && oi < myi))) ++rank;
     }
-    // certification: a non-candidate of half h has approx <= list_h[TOPM-1]
-    const float a0 = __shfl(mya, TOPM - 1, 64), a1 = __shfl(mya, 2 * TOPM - 1, 64);
-    const int i0 = __shfl(myi, TOPM - 1, 64), i1 = __shfl(myi, 2 * TOPM - 1, 64);
+    // certification: a non-candidate of half h has approx <= list_h[TM-1]
+    const float a0 = __shfl(mya, TM - 1, 64), a1 = __shfl(mya, 2 * TM - 1, 64);
+    const int i0 = __shfl(myi, TM - 1, 64), i1 = __shfl(myi, 2 * TM - 1, 64);
     // if a list is not full, that half has no non-candidates at all
     float astar = -INFINITY;
     if (i0 >= 0) astar = fmaxf(astar, a0);
@@ -617,7 +930,7 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
     }
     f2 = wave_sum_f64(f2);
     const float wmax = sqrtf(__uint_as_float(hdr->wmax2_bits));
-    const float E = 1.5f * fabsf(scale) * ((float)d * 5.9604645e-8f + 2.4e-7f) * (float)sqrt(f2) * wmax + 1e-30f;
+    const float E = 1.5f * fabsf(scale) * ((float)d * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * (float)sqrt(f2) * wmax + 1e-30f;   // + key bits of the row-block kernel (< 2^-20 relative)
     // exact value of the k-th ranked candidate
     double kth = -INFINITY;
     {
@@ -757,6 +1070,24 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 4>, 65536 + 16384); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 4>, 65536 + 16384); if (rc_) return rc_; }
+    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 1;
+    if (use_rb && d == 512 && v < (1ll << 28)) {
+        // row-block kernel (default at the CLIP width): units of 32 names x K = 512, epilogue hidden behind the next unit's MFMAs
+        const bool sm = mode == SCD_SIM_SOFTMAX;
+#define RB_GO(SM, TMV)                                                                                                          \
+    {                                                                                                                           \
+        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV>, 131072); if (rc_) return rc_; }              \
+        sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                   \
+        sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out); \
+        sim_exact_kernel<SM><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);                \
+    }
+        if (k <= 3) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
+        else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
+#undef RB_GO
+        if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));
+        SCD_LAUNCH_CHECK();
+        return SCD_OK;
+    }
     static const int use_w4 = getenv("SCD_SIM_W4") ? atoi(getenv("SCD_SIM_W4")) : 0;
     static const int sim_x = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
     static const int sim_nw = getenv("SCD_SIM_NW") ? atoi(getenv("SCD_SIM_NW")) : 8;
@@ -764,21 +1095,21 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_w4_kernel<false>, 131072); if (rc_) return rc_; }
     if (use_w4 && mode == SCD_SIM_SOFTMAX) {
         sim_topk_w4_kernel<true><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else if (use_w4) {
         sim_topk_w4_kernel<false><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else if (mode == SCD_SIM_SOFTMAX) {
         if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<true><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     } else {
         if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<false><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
+        sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
         sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
     }
     if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));

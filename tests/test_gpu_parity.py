@@ -908,12 +908,14 @@ def test_mains_run_on_reference_cache_files(ops, tmp_path, monkeypatch, capsys):
     monkeypatch.setenv("SCD_ROOT", root)
     monkeypatch.setenv("SCD_DATA", os.path.join(root, "data"))
     clip.allow_synthetic(False)
+    monkeypatch.setattr(clip, "_tokenizer", None)               # an earlier test may have opted in to the hash tokenizer
     monkeypatch.setenv("SCD_SYNTHETIC", "")
     mu = importlib.import_module("main_unsup")
     common = ["--root_dir", root, "--dataset_name", "cifar10", "--n_cluster", "8", "--topk", "3", "--num_common_vote", "10",
               "--num_common_linear", "2", "--class_names", os.path.join(root, "class_names.json")]
     with pytest.raises(FileNotFoundError, match="BPE"):          # the real tokenizer file is absent: no silent stand-in
         mu.main(common + ["--feat_model", "dino_vit", "--cluster", "KM", "--run_cluster", "true"])
+    monkeypatch.setattr(clip, "_tokenizer", None)
     monkeypatch.setenv("SCD_SYNTHETIC", "1")                     # opt in to the hash tokenizer (weights come from the checkpoint)
     cand, u_preds = mu.main(common + ["--feat_model", "dino_vit", "--cluster", "KM", "--run_cluster", "true", "--save_cluster", "true"])
     out = capsys.readouterr().out
