@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restri
 #define SW_RD(DST, SL, CB, K16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((SL) + ((((2 * (K16) + hh) ^ fsw)) << 4)), "n"((CB) * 4096))
 #define SW_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR[0]), "+v"(FR[1]), "+v"(FR[2]), "+v"(FR[3]))
 #define SW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
-#define SW_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "a"(B))
+#define SW_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
     int s = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
@@ -562,7 +562,7 @@ __device__ __forceinline__ double rb_max64(double a, double b) { double d; asm("
 __device__ __forceinline__ double rb_min64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 #define RB_NEG -3.0e38f                    /* masks padded names: finite, so that widening + index bits stays a number */
 
-template <bool SOFTMAX, int TM>
+template <bool SOFTMAX, int TM, int XM = 0>          // XM: timing ablations (1 no epilogue pieces, 2 no ring fills, 4 no MFMAs; results are wrong)
 __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
                                                           long long v, float scale, float* __restrict__ cand_val,
                                                           int* __restrict__ cand_idx, float* __restrict__ stats) {
@@ -625,37 +625,37 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
 #define RB_RD(DST, J, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[J]), "n"(IMM))
 #define RB_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
 #define RB_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
-#define RB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "a"(B))
+// "=&v": the destination of a multi-pass MFMA must not overlap its A / B sources (only C may be the same registers); without the
+// early clobber hipcc reuses the registers of a fragment that dies here, and the results are garbage
+#define RB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
 
     // ---- epilogue pieces of one finished unit -------------------------------------------------------------------------------
     auto key = [](float a, int i) { return __uint_as_float((__float_as_uint(a) & 0xfffffff0u) | (unsigned)i); };
     auto name_of = [&](int unit, int i) { return unit * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh; };
-    auto p_top2 = [&](const f32x16& a, int q, int i0) {        // four values into the running (largest, second) key pair
-#pragma unroll
-        for (int i = i0; i < i0 + 4; ++i) {
-            const float k = key(a[i], i);
-            if (i == 0) {
-                m1[q] = k;
-                m2[q] = -INFINITY;
-            } else {
-                const float n1 = rb_max(m1[q], k);
-                m2[q] = rb_med3(m1[q], m2[q], k);
-                m1[q] = n1;
-            }
+    auto p_top2 = [&](const f32x16& a, int q, int i) {         // value i into the running (largest, second) key pair
+        const float k = key(a[i], i);
+        if (i == 0) {
+            m1[q] = k;
+            m2[q] = -INFINITY;
+        } else {
+            const float n1 = rb_max(m1[q], k);
+            m2[q] = rb_med3(m1[q], m2[q], k);
+            m1[q] = n1;
         }
     };
     auto widen = [&](float k, int unit) {                      // double(key) with the name index in the low mantissa word
         const int i = (int)(__float_as_uint(k) & 15u);
         return __hiloint2double(__double2hiint((double)k), name_of(unit, i));
     };
-    auto p_ins = [&](int q, int j0, int j1) {                  // tk[q] sinks through list entries j0 .. j1-1
+    auto p_ins = [&](int q, int j) {                           // tk[q] sinks past list entry j
+        const double hi = rb_max64(L[q][j], tk[q]);
+        if (j + 1 < TM) tk[q] = rb_min64(L[q][j], tk[q]);
+        L[q][j] = hi;
+        if (j + 1 == TM) thr[q] = (float)L[q][TM - 1];
+    };
+    auto p_ins_all = [&](int q) {
 #pragma unroll
-        for (int j = j0; j < j1; ++j) {
-            const double hi = rb_max64(L[q][j], tk[q]);
-            if (j + 1 < TM) tk[q] = rb_min64(L[q][j], tk[q]);
-            L[q][j] = hi;
-        }
-        if (j1 == TM) thr[q] = (float)L[q][TM - 1];
+        for (int j = 0; j < TM; ++j) p_ins(q, j);
     };
     auto p_rest = [&](const f32x16& a, int q, int unit) {      // rare: the lane's second key beats its list as well
         if (!__any(m2[q] > thr[q])) return;
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
             if (!__any(c > thr[q])) break;
             if (c > thr[q]) {
                 tk[q] = widen(c, unit);
-                p_ins(q, 0, TM);
+                p_ins_all(q);
             }
             bound = c;
         }
@@ -681,19 +681,20 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
         smm[q] = mref;
         nmc[q] = -mref * c2;
     };
-    auto p_sm_add = [&](const f32x16& a, int q, int i0) {      // two values per call
-        smz[q] += __builtin_amdgcn_exp2f(fmaf(a[i0], c2, nmc[q])) + __builtin_amdgcn_exp2f(fmaf(a[i0 + 1], c2, nmc[q]));
-    };
-    constexpr int IS = TM == 4 ? 2 : 3;                        // steps one list insertion is dealt over
-    constexpr int JA = TM == 4 ? 2 : 3, JB = TM == 4 ? 4 : 6;  // list entries per step
-    constexpr int SM0 = 11 + 2 * IS;                           // first softmax step
-
+    auto p_sm_add = [&](const f32x16& a, int q, int i) { smz[q] += __builtin_amdgcn_exp2f(fmaf(a[i], c2, nmc[q])); };
     // ---- one unit: 32 k16 steps x 2 MFMAs into acc[P][], the epilogue of the previous unit (acc[1-P][]) in their shadow -------
+    // A wave is held at its second MFMA until the matrix pipe takes it, so the vector work is dealt in HALF-steps, a few
+    // instructions behind EACH MFMA (h = 2s after the first, 2s+1 after the second):
+    //   h  4..19  one value of each image set into its (largest, second) key pair
+    //   h  20     widen both winners; softmax reference maxima
+    //   h 21..36  image set 0: one list entry per half-step (max, min), one softmax term;  h 37: its rare second-key loop
+    //   h 37..52  image set 1: the same;                                                  h 53: its rare second-key loop
     // (the accumulators are indexed with compile-time constants only: handed to a lambda by reference, hipcc keeps them in scratch)
     f32x16 acc[2][2];
-    half8 fr[3];
+    half8 fr[4];                                               // 32 steps per unit: the rotation phase survives the unit boundary
     auto body = [&](auto has_prev, auto parity, int u) {
         constexpr int P = decltype(parity)::value;
+        constexpr bool EPI = decltype(has_prev)::value && !(XM & 1);
         // my fills of unit u+1 have landed (those of u+2 may fly); after the barrier everybody's have, and slot (u-1)&3 is free
         if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -702,46 +703,54 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
         const bool more = u + 1 < nunits;
         static_for<0, 32>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            // fragment read two steps ahead (steps 30 / 31: the first two fragments of unit u+1, whose slot is published)
-            if (s == 30) {
+            // fragment reads run THREE steps ahead and the wait of step s retires the fragment of step s+1: an MFMA issued within
+            // a few wait states of the s_waitcnt that retires its A operand's ds_read still saw the OLD register content
+            // (measured: with two-ahead reads the first MFMA of every step was wrong, the second, 32 cycles later, right).
+            // Steps 29..31 read the first three fragments of unit u+1, whose slot was published by this unit's barrier.
+            if (s == 29) {
                 const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
 #pragma unroll
                 for (int j = 0; j < 8; ++j) fa[j] += delta;
             }
-            if constexpr (s < 30) RB_RD(fr[(s + 2) % 3], (s + 2) & 7, ((s + 2) >> 3) * 256);
-            else if (more) RB_RD(fr[(s + 2) % 3], (s + 2 - 32) & 7, 0);
-            if (s < 30 || more) RB_WAIT(2, fr[s % 3]);
-            else if (s == 30) RB_WAIT(1, fr[s % 3]);
-            else RB_WAIT(0, fr[s % 3]);
-            if (s == 0) {
-                RB_MFMA0(acc[P][0], fr[s % 3], bf[0][s]);
-                RB_MFMA0(acc[P][1], fr[s % 3], bf[1][s]);
-            } else {
-                RB_MFMA(acc[P][0], fr[s % 3], bf[0][s]);
-                RB_MFMA(acc[P][1], fr[s % 3], bf[1][s]);
-            }
-            if ((s & 3) == 3 && u + 3 < nunits) fill(u + 3, s >> 2);
-            if constexpr (decltype(has_prev)::value) {          // epilogue piece of unit u-1 hidden behind this step
-                if constexpr (s >= 2 && s < 6) p_top2(acc[1 - P][0], 0, 4 * (s - 2));
-                else if constexpr (s >= 6 && s < 10) p_top2(acc[1 - P][1], 1, 4 * (s - 6));
-                else if constexpr (s == 10) { tk[0] = widen(m1[0], u - 1); tk[1] = widen(m1[1], u - 1); }
-                else if constexpr (s == 11) p_ins(0, 0, JA);
-                else if constexpr (s == 12) p_ins(0, JA, IS == 2 ? TM : JB);
-                else if constexpr (IS == 3 && s == 13) p_ins(0, JB, TM);
-                else if constexpr (s == 11 + IS) p_ins(1, 0, JA);
-                else if constexpr (s == 12 + IS) p_ins(1, JA, IS == 2 ? TM : JB);
-                else if constexpr (IS == 3 && s == 13 + IS) p_ins(1, JB, TM);
-                if constexpr (s == SM0 - 1) {
-                    p_rest(acc[1 - P][0], 0, u - 1);
-                    p_rest(acc[1 - P][1], 1, u - 1);
-                    if (SOFTMAX) { p_sm_begin(0); p_sm_begin(1); }
+            if constexpr (s < 29) RB_RD(fr[(s + 3) & 3], (s + 3) & 7, ((s + 3) >> 3) * 256);
+            else if (more) RB_RD(fr[(s + 3) & 3], (s + 3 - 32) & 7, 0);
+            if (s < 29 || more) RB_WAIT(2, fr[(s + 1) & 3]);
+            else if (s == 29) RB_WAIT(1, fr[(s + 1) & 3]);
+            else if (s == 30) RB_WAIT(0, fr[(s + 1) & 3]);
+            if constexpr (XM & 16) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            if constexpr (XM & 32) asm volatile("s_nop 1" ::: "memory");
+            if constexpr (XM & 64) asm volatile("s_nop 7" ::: "memory");
+            static_for<0, 2>([&](auto qc) {
+                constexpr int q = (XM & 8) ? 1 - decltype(qc)::value : decltype(qc)::value;
+                constexpr int h = 2 * s + decltype(qc)::value;
+                if constexpr (!(XM & 4)) {
+                    if (s == 0) RB_MFMA0(acc[P][q], fr[s & 3], bf[q][s]);
+                    else RB_MFMA(acc[P][q], fr[s & 3], bf[q][s]);
                 }
-                if constexpr (SOFTMAX && s >= SM0 && s < SM0 + 8) {     // 2 + 2 values of each image set per step
-                    p_sm_add(acc[1 - P][0], 0, 2 * (s - SM0));
-                    p_sm_add(acc[1 - P][1], 1, 2 * (s - SM0));
+                if constexpr (decltype(qc)::value == 1 && !(XM & 2))
+                    if ((s & 3) == 3 && u + 3 < nunits) fill(u + 3, s >> 2);
+                if constexpr (EPI) {
+                    if constexpr (h >= 4 && h < 20) {
+                        p_top2(acc[1 - P][0], 0, h - 4);
+                        p_top2(acc[1 - P][1], 1, h - 4);
+                    } else if constexpr (h == 20) {
+                        tk[0] = widen(m1[0], u - 1);
+                        tk[1] = widen(m1[1], u - 1);
+                        if (SOFTMAX) { p_sm_begin(0); p_sm_begin(1); }
+                    } else if constexpr (h >= 21 && h < 37) {
+                        if constexpr (h - 21 < TM) p_ins(0, h - 21);
+                        if (SOFTMAX) p_sm_add(acc[1 - P][0], 0, h - 21);
+                    }
+                    if constexpr (h >= 37 && h < 53) {
+                        if constexpr (h == 37) p_rest(acc[1 - P][0], 0, u - 1);
+                        if constexpr (h - 37 < TM) p_ins(1, h - 37);
+                        if (SOFTMAX) p_sm_add(acc[1 - P][1], 1, h - 37);
+                    } else if constexpr (h == 53) {
+                        p_rest(acc[1 - P][1], 1, u - 1);
+                    }
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         });
     };
     using yes = std::true_type;
@@ -749,7 +758,7 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
 
-    // prologue: units 0..2 in flight, the first two fragments of unit 0
+    // prologue: units 0..2 in flight, the first three fragments of unit 0
 #pragma unroll 1
     for (int pre = 0; pre < 3; ++pre)
         if (pre < nunits)
@@ -762,6 +771,14 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
     asm volatile("" ::: "memory");
     RB_RD(fr[0], 0, 0);
     RB_RD(fr[1], 1, 0);
+    RB_RD(fr[2], 2, 0);
+    RB_WAIT(2, fr[0]);
+    if constexpr (XM & 4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[0][q][i] = acc[1][q][i] = 0.f;
+    }
 
     body(no{}, P0{}, 0);
     int u = 1;
@@ -782,9 +799,9 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
             for (int i = 0; i < 16; ++i)
                 if ((long long)name_of(lu, i) >= v) la[i] = RB_NEG;
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) p_top2(la, q, i);
+            for (int i = 0; i < 16; ++i) p_top2(la, q, i);
             tk[q] = widen(m1[q], lu);
-            p_ins(q, 0, TM);
+            p_ins_all(q);
             p_rest(la, q, lu);
             if (SOFTMAX) {
                 p_sm_begin(q);
@@ -1076,11 +1093,22 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         const bool sm = mode == SCD_SIM_SOFTMAX;
 #define RB_GO(SM, TMV)                                                                                                          \
     {                                                                                                                           \
-        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV>, 131072); if (rc_) return rc_; }              \
+        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
         sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                   \
         sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out); \
         sim_exact_kernel<SM><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);                \
     }
+        static const int sim_x_rb = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
+        if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernel (tools/sim_bench.py)
+            switch (sim_x_rb) {
+#define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
+                        sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
+                RB_X(1) RB_X(2) RB_X(3) RB_X(4) RB_X(5) RB_X(7) RB_X(8) RB_X(16) RB_X(32) RB_X(64)
+#undef RB_X
+            }
+            SCD_LAUNCH_CHECK();
+            return SCD_OK;
+        }
         if (k <= 3) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
         else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
 #undef RB_GO
