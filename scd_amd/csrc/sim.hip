@@ -604,17 +604,25 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
         const int row = 8 * wave + p;
         foff[p] = (unsigned)(row * 1024 + ((lane ^ (row & 15)) << 4));
     }
+    // per unit: fbase = W^T rows of unit u+3 (scalar), fm0 = LDS address of this wave's first row in the slot; per fill only m0 moves
+    const half_t* fbase = Wt;
+    unsigned fm0 = 0;
+    bool flast = false;
+    auto fill_unit = [&](int unit) {
+        fbase = Wt + (size_t)unit * 32 * D;
+        fm0 = sbase + (unit & 3) * UB + 8 * wave * 1024;
+        flast = unit == nunits - 1;
+    };
     auto fill = [&](int unit, int p) {
-        const half_t* base = Wt + (size_t)unit * 32 * D;                        // wave-uniform: scalar arithmetic
         unsigned off = foff[p];
-        if (unit == nunits - 1) {                                               // padded names re-read row v-1; masked in the epilogue
+        if (flast) {                                                            // padded names re-read row v-1; masked in the epilogue
             const int row = 8 * wave + p;
             long long vr = (long long)unit * 32 + row;
             vr = vr < v ? vr : v - 1;
             off = (unsigned)((int)(vr - (long long)unit * 32) * 1024 + ((lane ^ (row & 15)) << 4));
         }
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     ::"s"(sbase + (unit & 3) * UB + (8 * wave + p) * 1024), "v"(off), "s"(base) : "memory");
+                     ::"s"(fm0 + p * 1024), "v"(off), "s"(fbase) : "memory");
     };
     // A fragment of k16 step s: row r, source chunk 2s + hh -> LDS chunk (2s + hh) ^ (r & 15); with j = s & 7 the byte offset is
     // (s >> 3) * 256 + ((32 j) ^ (16 (hh ^ (r & 15)))): eight per-lane addresses + an immediate
@@ -696,11 +704,15 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
         constexpr int P = decltype(parity)::value;
         constexpr bool EPI = decltype(has_prev)::value && !(XM & 1);
         // my fills of unit u+1 have landed (those of u+2 may fly); after the barrier everybody's have, and slot (u-1)&3 is free
-        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(XM & 512)) {
+            if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!(XM & 256)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool more = u + 1 < nunits;
+        const bool fills = u + 3 < nunits;
+        if (fills) fill_unit(u + 3);
         static_for<0, 32>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // fragment reads run THREE steps ahead and the wait of step s retires the fragment of step s+1: an MFMA issued within
@@ -714,21 +726,19 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
             }
             if constexpr (s < 29) RB_RD(fr[(s + 3) & 3], (s + 3) & 7, ((s + 3) >> 3) * 256);
             else if (more) RB_RD(fr[(s + 3) & 3], (s + 3 - 32) & 7, 0);
-            if (s < 29 || more) RB_WAIT(2, fr[(s + 1) & 3]);
+            if constexpr (XM & 128) { asm volatile("" : "+v"(fr[(s + 1) & 3])); }
+            else if (s < 29 || more) RB_WAIT(2, fr[(s + 1) & 3]);
             else if (s == 29) RB_WAIT(1, fr[(s + 1) & 3]);
             else if (s == 30) RB_WAIT(0, fr[(s + 1) & 3]);
-            if constexpr (XM & 16) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-            if constexpr (XM & 32) asm volatile("s_nop 1" ::: "memory");
-            if constexpr (XM & 64) asm volatile("s_nop 7" ::: "memory");
             static_for<0, 2>([&](auto qc) {
-                constexpr int q = (XM & 8) ? 1 - decltype(qc)::value : decltype(qc)::value;
+                constexpr int q = decltype(qc)::value;
                 constexpr int h = 2 * s + decltype(qc)::value;
                 if constexpr (!(XM & 4)) {
                     if (s == 0) RB_MFMA0(acc[P][q], fr[s & 3], bf[q][s]);
                     else RB_MFMA(acc[P][q], fr[s & 3], bf[q][s]);
                 }
                 if constexpr (decltype(qc)::value == 1 && !(XM & 2))
-                    if ((s & 3) == 3 && u + 3 < nunits) fill(u + 3, s >> 2);
+                    if ((s & 3) == 3 && fills) fill(u + 3, s >> 2);
                 if constexpr (EPI) {
                     if constexpr (h >= 4 && h < 20) {
                         p_top2(acc[1 - P][0], 0, h - 4);
@@ -761,9 +771,11 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
     // prologue: units 0..2 in flight, the first three fragments of unit 0
 #pragma unroll 1
     for (int pre = 0; pre < 3; ++pre)
-        if (pre < nunits)
+        if (pre < nunits) {
+            fill_unit(pre);
 #pragma unroll
             for (int p = 0; p < 8; ++p) fill(pre, p);
+        }
     if (nunits > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");           // unit 0 has landed
     else if (nunits > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,8 +908,33 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
         mya = cand_val[img * 2 * TM + lane];
     }
     double mye = -INFINITY;
+    unsigned long long needm = __ballot(myi >= 0);                  // candidates whose exact value is computed and ranked
+    double f2 = 0.0;
+    for (int j = lane; j < d; j += 64) {
+        const double x = (double)(float)f[j];
+        f2 = fma(x, x, f2);
+    }
+    f2 = wave_sum_f64(f2);
+    const float wmax = sqrtf(__uint_as_float(hdr->wmax2_bits));
+    // |approx - exact| <= E: fp32 accumulation of exact fp16 products + the key bits of the row-block kernel (< 2^-20 relative)
+    const float E = 1.5f * fabsf(scale) * ((float)d * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * (float)sqrt(f2) * wmax + 1e-30f;
     if (d <= 512) {
-        // all 16 candidate rows are requested before the first is consumed (a loop with one load per iteration paid one
+        // Only candidates that can still reach rank k are recomputed: with A_k the k-th largest APPROXIMATE value, a candidate
+        // below A_k - 2E has an exact value below A_k - E <= the exact values of k others.  That is typically k+1 of the 2 TM
+        // rows, and the row gather (1 KB per candidate from L2 / Infinity Cache) is what this kernel's time is made of.
+        int ra = 0;
+        for (int c = 0; c < 2 * TM; ++c) {
+            const float oa = __shfl(mya, c, 64);
+            const int oi = __shfl(myi, c, 64);
+            if (oi >= 0 && (oa > mya || (oa == mya && c < lane))) ++ra;
+        }
+        float kap = -INFINITY;
+        {
+            const unsigned long long m = __ballot(ra == k - 1 && myi >= 0);
+            if (m) kap = __shfl(mya, __ffsll((long long)m) - 1, 64);
+        }
+        needm = __ballot(myi >= 0 && mya >= kap - 2.f * E);
+        // all needed candidate rows are requested before the first is consumed (a loop with one load per iteration paid one
         // L2 latency per candidate); lane l owns columns 8l .. 8l+7 of the image row and of every candidate row
         half8 fv, wv[2 * TM];
         const bool act = lane * 8 < d;
@@ -908,15 +945,16 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
         for (int c = 0; c < 2 * TM; ++c) {
             const int ci = __shfl(myi, c, 64);
             wv[c] = fv;
-            if (act && ci >= 0) wv[c] = *(const half8*)(Wt + (long long)ci * d + lane * 8);
+            if (act && (needm >> c & 1)) wv[c] = *(const half8*)(Wt + (long long)ci * d + lane * 8);
         }
 #pragma unroll
         for (int c = 0; c < 2 * TM; ++c) {
+            if (!(needm >> c & 1)) continue;                        // wave-uniform
             double sacc = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) sacc = fma((double)(float)fv[q], (double)(float)wv[c][q], sacc);
             const double e = (double)scale * wave_sum_f64(act ? sacc : 0.0);
-            if (lane == c && myi >= 0) mye = e;
+            if (lane == c) mye = e;
         }
     } else {
         for (int c = 0; c < 2 * TM; ++c) {
@@ -926,12 +964,13 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
             if (lane == c) mye = e;
         }
     }
-    // rank of each candidate among the 16: (value desc, index asc)
+    // rank of each recomputed candidate among them: (value desc, index asc)
+    const bool need_l = needm >> lane & 1;
     int rank = 0;
     for (int c = 0; c < 2 * TM; ++c) {
         const double oe = __shfl(mye, c, 64);
         const int oi = __shfl(myi, c, 64);
-        if (oi >= 0 && (oe > mye || (oe == mye && oi < myi))) ++rank;
+        if ((needm >> c & 1) && (oe > mye || (oe == mye && oi < myi))) ++rank;
     }
     // certification: a non-candidate of half h has approx <= list_h[TM-1]
     const float a0 = __shfl(mya, TM - 1, 64), a1 = __shfl(mya, 2 * TM - 1, 64);
@@ -940,18 +979,10 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
     float astar = -INFINITY;
     if (i0 >= 0) astar = fmaxf(astar, a0);
     if (i1 >= 0) astar = fmaxf(astar, a1);
-    double f2 = 0.0;
-    for (int j = lane; j < d; j += 64) {
-        const double x = (double)(float)f[j];
-        f2 = fma(x, x, f2);
-    }
-    f2 = wave_sum_f64(f2);
-    const float wmax = sqrtf(__uint_as_float(hdr->wmax2_bits));
-    const float E = 1.5f * fabsf(scale) * ((float)d * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * (float)sqrt(f2) * wmax + 1e-30f;   // + key bits of the row-block kernel (< 2^-20 relative)
     // exact value of the k-th ranked candidate
     double kth = -INFINITY;
     {
-        const unsigned long long m = __ballot(rank == k - 1 && myi >= 0);
+        const unsigned long long m = __ballot(rank == k - 1 && need_l);
         if (m) kth = __shfl(mye, __ffsll((long long)m) - 1, 64);
     }
     const bool certified = (astar == -INFINITY) || (kth > (double)astar + (double)E);
@@ -962,7 +993,7 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
         }
         return;
     }
-    if (myi >= 0 && rank < k) {
+    if (need_l && rank < k) {
         idx_out[img * k + rank] = myi;
         float o = (float)mye;
         if (SOFTMAX) {
@@ -1103,13 +1134,13 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
             switch (sim_x_rb) {
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
-                RB_X(1) RB_X(2) RB_X(3) RB_X(4) RB_X(5) RB_X(7) RB_X(8) RB_X(16) RB_X(32) RB_X(64)
+                RB_X(1) RB_X(3) RB_X(4) RB_X(5)
 #undef RB_X
             }
             SCD_LAUNCH_CHECK();
             return SCD_OK;
         }
-        if (k <= 3) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
+        if (k == 1) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }   // two half lists of 4; k >= 2: 8 (certification needs margin)
         else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
 #undef RB_GO
         if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));

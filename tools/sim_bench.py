@@ -3,13 +3,14 @@ import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scd_amd import ops
 n, v, d = int(sys.argv[1]) if len(sys.argv) > 1 else 126976, 21000, 512
+k = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 f = torch.nn.functional.normalize(torch.randn(n, d, device="cuda"), dim=-1).half()
 wt = torch.nn.functional.normalize(torch.randn(v, d, device="cuda"), dim=-1).half()
 for mode in ("raw", "softmax"):
-    for _ in range(2): idx, val, fb = ops.sim_topk(f, wt, 5, mode, return_fallback=True)
+    for _ in range(2): idx, val, fb = ops.sim_topk(f, wt, k, mode, return_fallback=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): ops.sim_topk(f, wt, 5, mode)
+    for _ in range(5): ops.sim_topk(f, wt, k, mode)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    print("sim_topk[%s] n=%d v=%d: %.3f ms  %.1f TFLOP/s  fallback rows %d" % (mode, n, v, ms, 2.0 * n * v * d / ms / 1e9, int(fb)))
+    print("sim_topk[%s] k=%d n=%d v=%d: %.3f ms  %.1f TFLOP/s  fallback rows %d" % (mode, k, n, v, ms, 2.0 * n * v * d / ms / 1e9, int(fb)))
