@@ -76,6 +76,10 @@ int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* pre
 size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k);
 int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                      int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream);
+/* Hint for the NEXT scd_kmeans_estep on this handle (consumed by it): the caller expects few rows inside the filter's error bound
+ * (Lloyd iterations after the first two; converged centres).  Those rows are then re-evaluated in the tail of the filter kernel
+ * instead of by a refine launch.  Results are identical either way; a wrong hint only costs time. */
+int scd_kmeans_estep_hint(scd_handle h, int expect_few_refined_rows);
 /* d2_out[i] = ||x_i - c_{labels[i]}||^2 (float64 sum rounded to float32) */
 int scd_kmeans_rowdist(scd_handle h, const float* X, const float* C, const int32_t* labels, int64_t n, int d, int k,
                        float* d2_out, void* stream);
@@ -90,11 +94,23 @@ size_t scd_kmeans_mstep_ws_bytes(int64_t n, int d, int k);
 int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d, int k,
                      int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes,
                      void* stream);
+/* The same partials from an fp16 copy of X (half the row bytes): valid when every value of X is exactly representable in fp16,
+ * as features that left an fp16 encoder are - the float64 sums are then bit-identical.  scd_f16_exact writes the copy
+ * (n_elems % 4 == 0) and counts the waves that saw a value that does not survive the round trip (*inexact_out == 0: exact). */
+int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream);
+int scd_kmeans_mstep_f16(scd_handle h, const void* X16, const int32_t* labels, const float* C_old, int64_t n, int d, int k,
+                         int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes,
+                         void* stream);
 /* centres = sums / counts (empty -> NaN, as torch mean of an empty selection); shift_out (device double, may be NULL)
  * = (sum_k ||c_k - c_old_k||_2)^2  (shift_mode 0: sskm_constrained.py:135-136) or sum_k ||c_k - c_old_k||^2 (shift_mode 1:
  * sklearn's center_shift_tot, the `--cluster KM` path of main_unsup.py:362) */
 int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old,
-                        float* C_out, double* shift_out, int shift_mode, void* stream);
+                        float* C_out, double* shift_out, int shift_mode, const void* prep, void* estep_ws,
+                        size_t estep_ws_bytes, int64_t n, void* stream);
+/* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
+ * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
+ * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips
+ * its centre-prep launch.  Any other scd_kmeans_finalize / scd_kmeans_estep call on the handle drops the hand-over. */
 /* sklearn.cluster.KMeans pieces (main_unsup.py:362, main_ptsup.py:381 `KMeans(n_clusters, random_state=0).fit(u_feats)`):
  * out (device int64) = number of rows whose label changed (strict convergence, `np.array_equal(labels, labels_old)`); */
 int scd_labels_changed(scd_handle h, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, void* stream);

@@ -46,11 +46,14 @@ SIGNATURES = {
     "scd_kmeans_prepare": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "scd_kmeans_estep_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kmeans_estep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kmeans_estep_hint": (_i, [_vp, _i]),
     "scd_kmeans_rowdist": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "scd_kmeans_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "scd_kmeans_mstep_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kmeans_mstep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "scd_f16_exact": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "scd_kmeans_mstep_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i64, _vp]),
     "scd_labels_changed": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "scd_kpp_searchsorted": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "scd_kmeans_min_update": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),

@@ -50,6 +50,9 @@ extern "C" int scd_create(int device, scd_handle* out) {
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     c->scratch = nullptr;
+    c->prep_C = c->prep_ws = nullptr;
+    c->prep_k = c->prep_d = 0;
+    c->estep_few = 0;
     SCD_HIP(hipMalloc(&c->scratch, SCD_SCRATCH_BYTES));
     SCD_HIP(hipMemset(c->scratch, 0, SCD_SCRATCH_BYTES));
     *out = c;

@@ -11,6 +11,12 @@ struct scd_ctx {
     int device;
     int n_cu;
     void* scratch;          // 256 KB + 64 B of device memory, zero at creation: per-centre partials + ticket of scd_kmeans_finalize
+    // set by scd_kmeans_finalize when it also wrote the E-step operands of C_out into an E-step workspace; consumed (and
+    // cleared) by the next scd_kmeans_estep on the same handle: a match skips the centre-prep launch
+    const void* prep_C;
+    const void* prep_ws;
+    int prep_k, prep_d;
+    int estep_few;          // scd_kmeans_estep_hint: the next E-step re-evaluates its (few) flagged rows in the filter kernel's tail
 };
 #define SCD_SCRATCH_BYTES (262144 + 64)
 

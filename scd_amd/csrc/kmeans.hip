@@ -128,12 +128,13 @@ extern "C" size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k) {
 }
 
 // one block per (padded) centre: c' = (c-mu)*scale -> fp16; cn = ||c'||^2 (float64 -> float32)
-__global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
-                                                           const PrepHdr* hdr, const double* mu, EHdr* eh, float* cn,
-                                                           half_t* ch, float* ct, int kp, int zero_counts, half_t* chf) {
+// E-step operands of ONE centre (block-wide, 256 threads): norm, fp16 centred / scaled row (row-major and MFMA-fragment order),
+// fp32 transposed copy.  Called by prep_centers_kernel and, fused, by finalize_kernel (the block that has just produced the centre).
+__device__ __forceinline__ void prep_center_row(const float* C, int c, int k, int d, int dp, const PrepHdr* hdr,
+                                                const double* mu, EHdr* eh, float* cn, half_t* ch, float* ct, int kp,
+                                                int zero_counts, half_t* chf) {
     __shared__ double red[4];
     __shared__ int bad;
-    const int c = blockIdx.x;
     if (threadIdx.x == 0) bad = 0;
     if (zero_counts && c == 0 && threadIdx.x == 0) { eh->flag_cnt = 0; eh->full_cnt = 0; }   // streaming path: no memset launch
     __syncthreads();
@@ -171,6 +172,12 @@ __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restri
             atomicMax(&eh->cmax_bits, __float_as_uint((float)sqrt(t) * 1.0000002f));
         }
     }
+}
+
+__global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
+                                                           const PrepHdr* hdr, const double* mu, EHdr* eh, float* cn,
+                                                           half_t* ch, float* ct, int kp, int zero_counts, half_t* chf) {
+    prep_center_row(C, blockIdx.x, k, d, dp, hdr, mu, eh, cn, ch, ct, kp, zero_counts, chf);
 }
 
 // MFMA filter.  Block = 4 waves = 128 points; each wave owns 32 points (MFMA columns) against a chunk
@@ -329,13 +336,142 @@ __device__ __forceinline__ void es_insert(float& b0, float& b1, float& b2, float
     b0 = es_min(b0, k);
 }
 
+// exact re-evaluation of ONE flagged row (float64 difference form), shared by estep_refine_both_kernel and the tail of
+// estep_stream_kernel.  Pair form: one wave, the two candidate centres.  Full form: one 256-thread block, every centre.
+__device__ __forceinline__ void refine_pair_row(const float* __restrict__ X, const float* __restrict__ C, long long row, int cand,
+                                                int d, int lane, int32_t* labels) {
+    const float* x = X + row * d;
+    const int ca = cand & 0xffff, cb = cand >> 16;
+    const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+    const float *c0 = C + (size_t)lo * d, *c1 = C + (size_t)hi * d;
+    double s0 = 0.0, s1 = 0.0;
+    if ((d & 3) == 0) {
+        // all loads of a 1024-column slab are issued before the first is consumed (a scalar loop paid one memory
+        // latency per 64 columns); the per-lane partial sums differ from the scalar loop's, the float64 total does
+        // not beyond 1e-16 relative (decision semantics)
+        for (int j0 = 0; j0 < d; j0 += 1024) {
+            float4 xv[4], av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 256 * u + 4 * lane;
+                if (j < d) {
+                    xv[u] = *(const float4*)(x + j);
+                    av[u] = *(const float4*)(c0 + j);
+                    bv[u] = *(const float4*)(c1 + j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 256 * u + 4 * lane;
+                if (j < d) {
+                    double t;
+                    t = (double)xv[u].x - (double)av[u].x; s0 = fma(t, t, s0);
+                    t = (double)xv[u].y - (double)av[u].y; s0 = fma(t, t, s0);
+                    t = (double)xv[u].z - (double)av[u].z; s0 = fma(t, t, s0);
+                    t = (double)xv[u].w - (double)av[u].w; s0 = fma(t, t, s0);
+                    t = (double)xv[u].x - (double)bv[u].x; s1 = fma(t, t, s1);
+                    t = (double)xv[u].y - (double)bv[u].y; s1 = fma(t, t, s1);
+                    t = (double)xv[u].z - (double)bv[u].z; s1 = fma(t, t, s1);
+                    t = (double)xv[u].w - (double)bv[u].w; s1 = fma(t, t, s1);
+                }
+            }
+        }
+    } else
+    for (int j = lane; j < d; j += 64) {
+        const double xv = (double)x[j];
+        const double d0 = xv - (double)c0[j], d1 = xv - (double)c1[j];
+        s0 = fma(d0, d0, s0);
+        s1 = fma(d1, d1, s1);
+    }
+    s0 = wave_sum_f64(s0);
+    s1 = wave_sum_f64(s1);
+    // same decision sequence as estep_refine_kernel: NaN never wins, ties keep the lower index
+    double best = INFINITY;
+    int bi = 0;
+    if (s0 < best) { best = s0; bi = lo; }
+    if (s1 < best) { best = s1; bi = hi; }
+    if (lane == 0) labels[row] = bi;
+}
+
+__device__ __forceinline__ void refine_full_row(const float* __restrict__ X, const float* __restrict__ C, long long row, int d, int k,
+                                                double* xs, double* rv, int* ri, int32_t* labels) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int j = threadIdx.x; j < d; j += 256) xs[j] = (double)X[row * d + j];
+    __syncthreads();
+    double best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int c0 = wv; c0 < k; c0 += 32) {
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if ((d & 3) == 0) {
+            for (int j0 = 4 * lane; j0 < d; j0 += 768) {
+                float4 cv[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const int c = c0 + 4 * u, j = j0 + 256 * v;
+                        if (c < k && j < d) cv[u][v] = *(const float4*)(C + (size_t)c * d + j);
+                    }
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int j = j0 + 256 * v;
+                    if (j < d) {
+                        const double x0 = xs[j], x1 = xs[j + 1], x2 = xs[j + 2], x3 = xs[j + 3];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (c0 + 4 * u < k) {
+                                double t;
+                                t = x0 - (double)cv[u][v].x; a[u] = fma(t, t, a[u]);
+                                t = x1 - (double)cv[u][v].y; a[u] = fma(t, t, a[u]);
+                                t = x2 - (double)cv[u][v].z; a[u] = fma(t, t, a[u]);
+                                t = x3 - (double)cv[u][v].w; a[u] = fma(t, t, a[u]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int j = lane; j < d; j += 64) {
+                const double x0 = xs[j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + 4 * u;
+                    if (c < k) {
+                        const double t = x0 - (double)C[(size_t)c * d + j];
+                        a[u] = fma(t, t, a[u]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + 4 * u;
+            if (c < k) {
+                const double sum = wave_sum_f64(a[u]);
+                if (sum < best || (sum == best && c < bi)) { best = sum; bi = c; }      // NaN never wins
+            }
+        }
+    }
+    if (lane == 0) { rv[wv] = best; ri[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int w = 0;
+        for (int q = 1; q < 4; ++q)
+            if (rv[q] < rv[w] || (rv[q] == rv[w] && ri[q] < ri[w])) w = q;
+        labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
                                                            const half_t* __restrict__ ch, const float* __restrict__ cn,
                                                            EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
                                                            long long n, int32_t* __restrict__ labels, int dbg, int cbase,
                                                            int pass, float* __restrict__ tkey, int* __restrict__ tidx,
-                                                           const float* __restrict__ cn_all, int kp_all) {
+                                                           const float* __restrict__ cn_all, int kp_all,
+                                                           const float* __restrict__ Xf, const float* __restrict__ Cf, int d_f,
+                                                           int k_f) {
     // K > 128 runs one launch per 128-centre chunk (`ch` / `cn` point at the chunk, cbase = its first centre): every pass but
     // the last leaves each row's three smallest (key, centre) pairs in tkey / tidx [3][n], every pass but the first merges
     // them in; the last pass (pass & 2) takes the decisions.  pass = 1 first | 2 last.
@@ -599,6 +735,22 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         }
     }
     __syncthreads();
+    if (Xf) {
+        // refine in the tail: every block re-evaluates the rows IT flagged (exact float64 difference form) - no refine launch, no
+        // global lists; converged centres flag nothing and the kernel simply ends.  The lists sit at the start of the (drained)
+        // ring, the row buffer of the all-centres form behind them.
+        double* xs = (double*)(smem + 3 * ES_RMAX * 4);
+        double* rv = xs + 1024;
+        int* ri = (int*)(rv + 4);
+        const int n0 = cnts[0], n1 = cnts[1];
+        for (int i = tid >> 6; i < n0; i += 4) refine_pair_row(Xf, Cf, l_flag[i], l_cand[i], d_f, tid & 63, labels);
+        for (int i = 0; i < n1; ++i) refine_full_row(Xf, Cf, l_full[i], d_f, k_f, xs, rv, ri, labels);
+        if (tid == 0) {
+            if (n0) atomicAdd(&eh->flag_cnt, n0);
+            if (n1) atomicAdd(&eh->full_cnt, n1);
+        }
+        return;
+    }
     if (tid == 0) {
         cnts[2] = cnts[0] ? atomicAdd(&eh->flag_cnt, cnts[0]) : 0;
         cnts[3] = cnts[1] ? atomicAdd(&eh->full_cnt, cnts[1]) : 0;
@@ -713,59 +865,7 @@ __global__ void __launch_bounds__(256) estep_refine_both_kernel(const float* __r
         const int lane = threadIdx.x & 63;
         const int cnt = eh->flag_cnt;
         for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < cnt; f += 4 * half_grid) {
-            const long long row = flag_list[f];
-            const int cand = flag_cand[f];
-            const float* x = X + row * d;
-            const int ca = cand & 0xffff, cb = cand >> 16;
-            const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
-            const float *c0 = C + (size_t)lo * d, *c1 = C + (size_t)hi * d;
-            double s0 = 0.0, s1 = 0.0;
-            if ((d & 3) == 0) {
-                // all loads of a 1024-column slab are issued before the first is consumed (a scalar loop paid one memory
-                // latency per 64 columns); the per-lane partial sums differ from the scalar loop's, the float64 total does
-                // not beyond 1e-16 relative (decision semantics)
-                for (int j0 = 0; j0 < d; j0 += 1024) {
-                    float4 xv[4], av[4], bv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + 256 * u + 4 * lane;
-                        if (j < d) {
-                            xv[u] = *(const float4*)(x + j);
-                            av[u] = *(const float4*)(c0 + j);
-                            bv[u] = *(const float4*)(c1 + j);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = j0 + 256 * u + 4 * lane;
-                        if (j < d) {
-                            double t;
-                            t = (double)xv[u].x - (double)av[u].x; s0 = fma(t, t, s0);
-                            t = (double)xv[u].y - (double)av[u].y; s0 = fma(t, t, s0);
-                            t = (double)xv[u].z - (double)av[u].z; s0 = fma(t, t, s0);
-                            t = (double)xv[u].w - (double)av[u].w; s0 = fma(t, t, s0);
-                            t = (double)xv[u].x - (double)bv[u].x; s1 = fma(t, t, s1);
-                            t = (double)xv[u].y - (double)bv[u].y; s1 = fma(t, t, s1);
-                            t = (double)xv[u].z - (double)bv[u].z; s1 = fma(t, t, s1);
-                            t = (double)xv[u].w - (double)bv[u].w; s1 = fma(t, t, s1);
-                        }
-                    }
-                }
-            } else
-            for (int j = lane; j < d; j += 64) {
-                const double xv = (double)x[j];
-                const double d0 = xv - (double)c0[j], d1 = xv - (double)c1[j];
-                s0 = fma(d0, d0, s0);
-                s1 = fma(d1, d1, s1);
-            }
-            s0 = wave_sum_f64(s0);
-            s1 = wave_sum_f64(s1);
-            // same decision sequence as estep_refine_kernel: NaN never wins, ties keep the lower index
-            double best = INFINITY;
-            int bi = 0;
-            if (s0 < best) { best = s0; bi = lo; }
-            if (s1 < best) { best = s1; bi = hi; }
-            if (lane == 0) labels[row] = bi;
+            refine_pair_row(X, C, flag_list[f], flag_cand[f], d, lane, labels);
         }
         return;
     }
@@ -775,72 +875,7 @@ __global__ void __launch_bounds__(256) estep_refine_both_kernel(const float* __r
     const int cnt = eh->full_cnt;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int f = blockIdx.x - half_grid; f < cnt; f += half_grid) {
-        const long long row = full_list[f];
-        __syncthreads();
-        for (int j = threadIdx.x; j < d; j += 256) xs[j] = (double)X[row * d + j];
-        __syncthreads();
-        double best = INFINITY;
-        int bi = 0x7fffffff;
-        for (int c0 = wv; c0 < k; c0 += 32) {
-            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if ((d & 3) == 0) {
-                for (int j0 = 4 * lane; j0 < d; j0 += 768) {
-                    float4 cv[8][3];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int v = 0; v < 3; ++v) {
-                            const int c = c0 + 4 * u, j = j0 + 256 * v;
-                            if (c < k && j < d) cv[u][v] = *(const float4*)(C + (size_t)c * d + j);
-                        }
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        const int j = j0 + 256 * v;
-                        if (j < d) {
-                            const double x0 = xs[j], x1 = xs[j + 1], x2 = xs[j + 2], x3 = xs[j + 3];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                if (c0 + 4 * u < k) {
-                                    double t;
-                                    t = x0 - (double)cv[u][v].x; a[u] = fma(t, t, a[u]);
-                                    t = x1 - (double)cv[u][v].y; a[u] = fma(t, t, a[u]);
-                                    t = x2 - (double)cv[u][v].z; a[u] = fma(t, t, a[u]);
-                                    t = x3 - (double)cv[u][v].w; a[u] = fma(t, t, a[u]);
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {
-                for (int j = lane; j < d; j += 64) {
-                    const double x0 = xs[j];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = c0 + 4 * u;
-                        if (c < k) {
-                            const double t = x0 - (double)C[(size_t)c * d + j];
-                            a[u] = fma(t, t, a[u]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + 4 * u;
-                if (c < k) {
-                    const double sum = wave_sum_f64(a[u]);
-                    if (sum < best || (sum == best && c < bi)) { best = sum; bi = c; }      // NaN never wins
-                }
-            }
-        }
-        if (lane == 0) { rv[wv] = best; ri[wv] = bi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int w = 0;
-            for (int q = 1; q < 4; ++q)
-                if (rv[q] < rv[w] || (rv[q] == rv[w] && ri[q] < ri[w])) w = q;
-            labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
-        }
+        refine_full_row(X, C, full_list[f], d, k, xs, rv, ri, labels);
     }
 }
 
@@ -871,30 +906,41 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
     static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
     if (use_stream && kp <= 2048 && dp <= 768) {
-        // streaming filter (D <= 768): centre prep, one filter launch per 128 centres, refine; no memset
-        prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
+        // streaming filter (D <= 768): centre prep (unless scd_kmeans_finalize has just produced these very centres and their
+        // operands into this workspace), one filter launch per 128 centres, refine; no memset
+        const bool prepared = h->prep_C == C && h->prep_ws == ws && h->prep_k == k && h->prep_d == d;
+        h->prep_C = nullptr;
+        if (!prepared) prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
         const long long g32 = (n + 31) / 32;               // units of 32 rows
         long long grid = g32 < h->n_cu ? g32 : h->n_cu;
         if (grid < scd_cdiv(g32, ES_RMAX / 32)) grid = scd_cdiv(g32, ES_RMAX / 32);
         const half_t* xh = (const half_t*)(p + xh_off);
         const float* xn = (const float*)(p + xnorm_off);
         static const int es_dbg = getenv("SCD_ESTEP_DBG") ? atoi(getenv("SCD_ESTEP_DBG")) : 0;
+        static const int split = getenv("SCD_ESTEP_REFINE_SPLIT") ? atoi(getenv("SCD_ESTEP_REFINE_SPLIT")) : 0;   // 0: refine in the stream kernel's tail
+        // refine in the stream kernel's tail only when the caller expects few flagged rows (scd_kmeans_estep_hint: Lloyd iterations
+        // after the first two): with ~10 % of the rows flagged the one-block-per-CU tail takes 190 us where the refine kernel at
+        // full occupancy takes 60-100; with none flagged the tail saves the launch (37 -> 31 us per call)
+        const bool tail = split == 0 && d <= 1024 && h->estep_few;
+        h->estep_few = 0;
 #define ES_LAUNCH(NCH)                                                                                                       \
     case NCH: {                                                                                                              \
         { const int rc_ = scd_set_max_lds((const void*)estep_stream_kernel<NCH>, ES_LDS); if (rc_) return rc_; }                                                                                                                    \
         for (int cb = 0; cb < kp / 128; ++cb)                                                                                \
             estep_stream_kernel<NCH><<<(unsigned)grid, 256, ES_LDS, st>>>(xh, xn, chf + (size_t)cb * 128 * dp, cn + cb * 128, eh, flags, fcand, \
                                                                           fulls, n, labels_out, es_dbg, cb * 128,           \
-                                                                          (cb == 0 ? 1 : 0) | (cb == kp / 128 - 1 ? 2 : 0), tkey, tidx, cn, kp); \
+                                                                          (cb == 0 ? 1 : 0) | (cb == kp / 128 - 1 ? 2 : 0), tkey, tidx, cn, kp,  \
+                                                                          tail ? X : nullptr, C, d, k);                       \
     } break;
         switch (dp / 128) {
             ES_LAUNCH(1) ES_LAUNCH(2) ES_LAUNCH(3) ES_LAUNCH(4) ES_LAUNCH(5) ES_LAUNCH(6)
         }
 #undef ES_LAUNCH
-        static const int split = getenv("SCD_ESTEP_REFINE_SPLIT") ? atoi(getenv("SCD_ESTEP_REFINE_SPLIT")) : 0;
-        if (split == 2) {
+        if (tail) {
+            if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
+        } else if (split == 2) {
             // debugging: filter labels only
-        } else if (split) {
+        } else if (split == 1) {
             estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);
             estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
             if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
@@ -1020,10 +1066,15 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
 // finalize in flight per handle.
 __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const long long* counts, int k, int d,
                                                        const float* Cold, float* Cout, double* shift, double* part,
-                                                       unsigned* ticket, int shift_mode) {
+                                                       unsigned* ticket, int shift_mode, const PrepHdr* ph, const double* mu,
+                                                       EHdr* eh, float* cn, half_t* ch, float* ct, int kp, half_t* chf) {
     __shared__ double wred[4];
     __shared__ bool last;
     const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (c >= k) {                                   // padded centres of the fused E-step prep (grid = kp blocks)
+        prep_center_row(Cout, c, k, d, ph->dp, ph, mu, eh, cn, ch, ct, kp, 1, chf);
+        return;
+    }
     const double cnt = (double)counts[c];
     double ss = 0.0;
     for (int j = threadIdx.x; j < d; j += 256) {
@@ -1033,6 +1084,11 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
             const double df = (double)v - (double)Cold[(size_t)c * d + j];
             ss = fma(df, df, ss);
         }
+    }
+    if (ph) {                                       // the next E-step's operands of this centre, while its row is still in cache
+        __syncthreads();
+        prep_center_row(Cout, c, k, d, ph->dp, ph, mu, eh, cn, ch, ct, kp, 1, chf);
+        __syncthreads();
     }
     if (!shift) return;
     ss = wave_sum_f64(ss);
@@ -1064,13 +1120,45 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
 }
 
 extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d,
-                                   const float* C_old, float* C_out, double* shift_out, int shift_mode, void* stream_) {
+                                   const float* C_old, float* C_out, double* shift_out, int shift_mode, const void* prep,
+                                   void* estep_ws, size_t estep_ws_bytes, int64_t n, void* stream_) {
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
     SCD_REQUIRE(k <= 32768, "scd_kmeans_finalize: k=%d > 32768", k);
-    finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
-                                                         (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode);
+    const int dp = dpad(d), kp = kpad(k);
+    static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
+    static const int fuse_env = getenv("SCD_FINALIZE_PREP") ? atoi(getenv("SCD_FINALIZE_PREP")) : 1;
+    const bool fuse = prep && estep_ws && fuse_env && use_stream && kp <= 2048 && dp <= 768;
+    h->prep_C = nullptr;
+    if (fuse) {
+        // the NEXT E-step's centre operands, produced by the blocks that produce the centres (saves the prep launch and its gap)
+        SCD_REQUIRE(n > 0 && estep_ws_bytes >= scd_kmeans_estep_ws_bytes(n, d, k), "scd_kmeans_finalize: E-step workspace too small");
+        char* w = (char*)estep_ws;
+        EHdr* eh = (EHdr*)w;
+        float* cn = (float*)(w + 64);
+        half_t* ch = (half_t*)(w + 64 + scd_align(4 * (size_t)kp));
+        float* ct = (float*)((char*)ch + scd_align(2 * (size_t)kp * dp));
+        half_t* chf = (half_t*)((char*)ct + scd_align(4 * (size_t)kp * dp) + 3 * scd_align(4 * (size_t)n));
+        const char* p = (const char*)prep;
+        finalize_kernel<<<kp, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
+                                                              (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
+                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf);
+        h->prep_C = C_out;
+        h->prep_ws = estep_ws;
+        h->prep_k = k;
+        h->prep_d = d;
+    } else {
+        finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
+                                                             (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
+                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr);
+    }
     SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+extern "C" int scd_kmeans_estep_hint(scd_handle h, int expect_few_refined_rows) {
+    SCD_REQUIRE(h, "scd_kmeans_estep_hint: null handle");
+    h->estep_few = expect_few_refined_rows != 0;
     return SCD_OK;
 }
 

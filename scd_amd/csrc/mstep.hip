@@ -200,10 +200,136 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
     }
 }
 
+// The same segment reduction over an fp16 copy of X (scd_f16_exact: every value of X is exactly representable in fp16, as
+// features that left an fp16 encoder are): half the row bytes, the float64 sums are bit-identical (fp16 -> float64 is exact
+// like float32 -> float64).  Lane owns the column PAIRS 2 lane, 2 lane + 1 (+128, ...): one 4-byte load per 128 columns.
+template <int MAXG2, int MSTEP_ROWS, int MU>
+__global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __restrict__ X, const unsigned long long* __restrict__ keys,
+                                                              const float* __restrict__ Cold, long long n, int d, int k,
+                                                              long long split, double* __restrict__ sums,
+                                                              unsigned long long* __restrict__ counts, double* __restrict__ inertia) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const long long s0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MSTEP_ROWS;
+    if (s0 >= n) return;
+    const long long s1 = s0 + MSTEP_ROWS < n ? s0 + MSTEP_ROWS : n;
+    double acc[MAXG2][2];
+    float co[MAXG2][2];
+    double in0 = 0.0, in1 = 0.0;
+    int cur = -1;
+    long long run = 0;
+    auto flush = [&]() {
+        if (cur >= 0 && cur < k) {
+#pragma unroll
+            for (int g = 0; g < MAXG2; ++g) {
+                const int c = g * 128 + 2 * lane;
+                if (c < d) {
+                    atomicAdd(&sums[(size_t)cur * d + c], acc[g][0]);
+                    atomicAdd(&sums[(size_t)cur * d + c + 1], acc[g][1]);
+                }
+            }
+            if (lane == 0) atomicAdd(&counts[cur], (unsigned long long)run);
+        }
+    };
+    for (long long sb = s0; sb < s1; sb += MU) {
+        unsigned long long key[MU];
+        h2 xv[MU][MAXG2];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) key[u] = sb + u < s1 ? keys[sb + u] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const bool live = (unsigned)(key[u] >> 32) < (unsigned)k;
+            const long long row = live ? (long long)(key[u] & 0xffffffffull) : 0;
+            const half_t* xr = X + row * d;
+#pragma unroll
+            for (int g = 0; g < MAXG2; ++g) {
+                const int c = g * 128 + 2 * lane;
+                xv[u][g] = *(const h2*)(xr + (c < d ? c : d - 2));          // clamped (always valid) address, masked at use
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const int l = (int)(key[u] >> 32);
+            const long long row = (long long)(key[u] & 0xffffffffull);
+            if ((unsigned)l >= (unsigned)k) continue;
+            if (l != cur) {
+                flush();
+                cur = l;
+                run = 0;
+#pragma unroll
+                for (int g = 0; g < MAXG2; ++g) {
+                    acc[g][0] = acc[g][1] = 0.0;
+                    const int c = g * 128 + 2 * lane;
+                    co[g][0] = (Cold && c < d) ? Cold[(size_t)l * d + c] : 0.f;
+                    co[g][1] = (Cold && c < d) ? Cold[(size_t)l * d + c + 1] : 0.f;
+                }
+            }
+            ++run;
+            double a = 0.0;
+#pragma unroll
+            for (int g = 0; g < MAXG2; ++g) {
+                if (g * 128 + 2 * lane < d) {
+                    const double x0 = (double)(float)xv[u][g][0], x1 = (double)(float)xv[u][g][1];
+                    acc[g][0] += x0;
+                    acc[g][1] += x1;
+                    const double d0 = x0 - (double)co[g][0], d1 = x1 - (double)co[g][1];
+                    a = fma(d0, d0, a);
+                    a = fma(d1, d1, a);
+                }
+            }
+            if (row < split) in0 += a; else in1 += a;
+        }
+    }
+    flush();
+    if (inertia) {
+        in0 = wave_sum_f64(in0);
+        in1 = wave_sum_f64(in1);
+        if (lane == 0) {
+            if (in0 != 0.0) atomicAdd(&inertia[0], in0);
+            if (in1 != 0.0) atomicAdd(&inertia[1], in1);
+        }
+    }
+}
+
+// out16 = fp16(X); *inexact_out (device int32) = number of values that do not survive the round trip (0: the copy is exact)
+__global__ void __launch_bounds__(256) f16_exact_kernel(const float* __restrict__ X, long long n4, half_t* __restrict__ out,
+                                                        int* inexact) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = *(const float4*)(X + i * 4);
+    half4 h;
+    h[0] = (half_t)v.x; h[1] = (half_t)v.y; h[2] = (half_t)v.z; h[3] = (half_t)v.w;
+    *(half4*)(out + i * 4) = h;
+    const bool bad = (float)h[0] != v.x || (float)h[1] != v.y || (float)h[2] != v.z || (float)h[3] != v.w;     // NaN counts as inexact
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(inexact, 1);
+}
+extern "C" int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream_) {
+    SCD_REQUIRE(h && X && out16 && inexact_out && n_elems > 0 && n_elems % 4 == 0, "scd_f16_exact: bad arguments (n_elems % 4 != 0?)");
+    SCD_HIP(hipMemsetAsync(inexact_out, 0, 4, (hipStream_t)stream_));
+    f16_exact_kernel<<<(unsigned)scd_cdiv(n_elems / 4, 256), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+static int mstep_impl(scd_handle h, const float* X, const half_t* X16, const int32_t* labels, const float* C_old, int64_t n, int d,
+                      int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes, void* stream_);
+
 extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d,
                                 int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
                                 size_t ws_bytes, void* stream_) {
-    SCD_REQUIRE(h && X && labels && sums && counts && ws, "scd_kmeans_mstep: null argument");
+    SCD_REQUIRE(X, "scd_kmeans_mstep: null X");
+    return mstep_impl(h, X, nullptr, labels, C_old, n, d, k, split, sums, counts, inertia, ws, ws_bytes, stream_);
+}
+extern "C" int scd_kmeans_mstep_f16(scd_handle h, const void* X16, const int32_t* labels, const float* C_old, int64_t n, int d,
+                                    int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
+                                    size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(X16 && d % 2 == 0, "scd_kmeans_mstep_f16: null X16 or odd d");
+    return mstep_impl(h, nullptr, (const half_t*)X16, labels, C_old, n, d, k, split, sums, counts, inertia, ws, ws_bytes, stream_);
+}
+
+static int mstep_impl(scd_handle h, const float* X, const half_t* X16, const int32_t* labels, const float* C_old, int64_t n, int d,
+                      int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(h && labels && sums && counts && ws, "scd_kmeans_mstep: null argument");
     SCD_REQUIRE(n > 0 && d > 0 && d <= 1024 && k > 0 && n < (1ll << 32), "scd_kmeans_mstep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     SCD_REQUIRE(ws_bytes >= scd_kmeans_mstep_ws_bytes(n, d, k), "scd_kmeans_mstep: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
@@ -240,6 +366,17 @@ extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* lab
         else if (ms_var == 3) mstep_segment_kernel<G, 64, 8><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
         else mstep_segment_kernel<G, 32, 4><<<(unsigned)scd_cdiv(n, 4 * 32), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
     } while (0)
+    if (X16) {
+#define MSTEP16_LAUNCH(G2) mstep_segment16_kernel<G2, 64, 8><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X16, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia)
+        if (d <= 128) MSTEP16_LAUNCH(1);
+        else if (d <= 256) MSTEP16_LAUNCH(2);
+        else if (d <= 512) MSTEP16_LAUNCH(4);
+        else if (d <= 768) MSTEP16_LAUNCH(6);
+        else MSTEP16_LAUNCH(8);
+#undef MSTEP16_LAUNCH
+        SCD_LAUNCH_CHECK();
+        return SCD_OK;
+    }
     if (d <= 64) MSTEP_LAUNCH(1);
     else if (d <= 128) MSTEP_LAUNCH(2);
     else if (d <= 256) MSTEP_LAUNCH(4);

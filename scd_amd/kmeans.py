@@ -37,8 +37,8 @@ class HipBackend:
     def prepare(self, x):
         return self.ops.KMeansData(x)
 
-    def estep(self, data, centers):
-        return data.estep(centers)
+    def estep(self, data, centers, expect_few=False):
+        return data.estep(centers, expect_few=expect_few)
 
     def rowdist(self, data, centers, labels):
         return data.rowdist(centers, labels)
@@ -49,11 +49,14 @@ class HipBackend:
     def dist(self, data, centers, sqrt=False, with_cost=False):
         return data.dist(centers, sqrt=sqrt, with_cost=with_cost)
 
-    def mstep(self, x, labels32, c_old, k, split):
-        return self.ops.kmeans_mstep(x, labels32, c_old, k, split)
+    def mstep(self, x, labels32, c_old, k, split, x16=None):
+        return self.ops.kmeans_mstep(x, labels32, c_old, k, split, x16=x16)
 
-    def finalize(self, sums, counts, c_old):
-        return self.ops.kmeans_finalize(sums, counts, c_old)
+    def exact_f16(self, x):
+        return self.ops.f16_exact(x)
+
+    def finalize(self, sums, counts, c_old, data=None):
+        return self.ops.kmeans_finalize(sums, counts, c_old, data=data)
 
     def sum_f32(self, x):
         return self.ops.sum_f32(x)
@@ -213,22 +216,27 @@ class KMeansEngine:
         return dd.broadcast_(row.contiguous(), owner)
 
     # E-step on the unlabelled rows -> (int32 labels on device, float32 inertia contribution or None)
-    def _assign(self, data, centers):
+    def _assign(self, data, centers, it=0):
         self.stats["estep_calls"] += 1
-        return self._be().estep(data, centers), None
+        return self._be().estep(data, centers, expect_few=it >= 2), None
 
     def _lloyd(self, data_u, cat, labels, l_num, centers):
         """Iterations shared by fit_once / fit_mix_once (sskm_constrained.py:110-138)."""
         be = self._be()
         dd = self._dist()
+        key = (cat.data_ptr(), tuple(cat.shape))
+        if getattr(self, "_cat16_key", None) != key:            # once per data set: the M-step streams an fp16 copy when it is exact
+            self._cat16 = be.exact_f16(cat) if hasattr(be, "exact_f16") else None
+            self._cat16_key = key
+        cat16 = self._cat16
         best = (None, None, None)
         it = 0
         for it in range(self.max_iterations):
             old = centers
-            u_lab, u_inertia = self._assign(data_u, old)
+            u_lab, u_inertia = self._assign(data_u, old, it)
             labels[l_num:] = u_lab.to(labels.dtype)
             lab32 = labels.to(torch.int32).contiguous()
-            sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num)
+            sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, self.k, l_num)
             if dd:
                 packed = torch.cat([sums.reshape(-1), counts.to(torch.float64), inertia2])
                 dd.allreduce_(packed)
@@ -236,7 +244,7 @@ class KMeansEngine:
                 sums = packed[:kd].reshape(sums.shape)
                 counts = packed[kd:kd + self.k].round().to(torch.int64)
                 inertia2 = packed[kd + self.k:]
-            centers, shift = be.finalize(sums, counts, old)
+            centers, shift = be.finalize(sums, counts, old, data_u)
             host = torch.cat([inertia2, shift.reshape(1)]).cpu().numpy()          # the only per-iteration D2H
             ui = np.float32(host[1]) if u_inertia is None else np.float32(u_inertia)
             inertia = np.float32(ui + np.float32(host[0]))
@@ -321,7 +329,7 @@ class ConstrainedEngine(KMeansEngine):
         self.size_min = size_min
         self.size_max = size_max
 
-    def _assign(self, data, centers):
+    def _assign(self, data, centers, it=0):
         be = self._be()
         d_sqrt, cost = be.dist(data, centers, sqrt=True, with_cost=True)
         dd = self._dist()

@@ -131,12 +131,16 @@ class KMeansData:
             w = self._ws[key] = _ws(nbytes, self.x.device)
         return w
 
-    def estep(self, centers, return_refined=False):
+    def estep(self, centers, return_refined=False, expect_few=False):
+        """expect_few: few rows are expected inside the filter's error bound (late Lloyd iterations): they are re-evaluated in
+        the filter kernel's tail, no refine launch.  Same labels either way."""
         _need_cuda(self.x)
+        if expect_few:
+            check(_L().scd_kmeans_estep_hint(handle(), 1))
         k = centers.shape[0]
         centers = centers.to(torch.float32).contiguous()
         labels = torch.empty(self.n, dtype=torch.int32, device=self.x.device)
-        ref = torch.zeros(1, dtype=torch.int32, device=self.x.device)
+        ref = torch.zeros(1, dtype=torch.int32, device=self.x.device) if return_refined else None     # (a fill launch otherwise)
         nb = _L().scd_kmeans_estep_ws_bytes(self.n, self.d, k)
         ws = self.ws(("e", k), nb)
         check(_L().scd_kmeans_estep(handle(), ptr(self.x), ptr(self.prep), ptr(centers), self.n, self.d, k, ptr(labels),
@@ -167,28 +171,51 @@ class KMeansData:
         return (out, cost) if with_cost else out
 
 
-def kmeans_mstep(x, labels32, c_old, k, split=0):
-    """(sums float64 [k,d], counts int64 [k], inertia float64 [2]) partials of one rank."""
+def f16_exact(x):
+    """fp16 copy of x if every value survives the round trip (features that left an fp16 encoder), else None.  One device
+    read-back per data set; the copy halves the bytes the M-step streams per Lloyd iteration."""
+    _need_cuda(x)
+    x = x.to(torch.float32).contiguous()
+    if x.numel() % 4 or x.shape[-1] % 2:
+        return None
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    bad = torch.empty(1, dtype=torch.int32, device=x.device)
+    check(_L().scd_f16_exact(handle(), ptr(x), x.numel(), ptr(out), ptr(bad), stream_ptr()))
+    return out if int(bad.item()) == 0 else None
+
+
+def kmeans_mstep(x, labels32, c_old, k, split=0, x16=None):
+    """(sums float64 [k,d], counts int64 [k], inertia float64 [2]) partials of one rank.  x16: the exact fp16 copy of x
+    (f16_exact), streamed instead of x."""
     _need_cuda(x, labels32)
     n, d = x.shape
     sums = torch.empty((k, d), dtype=torch.float64, device=x.device)
     counts = torch.empty(k, dtype=torch.int64, device=x.device)
-    inertia = torch.zeros(2, dtype=torch.float64, device=x.device)
+    inertia = torch.empty(2, dtype=torch.float64, device=x.device)          # zeroed by the library (no torch fill launch)
     nb = _L().scd_kmeans_mstep_ws_bytes(n, d, k)
     ws = _ws(nb, x.device)
-    check(_L().scd_kmeans_mstep(handle(), ptr(x), ptr(labels32), ptr(c_old), n, d, k, int(split), ptr(sums), ptr(counts),
-                                ptr(inertia), ptr(ws), nb, stream_ptr()))
+    if x16 is not None:
+        check(_L().scd_kmeans_mstep_f16(handle(), ptr(x16), ptr(labels32), ptr(c_old), n, d, k, int(split), ptr(sums), ptr(counts),
+                                        ptr(inertia), ptr(ws), nb, stream_ptr()))
+    else:
+        check(_L().scd_kmeans_mstep(handle(), ptr(x), ptr(labels32), ptr(c_old), n, d, k, int(split), ptr(sums), ptr(counts),
+                                    ptr(inertia), ptr(ws), nb, stream_ptr()))
     return sums, counts, inertia
 
 
-def kmeans_finalize(sums, counts, c_old=None, shift_mode=0):
-    """shift_mode 0: (sum_k ||dc_k||)^2 (the reference's SSKM test); 1: sum_k ||dc_k||^2 (sklearn's center_shift_tot)."""
+def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):
+    """shift_mode 0: (sum_k ||dc_k||)^2 (the reference's SSKM test); 1: sum_k ||dc_k||^2 (sklearn's center_shift_tot).
+    data (a KMeansData): the centres' E-step operands are produced by the same launch, for the next data.estep(centres)."""
     _need_cuda(sums)
     k, d = sums.shape
     c = torch.empty((k, d), dtype=torch.float32, device=sums.device)
-    shift = torch.zeros(1, dtype=torch.float64, device=sums.device)
+    shift = torch.empty(1, dtype=torch.float64, device=sums.device)
+    prep, ws, nb, n = None, None, 0, 0
+    if data is not None and data.d == d:
+        nb = _L().scd_kmeans_estep_ws_bytes(data.n, d, k)
+        prep, ws, n = data.prep, data.ws(("e", k), nb), data.n
     check(_L().scd_kmeans_finalize(handle(), ptr(sums), ptr(counts), k, d, ptr(c_old), ptr(c), ptr(shift), int(shift_mode),
-                                   stream_ptr()))
+                                   ptr(prep), ptr(ws), nb, n, stream_ptr()))
     return c, shift
 
 

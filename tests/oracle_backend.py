@@ -18,7 +18,7 @@ class OracleBackend:
     def prepare(self, x):
         return _Data(x)
 
-    def estep(self, data, centers):
+    def estep(self, data, centers, expect_few=False):
         lab, _, _ = ko.estep(data.x.numpy(), centers.numpy())
         return torch.from_numpy(lab.astype(np.int32))
 
@@ -49,7 +49,7 @@ class OracleBackend:
             inertia[:] = [row[:split].sum(), row[split:].sum()]
         return torch.from_numpy(sums), torch.from_numpy(counts), torch.from_numpy(inertia)
 
-    def finalize(self, sums, counts, c_old):
+    def finalize(self, sums, counts, c_old, data=None):
         with np.errstate(invalid="ignore", divide="ignore"):
             c = (sums.numpy() / counts.numpy().astype(np.float64)[:, None]).astype(np.float32)
         shift = np.array([np.nan])

@@ -116,6 +116,7 @@ def test_estep_unstructured_data_takes_refine_path(ops):
     olab, _, _ = ko.estep(x, c)
     assert np.array_equal(lab.cpu().numpy(), olab)
     assert int(ref.item()) > 0 and 3 not in set(lab.cpu().numpy().tolist())
+    assert torch.equal(data.estep(dev(c), expect_few=True), lab)          # tail refine: same decisions
 
 
 def test_estep_nan_centre_never_wins(ops):
@@ -142,6 +143,9 @@ def test_estep_stream_kernel_shapes(ops, n, d, k, seed):
     olab, omind, _ = ko.estep(x, c)
     assert np.array_equal(lab.cpu().numpy().astype(np.int64), olab)
     assert np.array_equal(data.rowdist(dev(c), lab).cpu().numpy(), omind)
+    # the same rows re-evaluated in the filter kernel's tail (scd_kmeans_estep_hint) instead of by the refine launch
+    lab2, ref2 = data.estep(dev(c), return_refined=True, expect_few=True)
+    assert torch.equal(lab2, lab) and int(ref2.item()) == int(ref.item())
 
 
 def test_estep_stream_kernel_many_units_per_block(ops):
@@ -183,6 +187,30 @@ def test_mstep_counting_sort_edges(ops, n, d, k):
     np.add.at(ref, labels[ok], x[ok].astype(np.float64))
     assert np.array_equal(counts.cpu().numpy(), np.bincount(labels[ok], minlength=k))
     assert np.allclose(sums.cpu().numpy(), ref, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("n,d,k", [(5000, 768, 37), (3001, 512, 100), (777, 64, 5), (2000, 130, 9)])
+def test_mstep_f16_copy_gives_the_same_partials(ops, n, d, k):
+    """scd_kmeans_mstep_f16 on the exact fp16 copy (scd_f16_exact) = scd_kmeans_mstep on the float32 rows: same counts, float64
+    sums equal to round-off of the atomic order, centres bit-equal after the single rounding to float32; a matrix with one value
+    that fp16 cannot hold is refused."""
+    x, y, cent = synth.clustered_features(n, d, k, seed=n)
+    x = x.astype(np.float16).astype(np.float32)                   # what an fp16 encoder hands over
+    rs = np.random.RandomState(2)
+    labels = rs.randint(0, k, size=n).astype(np.int32)
+    labels[3] = -1
+    xd = dev(x)
+    x16 = ops.f16_exact(xd)
+    assert x16 is not None and x16.dtype == torch.float16 and torch.equal(x16.float(), xd)
+    s32, c32, i32 = ops.kmeans_mstep(xd, dev(labels), dev(cent), k, n // 3)
+    s16, c16, i16 = ops.kmeans_mstep(xd, dev(labels), dev(cent), k, n // 3, x16=x16)
+    assert torch.equal(c32, c16)
+    assert torch.allclose(s32, s16, rtol=1e-13, atol=1e-13) and torch.allclose(i32, i16, rtol=1e-12)
+    ce32, _ = ops.kmeans_finalize(s32, c32, dev(cent))
+    ce16, _ = ops.kmeans_finalize(s16, c16, dev(cent))
+    assert torch.equal(ce32.nan_to_num(7.0), ce16.nan_to_num(7.0))
+    x[5, 7] = 1.0 + 2.0 ** -12                                     # not an fp16 value
+    assert ops.f16_exact(dev(x)) is None
 
 
 def test_dist_and_costs(ops):

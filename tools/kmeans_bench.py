@@ -31,7 +31,8 @@ if __name__ == "__main__":
     data = ops.KMeansData(X)
     for name, cc in (("converged centres", C), ("data-point centres", C2)):
         lab, ref = data.estep(cc, return_refined=True)
-        us = timeit(lambda: data.estep(cc))
+        few = name.startswith("converged")
+        us = timeit(lambda: data.estep(cc, expect_few=few))
         dp = (d + 127) // 128 * 128
         algo = n * dp * 2 + 4 * n + ((k + 127) // 128 * 128) * dp * 2
         print("estep  [%s] %8.1f us  refined rows %6d (%.2f%%)  algorithmic %.1f MB -> %.0f GB/s" % (name, us, int(ref), 100.0 * int(ref) / n, algo / 1e6, algo / us / 1e3))
@@ -39,6 +40,11 @@ if __name__ == "__main__":
     us = timeit(lambda: ops.kmeans_mstep(X, lab, C, k, 0))
     algo = n * d * 4 + 4 * n
     print("mstep  %8.1f us  algorithmic %.1f MB -> %.0f GB/s" % (us, algo / 1e6, algo / us / 1e3))
+    X16 = ops.f16_exact(X.half().float())
+    Xe = X.half().float().contiguous()
+    us = timeit(lambda: ops.kmeans_mstep(Xe, lab, C, k, 0, x16=X16))
+    algo = n * d * 2 + 4 * n
+    print("mstep on the exact fp16 copy %8.1f us  algorithmic %.1f MB -> %.0f GB/s" % (us, algo / 1e6, algo / us / 1e3))
     d2 = data.rowdist(C, lab)
     us = timeit(lambda: data.min_update(X[17], d2))
     algo = n * d * 4 + 8 * n
@@ -48,3 +54,19 @@ if __name__ == "__main__":
     sums, counts, _ = ops.kmeans_mstep(X, lab, C, k, 0)
     us = timeit(lambda: ops.kmeans_finalize(sums, counts, C))
     print("final  %8.1f us" % us)
+    us = timeit(lambda: ops.kmeans_finalize(sums, counts, C, data=data))
+    print("final+prep (fused E-step operands) %8.1f us" % us)
+    # one Lloyd iteration as scd_amd.kmeans runs it: E-step (operands prepared by the previous finalize) + M-step + finalize
+    state = {"c": C, "x16": None}
+    def lloyd():
+        lab = data.estep(state["c"], expect_few=True)
+        sums, counts, _ = ops.kmeans_mstep(X, lab, state["c"], k, 0, x16=state["x16"])
+        state["c"], _ = ops.kmeans_finalize(sums, counts, state["c"], data=data)
+    for tag, x16 in (("float32 rows", None), ("exact fp16 copy", X16)):
+        state.update(c=C, x16=x16)
+        us = timeit(lloyd)
+        algo = n * dp * 2 + n * d * (4 if x16 is None else 2) + 8 * n
+        print("lloyd iteration (estep + mstep[%s] + finalize, no host sync) %8.1f us   X bytes read %.1f MB -> %.0f GB/s" % (tag, us, algo / 1e6, algo / us / 1e3))
+    cc, _ = ops.kmeans_finalize(sums, counts, C, data=data)
+    us = timeit(lambda: data.estep(cc, expect_few=True))          # the hand-over is consumed by the first call only: this times prep + stream
+    print("estep call without hand-over %8.1f us" % us)
