@@ -144,9 +144,9 @@ def dominant_kernel_roofline(ms, launches, flop):
 
 def secondary_rooflines(out, wt, dev):
     """Call-level rates of the two other kernels north_star names, measured after the timed region on this run's own
-    tensors (HIP events on the current stream, 20 calls each): the similarity + top-k call (MFMA-bound) and one k-means
-    E-step call (HBM-bound: centre prep + streaming filter + refine launch).  Informational; `roofline` above stays the
-    dominant kernel of the metric."""
+    tensors (HIP events on the current stream, 20 calls each): the similarity + top-k call (MFMA-bound) and the k-means
+    E-step call (HBM-bound: centre prep + streaming filter + refine) on the run's features and on clustered features of the
+    same shape.  Informational; `roofline` above stays the dominant kernel of the metric."""
     import torch
     from scd_amd import ops
     res = []
@@ -174,12 +174,24 @@ def secondary_rooflines(out, wt, dev):
     c = out["kmeans"].cluster_centers_.to(torch.float32).contiguous()
     k = int(c.shape[0])
     data = ops.KMeansData(x)
-    t = timeit(lambda: data.estep(c))
     dp = (d + 127) // 128 * 128
     by = n * dp * 2 + 4 * n + 128 * dp * 2
-    res.append({"kernel": "scd_kmeans_estep call (prep_centers + estep_stream_kernel + refine), N=%d D=%d K=%d" % (n, d, k),
+
+    def estep_line(tag, dat, cen, few):
+        _, ref = dat.estep(cen, return_refined=True)
+        t = timeit(lambda: dat.estep(cen, expect_few=few))
+        return {"kernel": "scd_kmeans_estep call (centre prep + estep_stream_kernel + refine), N=%d D=%d K=%d, %s" % (n, d, k, tag),
                 "bound": "hbm", "achieved": round(by / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / t / 8e12, 4),
-                "call_us": round(t * 1e6, 1)})
+                "call_us": round(t * 1e6, 1), "rows_refined": int(ref.item())}
+    # (i) the run's own features and final centres: CLIP features of SYNTHETIC images sit in one blob, many rows fall inside the
+    # filter's error bound and are re-evaluated exactly; (ii) the same shape with cluster structure (SURVEY.md 8d generator), where
+    # the filter decides every row - the regime of real features and of the north-star HBM target
+    res.append(estep_line("this run's features / final centres", data, c, False))
+    g = torch.Generator(device=dev).manual_seed(11)
+    cen = torch.nn.functional.normalize(torch.randn(k, d, device=dev, generator=g), dim=-1)
+    yy = torch.randint(0, k, (n,), device=dev, generator=g)
+    xc = torch.nn.functional.normalize(cen[yy] + (0.8 / d ** 0.5) * torch.randn(n, d, device=dev, generator=g), dim=-1)
+    res.append(estep_line("clustered synthetic features / converged centres", ops.KMeansData(xc), cen.contiguous(), True))
     return res
 
 

@@ -734,8 +734,9 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
                 constexpr int q = decltype(qc)::value;
                 constexpr int h = 2 * s + decltype(qc)::value;
                 if constexpr (!(XM & 4)) {
-                    if (s == 0) RB_MFMA0(acc[P][q], fr[s & 3], bf[q][s]);
-                    else RB_MFMA(acc[P][q], fr[s & 3], bf[q][s]);
+                    constexpr int PP = (XM & 8) ? ((s & 1) ? 1 - P : P) : P;        // XM & 8 (timing only): four accumulator chains
+                    if (s == 0 || ((XM & 8) && s == 1)) RB_MFMA0(acc[PP][q], fr[s & 3], bf[q][s]);
+                    else RB_MFMA(acc[PP][q], fr[s & 3], bf[q][s]);
                 }
                 if constexpr (decltype(qc)::value == 1 && !(XM & 2))
                     if ((s & 3) == 3 && fills) fill(u + 3, s >> 2);
@@ -1134,7 +1135,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
             switch (sim_x_rb) {
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
-                RB_X(1) RB_X(3) RB_X(4) RB_X(5)
+                RB_X(1) RB_X(3) RB_X(4)
 #undef RB_X
             }
             SCD_LAUNCH_CHECK();

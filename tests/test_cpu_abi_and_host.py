@@ -274,3 +274,60 @@ def test_soft_semantic_acc_memoised_equals_per_sample_loop():
     calls["n"] = 0
     assert naming.evaluate_soft_semantic_acc(t[:100], cidx_to_cname, p[:100], cand, wnid_to_synset, name_to_wnids, cache=cache) > 0
     assert calls["n"] == 0                                     # a second call over the same pairs walks nothing
+
+
+def test_bpe_tokenizer_against_independent_implementation(tmp_path, monkeypatch):
+    """Rows a4 / N3: scd_amd.clip.SimpleTokenizer (byte-level BPE of the third-party `clip` package, absent here together with
+    its 16e6 merges file) against the `tokenizers` library's BPE on the SAME merges table: a small table is learned on prompt-like
+    text, written in the package's file format (gzip, header line, one merge per line), loaded by SimpleTokenizer, and the token
+    ids of prompts with apostrophes, hyphens, digits and repeated words must be identical; clip.tokenize frames them with
+    SOT / EOT and zero padding to 77."""
+    import gzip
+    import json
+    tokenizers = pytest.importorskip("tokenizers")
+    from tokenizers import Regex, Tokenizer, models, normalizers, pre_tokenizers, trainers
+    import scd_amd.clip as clip
+    words = ("red fox", "tabby cat", "kit fox", "zebra", "grey whale", "arctic fox", "sea lion", "golden retriever", "labrador retriever",
+             "american black bear", "b-flat clarinet", "carpenter's kit", "soft-coated wheaten terrier", "4x4 truck", "don't")
+    corpus = ["a photo of a %s." % w for w in words] * 3
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))
+    cs, n = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    alphabet = [chr(c) for c in cs]
+    pat = r"""<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"""
+
+    def make(model):
+        tk = Tokenizer(model)
+        tk.normalizer = normalizers.Lowercase()
+        tk.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(pat), behavior="removed", invert=True),
+                                                    pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+        return tk
+    learner = make(models.BPE(end_of_word_suffix="</w>"))
+    learner.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=700, initial_alphabet=alphabet, end_of_word_suffix="</w>",
+                                                            special_tokens=[], show_progress=False))
+    merges = [tuple(m) for m in json.loads(learner.to_str())["model"]["merges"]]
+    assert len(merges) > 50
+    path = tmp_path / "bpe_simple_vocab_16e6.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    ours = clip.SimpleTokenizer(str(path))
+    assert ours.sot == len(ours.encoder) - 2 and ours.eot == len(ours.encoder) - 1
+    ref = make(models.BPE(vocab=dict(ours.encoder), merges=merges, end_of_word_suffix="</w>"))
+    texts = ["a photo of a red fox.", "A bad photo of the Carpenter's kit!", "art of the b-flat clarinet.", "a 4x4 truck, don't", "the   origami zebra  ",
+             "a photo of a soft-coated wheaten terrier.", "itap of a labrador retriever retriever.", "graffiti of a sea lion &amp; a kit fox"]
+    for t in texts:
+        import html
+        want = ref.encode(" ".join(html.unescape(t).split()).strip()).ids
+        assert ours.encode(t) == want, t
+    monkeypatch.setattr(clip, "_tokenizer", ours)
+    tok = clip.tokenize(texts[:2])
+    assert tok.shape == (2, 77) and tok.dtype.is_floating_point is False
+    ids = ours.encode(texts[0])
+    assert tok[0, 0].item() == ours.sot and tok[0, 1:1 + len(ids)].tolist() == ids and tok[0, 1 + len(ids)].item() == ours.eot
+    assert int(tok[0, 2 + len(ids):].abs().sum()) == 0
+    with pytest.raises(RuntimeError, match="too long"):
+        clip.tokenize(["fox " * 100])
