@@ -167,7 +167,7 @@ def secondary_rooflines(out, wt, dev):
     v = wt.shape[0]
     t = timeit(lambda: ops.sim_topk(feats, wt, 3, "softmax"), 5)
     fl = 2.0 * n * v * d
-    res.append({"kernel": "scd_sim_topk call (sim_topk_kernel + refine), %d x %d x %d" % (n, v, d), "bound": "mfma",
+    res.append({"kernel": "scd_sim_topk call (sim_topk_rb_kernel + sim_refine_kernel), %d x %d x %d" % (n, v, d), "bound": "mfma",
                 "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4),
                 "call_us": round(t * 1e6, 1)})
     x = feats.float()

@@ -128,6 +128,14 @@ int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int6
 size_t scd_kpp_draw_ws_bytes(int64_t n);
 int scd_kpp_draw(scd_handle h, const float* d2, int64_t n, float r, const double* total, const double* prefix,
                  int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream);
+/* The same for R restarts in lock-step (the n_init restarts of one fit share X and a fixed random stream): d2 [R][ld] (ld >= n),
+ * c_new [R][d], r_dev device float [R], total / prefix / idx_out / probsum_out device arrays of R (or NULL as above).  X is read
+ * once per round instead of R times; ws: R * scd_kpp_draw_ws_bytes(n).  scd_sum_f32_multi: out[r] = float64 sum of row r. */
+int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R, float* d2_inout,
+                                int64_t ld, void* stream);
+int scd_kpp_draw_multi(scd_handle h, const float* d2, int64_t n, int64_t ld, int R, const float* r_dev, const double* total,
+                       const double* prefix, int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream);
+int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_t ld, int R, double* out, void* stream);
 /* deterministic float64 sum of a float32 vector (inertia, d2.sum()) */
 int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out, void* stream);
 

@@ -1425,3 +1425,178 @@ extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, co
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ for R restarts in lock-step (the restarts of one fit share X and draw from a fixed random stream, so their t-th
+// centres can be added together): X is read ONCE per round instead of R times, and a round is 4 launches instead of 4 R.
+//   scd_kmeans_min_update_multi   d2[r][i] = min(d2[r][i], ||x_i - c_r||^2), r < R: one wave per row keeps the row in registers
+//                                 and sweeps the R new centres (same per-lane float64 order as rowdist_kernel: same bits)
+//   scd_kpp_draw_multi            the draw of scd_kpp_draw for R vectors, blockIdx.y = restart
+template <int NV>
+__global__ void __launch_bounds__(256) minupd_multi_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
+                                                           int R, float* __restrict__ d2, long long ld) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* x = X + row * d;
+    float4 xv[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+        const int j = lane * 4 + 256 * t;
+        xv[t] = j < d ? *(const float4*)(x + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int r = 0; r < R; ++r) {
+        const float* c = Cn + (size_t)r * d;
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int j = lane * 4 + 256 * t;
+            if (j < d) {
+                const float4 cv = *(const float4*)(c + j);
+                double a = (double)xv[t].x - (double)cv.x; s = fma(a, a, s);
+                a = (double)xv[t].y - (double)cv.y; s = fma(a, a, s);
+                a = (double)xv[t].z - (double)cv.z; s = fma(a, a, s);
+                a = (double)xv[t].w - (double)cv.w; s = fma(a, a, s);
+            }
+        }
+        s = wave_sum_f64(s);
+        if (lane == 0) {
+            float* p = d2 + (size_t)r * ld + row;
+            *p = fminf(*p, (float)s);
+        }
+    }
+}
+
+extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R,
+                                           float* d2_inout, int64_t ld, void* stream_) {
+    SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0 && R > 0 && ld >= n, "scd_kmeans_min_update_multi: bad arguments");
+    SCD_REQUIRE(d % 4 == 0 && d <= 1024, "scd_kmeans_min_update_multi: d=%d must be a multiple of 4, <= 1024", d);
+    hipStream_t st = (hipStream_t)stream_;
+    const unsigned g = (unsigned)scd_cdiv(n, 4);
+    if (d <= 256) minupd_multi_kernel<1><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
+    else if (d <= 512) minupd_multi_kernel<2><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
+    else if (d <= 768) minupd_multi_kernel<3><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
+    else minupd_multi_kernel<4><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+__global__ void __launch_bounds__(1024) kpp_tile_sum_multi_kernel(const float* __restrict__ d2, long long n, long long ld, double* bsum, int nb) {
+    __shared__ double sh[16];
+    const float* v = d2 + (size_t)blockIdx.y * ld;
+    const long long i0 = (long long)blockIdx.x * KPP_TILE + threadIdx.x * 4;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) s += (double)v[i0 + q];
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) bsum[(size_t)blockIdx.y * nb + blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(1024) kpp_tile_prob_multi_kernel(const float* __restrict__ d2, long long n, long long ld, const double* bsum,
+                                                                   int nb, const double* total_in, double* psum) {
+    __shared__ double sh[16];
+    const int y = blockIdx.y;
+    const float totf = kpp_total(bsum + (size_t)y * nb, nb, total_in ? total_in + y : nullptr);
+    const float* v = d2 + (size_t)y * ld;
+    const long long i0 = (long long)blockIdx.x * KPP_TILE + threadIdx.x * 4;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i0 + q < n) s += (double)__fdiv_rn(v[i0 + q], totf);
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) psum[(size_t)y * nb + blockIdx.x] = s;
+}
+// (the pick of kpp_pick_kernel, one block per restart)
+__global__ void __launch_bounds__(1024) kpp_pick_multi_kernel(const float* __restrict__ d2, long long n, long long ld, const float* __restrict__ rarr,
+                                                              const double* bsum_all, const double* psum_all, int nb, const double* total_in,
+                                                              const double* prefix_in, long long* idx_out, double* probsum_out) {
+    __shared__ double sh[32];
+    __shared__ long long best;
+    __shared__ int owner;
+    __shared__ double owner_pre;
+    const int y = blockIdx.x;
+    const float* v = d2 + (size_t)y * ld;
+    const double* bsum = bsum_all + (size_t)y * nb;
+    const double* psum = psum_all + (size_t)y * nb;
+    const float r = rarr[y];
+    const float totf = kpp_total(bsum, nb, total_in ? total_in + y : nullptr);
+    if (threadIdx.x == 0) {
+        double run = prefix_in ? prefix_in[y] : 0.0;
+        int ow = -1;
+        double opre = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double nxt = run + psum[b];
+            if (ow < 0 && (float)nxt >= r) { ow = b; opre = run; }
+            run = nxt;
+        }
+        owner = ow;
+        owner_pre = opre;
+        best = 0x7fffffffffffffffll;
+        if (probsum_out) probsum_out[y] = run - (prefix_in ? prefix_in[y] : 0.0);
+    }
+    __syncthreads();
+    if (!idx_out) return;
+    if (owner < 0) {
+        if (threadIdx.x == 0) idx_out[y] = -1;
+        return;
+    }
+    double pre = owner_pre;
+    for (int b = owner; b < nb; ++b) {
+        const long long i0 = (long long)b * KPP_TILE + threadIdx.x * 4;
+        float pv[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pv[q] = (i0 + q < n) ? __fdiv_rn(v[i0 + q], totf) : 0.f;
+            s += (double)pv[q];
+        }
+        double tot;
+        double run = pre + block_scan_excl_1024(s, sh, &tot);
+        long long found = 0x7fffffffffffffffll;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += (double)pv[q];
+            if (found == 0x7fffffffffffffffll && i0 + q < n && (float)run >= r) found = i0 + q;
+        }
+        if (found != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&best, (unsigned long long)found);
+        __syncthreads();
+        if (best != 0x7fffffffffffffffll) break;
+        pre += tot;
+    }
+    if (threadIdx.x == 0) idx_out[y] = (best == 0x7fffffffffffffffll) ? -1 : best;
+}
+
+extern "C" int scd_kpp_draw_multi(scd_handle h, const float* d2, int64_t n, int64_t ld, int R, const float* r_dev, const double* total,
+                                  const double* prefix, int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes,
+                                  void* stream_) {
+    SCD_REQUIRE(h && d2 && r_dev && (idx_out || probsum_out) && n > 0 && ld >= n && R > 0 && ws, "scd_kpp_draw_multi: bad arguments");
+    SCD_REQUIRE(ws_bytes >= (size_t)R * scd_kpp_draw_ws_bytes(n), "scd_kpp_draw_multi: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const int nb = (int)scd_cdiv(n, KPP_TILE);
+    double* bsum = (double*)ws;
+    double* psum = bsum + (size_t)R * nb;
+    if (!total) kpp_tile_sum_multi_kernel<<<dim3(nb, R), 1024, 0, st>>>(d2, n, ld, bsum, nb);
+    kpp_tile_prob_multi_kernel<<<dim3(nb, R), 1024, 0, st>>>(d2, n, ld, bsum, nb, total, psum);
+    kpp_pick_multi_kernel<<<R, 1024, 0, st>>>(d2, n, ld, r_dev, bsum, psum, nb, total, prefix, (long long*)idx_out, probsum_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// per-row float64 sums of R float32 vectors (the shard totals of the lock-step k-means++ under a process group)
+__global__ void __launch_bounds__(1024) sum_multi_kernel(const float* __restrict__ x, long long n, long long ld, double* out) {
+    __shared__ double sh[32];
+    const float* v = x + (size_t)blockIdx.x * ld;
+    const long long seg = scd_cdiv_dev(n, 1024);
+    const long long a = threadIdx.x * seg, b = (a + seg < n) ? a + seg : n;
+    double s = 0.0;
+    for (long long i = a; i < b; ++i) s += (double)v[i];
+    double tot;
+    block_scan_excl_1024(s, sh, &tot);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_t ld, int R, double* out, void* stream_) {
+    SCD_REQUIRE(h && x && out && n > 0 && ld >= n && R > 0, "scd_sum_f32_multi: bad arguments");
+    sum_multi_kernel<<<R, 1024, 0, (hipStream_t)stream_>>>(x, n, ld, out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}

@@ -259,6 +259,39 @@ def kpp_draw(d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
 _kpp_ws = {}
 
 
+def min_update_multi(x, c_new, d2):
+    """d2[r] = min(d2[r], ||x - c_new[r]||^2) for the R rows of c_new at once (x read once).  d2 float32 [R, n], in place."""
+    _need_cuda(x, c_new, d2)
+    c_new = c_new.to(torch.float32).contiguous()
+    n, d = x.shape
+    check(_L().scd_kmeans_min_update_multi(handle(), ptr(x), ptr(c_new), n, d, c_new.shape[0], ptr(d2), d2.stride(0), stream_ptr()))
+
+
+def kpp_draw_multi(d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+    """scd_kpp_draw for every row of d2 [R, n] with the uniforms r (host floats [R]).  Returns (idx int64 [R] or None,
+    probsum float64 [R] or None)."""
+    _need_cuda(d2)
+    rr, n = d2.shape
+    rdev = torch.as_tensor(np.asarray(r, dtype=np.float32)).to(d2.device)
+    idx = torch.empty(rr, dtype=torch.int64, device=d2.device) if want_idx else None
+    ps = torch.empty(rr, dtype=torch.float64, device=d2.device) if want_probsum else None
+    nb = rr * _L().scd_kpp_draw_ws_bytes(n)
+    ws = _kpp_ws.get((d2.device, nb))
+    if ws is None:
+        ws = _kpp_ws[(d2.device, nb)] = _ws(nb, d2.device)
+    check(_L().scd_kpp_draw_multi(handle(), ptr(d2), n, d2.stride(0), rr, ptr(rdev), ptr(total), ptr(prefix), ptr(idx), ptr(ps),
+                                  ptr(ws), nb, stream_ptr()))
+    return idx, ps
+
+
+def sum_f32_multi(x):
+    """float64 row sums of a float32 matrix [R, n] (deterministic order)."""
+    _need_cuda(x)
+    out = torch.empty(x.shape[0], dtype=torch.float64, device=x.device)
+    check(_L().scd_sum_f32_multi(handle(), ptr(x), x.shape[1], x.stride(0), x.shape[0], ptr(out), stream_ptr()))
+    return out
+
+
 def sum_f32(x):
     _need_cuda(x)
     x = x.to(torch.float32).contiguous()
