@@ -1011,12 +1011,12 @@ extern "C" int scd_kmeans_rowdist(scd_handle h, const float* X, const float* C, 
     return SCD_OK;
 }
 
+extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R,
+                                           float* d2_inout, int64_t ld, void* stream_);
 extern "C" int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int64_t n, int d, float* d2_inout,
                                      void* stream_) {
     SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0, "scd_kmeans_min_update: bad arguments");
-    rowdist_kernel<true><<<(unsigned)scd_cdiv(n, 4), 256, 0, (hipStream_t)stream_>>>(X, c_new, nullptr, n, d, 1, d2_inout);
-    SCD_LAUNCH_CHECK();
-    return SCD_OK;
+    return scd_kmeans_min_update_multi(h, X, c_new, n, d, 1, d2_inout, n, stream_);
 }
 
 // full [n,k] exact distances: each wave keeps 4 rows in registers and sweeps the centres
@@ -1429,54 +1429,108 @@ extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, co
 // ------------------------------------------------------------------------------------------------
 // k-means++ for R restarts in lock-step (the restarts of one fit share X and draw from a fixed random stream, so their t-th
 // centres can be added together): X is read ONCE per round instead of R times, and a round is 4 launches instead of 4 R.
-//   scd_kmeans_min_update_multi   d2[r][i] = min(d2[r][i], ||x_i - c_r||^2), r < R: one wave per row keeps the row in registers
-//                                 and sweeps the R new centres (same per-lane float64 order as rowdist_kernel: same bits)
+//   scd_kmeans_min_update_multi   d2[r][i] = min(d2[r][i], ||x_i - c_r||^2), r < R (scd_kmeans_min_update is its R = 1 case, so the
+//                                 lock-step and the one-restart-at-a-time seedings see the same bits)
 //   scd_kpp_draw_multi            the draw of scd_kpp_draw for R vectors, blockIdx.y = restart
-template <int NV>
-__global__ void __launch_bounds__(256) minupd_multi_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
-                                                           int R, float* __restrict__ d2, long long ld) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float* x = X + row * d;
-    float4 xv[NV];
+// One thread per row, 256 rows per block; X goes through LDS in 32-column chunks (coalesced 128-byte row pieces in, one row per
+// thread out, row stride 36 dwords = conflict-free b128 on both sides), the RB centres of the pass as float64 in LDS (uniform
+// address: broadcast reads).  Thread-private float64 accumulators, columns in ascending order: no cross-lane reduction, and the
+// sum of a row does not depend on R, RB or the launch shape.  Float64 VALU-bound: (1 + 2 RB) ops per element.
+constexpr int MU_ROWS = 256, MU_COLS = 32, MU_LD = 36;
+template <int RB, bool VEC>
+__global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
+                                                          int r0, int R, float* __restrict__ d2, long long ld) {
+    __shared__ __attribute__((aligned(16))) float xs[MU_ROWS * MU_LD];
+    __shared__ __attribute__((aligned(16))) double cs[RB * MU_COLS];
+    const int t = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * MU_ROWS;
+    const int nch = (d + MU_COLS - 1) / MU_COLS;
+    constexpr int NC = (RB * MU_COLS + 255) / 256;
+    float4 pre[8];
+    float prs[VEC ? 1 : 32];
+    float prc[NC];
+    auto fetch = [&](int ch) {
+        const int c0 = ch * MU_COLS;
+        if (VEC) {
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-        const int j = lane * 4 + 256 * t;
-        xv[t] = j < d ? *(const float4*)(x + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int r = 0; r < R; ++r) {
-        const float* c = Cn + (size_t)r * d;
-        double s = 0.0;
+            for (int i = 0; i < 8; ++i) {
+                const long long r = row0 + (t >> 3) + 32 * i;
+                const int c = c0 + (t & 7) * 4;
+                pre[i] = (r < n && c < d) ? *(const float4*)(X + r * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
 #pragma unroll
-        for (int t = 0; t < NV; ++t) {
-            const int j = lane * 4 + 256 * t;
-            if (j < d) {
-                const float4 cv = *(const float4*)(c + j);
-                double a = (double)xv[t].x - (double)cv.x; s = fma(a, a, s);
-                a = (double)xv[t].y - (double)cv.y; s = fma(a, a, s);
-                a = (double)xv[t].z - (double)cv.z; s = fma(a, a, s);
-                a = (double)xv[t].w - (double)cv.w; s = fma(a, a, s);
+            for (int i = 0; i < 32; ++i) {
+                const long long r = row0 + (t >> 5) + 8 * i;
+                const int c = c0 + (t & 31);
+                prs[VEC ? 0 : i] = (r < n && c < d) ? X[r * d + c] : 0.f;
             }
         }
-        s = wave_sum_f64(s);
-        if (lane == 0) {
-            float* p = d2 + (size_t)r * ld + row;
-            *p = fminf(*p, (float)s);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int e = t + 256 * i, r = r0 + e / MU_COLS, c = c0 + e % MU_COLS;
+            prc[i] = (e < RB * MU_COLS && r < R && c < d) ? Cn[(size_t)r * d + c] : 0.f;
+        }
+    };
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    fetch(0);
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(float4*)(xs + ((t >> 3) + 32 * i) * MU_LD + (t & 7) * 4) = pre[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) xs[((t >> 5) + 8 * i) * MU_LD + (t & 31)] = prs[VEC ? 0 : i];
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            if (t + 256 * i < RB * MU_COLS) cs[t + 256 * i] = (double)prc[i];
+        __syncthreads();
+        if (ch + 1 < nch) fetch(ch + 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 xv = *(const float4*)(xs + t * MU_LD + q * 4);
+            const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const double2 c01 = *(const double2*)(cs + r * MU_COLS + q * 4);
+                const double2 c23 = *(const double2*)(cs + r * MU_COLS + q * 4 + 2);
+                double a = x0 - c01.x; acc[r] = fma(a, a, acc[r]);
+                a = x1 - c01.y; acc[r] = fma(a, a, acc[r]);
+                a = x2 - c23.x; acc[r] = fma(a, a, acc[r]);
+                a = x3 - c23.y; acc[r] = fma(a, a, acc[r]);
+            }
         }
     }
+    const long long row = row0 + t;
+    if (row < n) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r0 + r < R) {
+                float* p = d2 + (size_t)(r0 + r) * ld + row;
+                *p = fminf(*p, (float)acc[r]);
+            }
+    }
+}
+
+template <int RB>
+static void minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st) {
+    const unsigned g = (unsigned)scd_cdiv(n, MU_ROWS);
+    if ((d & 3) == 0) minupd_tile_kernel<RB, true><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
+    else minupd_tile_kernel<RB, false><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
 }
 
 extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R,
                                            float* d2_inout, int64_t ld, void* stream_) {
     SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0 && R > 0 && ld >= n, "scd_kmeans_min_update_multi: bad arguments");
-    SCD_REQUIRE(d % 4 == 0 && d <= 1024, "scd_kmeans_min_update_multi: d=%d must be a multiple of 4, <= 1024", d);
     hipStream_t st = (hipStream_t)stream_;
-    const unsigned g = (unsigned)scd_cdiv(n, 4);
-    if (d <= 256) minupd_multi_kernel<1><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
-    else if (d <= 512) minupd_multi_kernel<2><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
-    else if (d <= 768) minupd_multi_kernel<3><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
-    else minupd_multi_kernel<4><<<g, 256, 0, st>>>(X, c_new, n, d, R, d2_inout, ld);
+    int r0 = 0;
+    while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 10; }
+    while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 4; }
+    while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 1; }
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

@@ -64,6 +64,15 @@ class HipBackend:
     def kpp_draw(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
         return self.ops.kpp_draw(d2, r, total, prefix, want_idx, want_probsum)
 
+    def min_update_multi(self, data, c_new, d2):
+        self.ops.min_update_multi(data.x, c_new, d2)
+
+    def kpp_draw_multi(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+        return self.ops.kpp_draw_multi(d2, r, total, prefix, want_idx, want_probsum)
+
+    def sum_f32_multi(self, x):
+        return self.ops.sum_f32_multi(x)
+
     def transport(self, cost, size_min, size_max):
         return self.ops.transport_solve(cost, size_min, size_max)
 
@@ -196,6 +205,74 @@ class KMeansEngine:
             raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
         return C
 
+    def kpp_lockstep(self, data, pre_centers, k, rs, restarts):
+        """The k-means++ seedings of all `restarts` restarts of one fit, advanced together: restart j's t-th centre depends only
+        on restart j's earlier centres and on the (t)-th uniform of ITS slice of the random stream, and the reference's restarts
+        consume the stream back to back (kpp draws k-m uniforms, Lloyd draws none; sskm.py:28-44, :190-204), so drawing the
+        whole stream up front and adding centre t of every restart in one round gives the same centres as running kpp
+        `restarts` times.  Per round: one pass over X for all restarts' distance updates and one batched draw; under a process
+        group the same three all-gathers as kpp, each carrying `restarts` values.  Returns float32 [restarts, k, D]."""
+        be = self._be()
+        dd = self._dist()
+        x = data.x
+        n, d = x.shape
+        dev = x.device
+        if pre_centers is not None:
+            c0 = pre_centers.reshape(-1, d).to(torch.float32)
+            m = c0.shape[0]
+            if m >= k:
+                return c0.unsqueeze(0).expand(restarts, -1, -1).contiguous()
+            rv = rs.rand(restarts, k - m)                                   # C order: restart 0's draws first
+            buf = torch.empty((restarts, k, d), dtype=torch.float32, device=dev)
+            buf[:, :m] = c0
+            labels = be.estep(data, c0)
+            d2 = be.rowdist(data, c0, labels).reshape(1, -1).expand(restarts, -1).contiguous()
+        else:
+            n_glob = self._global_len(x, dd)
+            firsts, rv = [], np.empty((restarts, k - 1))
+            for j in range(restarts):                                       # fit_once: randint, then k-1 uniforms, per restart
+                firsts.append(rs.randint(0, n_glob))
+                rv[j] = rs.rand(k - 1)
+            m = 1
+            buf = torch.empty((restarts, k, d), dtype=torch.float32, device=dev)
+            rows = torch.stack([self._fetch_row(x, f, dd) for f in firsts]).to(torch.float32)
+            buf[:, 0] = rows
+            d2 = torch.full((restarts, n), float("inf"), dtype=torch.float32, device=dev)
+            be.min_update_multi(data, rows.contiguous(), d2)
+        picks = []
+        ar = torch.arange(restarts, device=dev)
+        for t in range(k - m):
+            r = rv[:, t]
+            if dd is None:
+                idx, _ = be.kpp_draw_multi(d2, r)
+                rows = x.index_select(0, idx.clamp(min=0))
+                picks.append(idx)
+            else:
+                tot = dd.allgather(be.sum_f32_multi(d2)).sum(0).contiguous()                   # [restarts], fixed rank order
+                _, ps = be.kpp_draw_multi(d2, r, total=tot, want_idx=False, want_probsum=True)
+                allps = dd.allgather(ps)
+                prefix = allps[: dd.rank].sum(0).contiguous() if dd.rank > 0 else torch.zeros_like(ps)
+                idx, _ = be.kpp_draw_multi(d2, r, total=tot, prefix=prefix)
+                cand = x.index_select(0, idx.clamp(min=0)).to(torch.float32)
+                pack = dd.allgather(torch.cat([(idx >= 0).to(torch.float32).reshape(-1, 1), cand], 1))   # [world, restarts, 1 + D]
+                hit = pack[:, :, 0] > 0
+                firsthit = (hit & (torch.cumsum(hit.to(torch.int32), 0) == 1)).to(torch.int64)
+                rows = pack[firsthit.argmax(0), ar, 1:]
+                picks.append(torch.where(hit.any(0), 0, -1))
+            rows = rows.to(torch.float32).contiguous()
+            buf[:, m + t] = rows
+            if t + 1 < k - m:
+                be.min_update_multi(data, rows, d2)
+        if picks and bool((torch.stack(picks) < 0).any()):
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+        return buf
+
+    def _lockstep(self):
+        import os
+        be = self._be()
+        return (self.init == "k-means++" and self.n_init > 1 and hasattr(be, "kpp_draw_multi")
+                and os.environ.get("SCD_KPP_LOCKSTEP", "1") != "0")
+
     @staticmethod
     def _global_len(x, dd):
         if dd is None:
@@ -255,7 +332,7 @@ class KMeansEngine:
         return best[0], best[1], best[2], it + 1
 
     # ------------------------------------------------------------------ reference API
-    def fit_once(self, X, random_state, data=None):
+    def fit_once(self, X, random_state, data=None, init_centers=None):
         be = self._be()
         if data is None:
             data = be.prepare(X)
@@ -263,7 +340,9 @@ class KMeansEngine:
         if self.init != "k-means++" and self.group is not None:
             # rows would be drawn from the LOCAL shard: every rank would start from different centres
             raise NotImplementedError("init=%r is not shard-aware; use init='k-means++' with a process group" % (self.init,))
-        if self.init == "k-means++":
+        if init_centers is not None:
+            centers = init_centers
+        elif self.init == "k-means++":
             centers = self.kpp(x, k=self.k, random_state=random_state, data=data)
         elif self.init == "random":
             rs = check_random_state(self.random_state)
@@ -274,7 +353,7 @@ class KMeansEngine:
         labels = torch.empty(len(x), dtype=torch.int64, device=x.device)
         return self._lloyd(data, x, labels, 0, centers)
 
-    def fit_mix_once(self, u_feats, l_feats, l_targets, random_state, data=None, cat=None):
+    def fit_mix_once(self, u_feats, l_feats, l_targets, random_state, data=None, cat=None, init_centers=None, l_rank=None):
         be = self._be()
         if data is None:
             data = be.prepare(u_feats)
@@ -283,20 +362,24 @@ class KMeansEngine:
         l_targets = l_targets.to(u.device)
         if cat is None:
             cat = torch.cat((l, u)).contiguous()
-        classes, l_rank, l_centers = self._class_means(l, l_targets)
+        if init_centers is None:
+            classes, l_rank, l_centers = self._class_means(l, l_targets)
         l_num = len(l_targets)
         labels = torch.empty(len(cat), dtype=torch.int64, device=u.device)
         labels[:l_num] = l_rank
-        centers = self.kpp(u, l_centers, k=self.k, random_state=random_state, data=data)
+        centers = init_centers if init_centers is not None else self.kpp(u, l_centers, k=self.k, random_state=random_state, data=data)
         lab, inertia, cent, _ = self._lloyd(data, cat, labels, l_num, centers)
         # reference quirk: returns `i + 1` with i the stale labelled-row index (sskm_constrained.py:104,139)
         return lab, inertia, cent, l_num
 
-    def _run(self, once, *args, **kw):
+    def _run(self, once, *args, inits=None, **kw):
+        """n_init restarts, best inertia kept (sskm.py:190-204).  `inits(rs)` -> per-restart keyword dicts when the seedings were
+        drawn in lock-step (kpp_lockstep); otherwise every restart runs its own kpp on the shared stream."""
         rs = check_random_state(self.random_state)
         best_inertia = None
-        for _ in range(self.n_init):
-            labels, inertia, centers, n_iters = once(*args, rs, **kw)
+        per = inits(rs) if inits is not None else [{} for _ in range(self.n_init)]
+        for extra in per:
+            labels, inertia, centers, n_iters = once(*args, rs, **kw, **extra)
             if best_inertia is None or inertia < best_inertia:
                 self.labels_ = labels.clone()
                 self.cluster_centers_ = centers.clone()
@@ -306,13 +389,24 @@ class KMeansEngine:
 
     def fit(self, X):
         data = self._be().prepare(X)
-        self._run(self.fit_once, X, data=data)
+        inits = None
+        if self._lockstep():
+            def inits(rs):
+                c = self.kpp_lockstep(data, None, self.k, rs, self.n_init)
+                return [dict(init_centers=c[j]) for j in range(self.n_init)]
+        self._run(self.fit_once, X, data=data, inits=inits)
 
     def fit_mix(self, u_feats, l_feats, l_targets):
         data = self._be().prepare(u_feats)
         l = l_feats.to(device=data.x.device, dtype=torch.float32).contiguous()
         cat = torch.cat((l, data.x)).contiguous()
-        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat)
+        inits = None
+        if self._lockstep():
+            def inits(rs):
+                _, l_rank, l_centers = self._class_means(l, l_targets.to(data.x.device))
+                c = self.kpp_lockstep(data, l_centers, self.k, rs, self.n_init)
+                return [dict(init_centers=c[j], l_rank=l_rank) for j in range(self.n_init)]
+        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat, inits=inits)
         self.cluster_centers_ = self.cluster_centers_.type_as(u_feats) if torch.is_floating_point(u_feats) else self.cluster_centers_
 
 

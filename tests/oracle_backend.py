@@ -72,6 +72,21 @@ class OracleBackend:
             idx = torch.tensor([int(hit[0]) if hit.size else -1], dtype=torch.int64)
         return idx, ps
 
+    # lock-step variants (one row per restart): loops over the single-vector versions above
+    def min_update_multi(self, data, c_new, d2):
+        for j in range(c_new.shape[0]):
+            self.min_update(data, c_new[j], d2[j])
+
+    def sum_f32_multi(self, x):
+        return torch.cat([self.sum_f32(x[j]) for j in range(x.shape[0])])
+
+    def kpp_draw_multi(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
+        outs = [self.kpp_draw(d2[j], r[j], None if total is None else total[j], None if prefix is None else prefix[j],
+                              want_idx, want_probsum) for j in range(d2.shape[0])]
+        idx = torch.cat([o[0] for o in outs]) if want_idx else None
+        ps = torch.cat([o[1] for o in outs]) if want_probsum else None
+        return idx, ps
+
     def transport(self, cost, size_min, size_max):
         from scd_amd import ops
         return ops.transport_solve(cost, size_min, size_max)      # host C++ solver (no device needed)

@@ -331,3 +331,30 @@ def test_bpe_tokenizer_against_independent_implementation(tmp_path, monkeypatch)
     assert int(tok[0, 2 + len(ids):].abs().sum()) == 0
     with pytest.raises(RuntimeError, match="too long"):
         clip.tokenize(["fox " * 100])
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_kpp_lockstep_equals_sequential_restarts(monkeypatch, mixed):
+    """KMeansEngine draws the seedings of all n_init restarts in lock-step (kpp_lockstep) from one pre-drawn random stream; the
+    reference runs kpp once per restart on the shared RandomState (sskm.py:190-204).  Same centres, labels, inertia, and the same
+    position in the random stream afterwards."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleBackend
+    from oracle import synth
+    from scd_amd.kmeans import KMeansEngine
+    x, y, mask_lab = synth.blob_case(500, 8, 7, 5)
+    xt = torch.from_numpy(x)
+    out = []
+    for lock in ("1", "0"):
+        monkeypatch.setenv("SCD_KPP_LOCKSTEP", lock)
+        rs = np.random.RandomState(11)
+        km = KMeansEngine(k=7, max_iterations=5, n_init=4, random_state=rs, backend=OracleBackend())
+        if mixed:
+            km.fit_mix(xt[~mask_lab], xt[mask_lab], torch.from_numpy(y[mask_lab]))
+        else:
+            km.fit(xt)
+        out.append((km.labels_.numpy(), km.cluster_centers_.numpy(), float(km.inertia_), rs.rand()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] and out[0][3] == out[1][3]

@@ -283,6 +283,59 @@ def test_min_update_exact(ops):
     assert np.array_equal(d2.cpu().numpy(), ref) and d2[17].item() == 0.0
 
 
+def test_kpp_multi_kernels_equal_single(ops):
+    """The lock-step forms (R restarts per launch) give, row by row, the bits of the single-vector kernels."""
+    rs = np.random.RandomState(8)
+    for n, d, R in ((3001, 768, 3), (95001, 512, 10), (513, 64, 2), (777, 1024, 5)):
+        x, _, _ = synth.clustered_features(n, d, 10, seed=n)
+        xt = dev(x)
+        data = ops.KMeansData(xt)
+        pick = rs.randint(0, n, size=R)
+        c_new = xt[torch.as_tensor(pick, device="cuda")].contiguous()
+        d2 = dev((rs.rand(R, n) * 3).astype(np.float32))
+        want = d2.clone()
+        for j in range(R):
+            data.min_update(c_new[j], want[j])
+        ops.min_update_multi(data.x, c_new, d2)
+        assert torch.equal(d2, want)
+        assert all(d2[j, pick[j]].item() == 0.0 for j in range(R))
+        rv = rs.rand(R)
+        rv[0] = 0.0
+        idx, _ = ops.kpp_draw_multi(d2, rv)
+        for j in range(R):
+            assert int(idx[j]) == int(ops.kpp_draw(d2[j], rv[j])[0]) == ko.kpp_draw(d2[j].cpu().numpy(), np.float32(rv[j]))
+        sums = ops.sum_f32_multi(d2)
+        assert all(float(sums[j]) == float(ops.sum_f32(d2[j])) for j in range(R))
+        # shard-aware form
+        h = n // 3
+        a, b = d2[:, :h].contiguous(), d2[:, h:].contiguous()
+        _, pa = ops.kpp_draw_multi(a, rv, total=sums, want_idx=False, want_probsum=True)
+        ia, _ = ops.kpp_draw_multi(a, rv, total=sums)
+        ib, _ = ops.kpp_draw_multi(b, rv, total=sums, prefix=pa)
+        for j in range(R):
+            got = int(ia[j]) if int(ia[j]) >= 0 else h + int(ib[j])
+            assert got == int(idx[j])
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_kpp_lockstep_equals_sequential_restarts_gpu(ops, monkeypatch, mixed):
+    """KMeansEngine on the device: seedings of the n_init restarts drawn in lock-step == one kpp per restart (sskm.py:190-204)."""
+    from scd_amd.kmeans import KMeansEngine
+    x, y, mask_lab = synth.blob_case(6000, 64, 12, 5)
+    xt = dev(x)
+    m = torch.as_tensor(mask_lab, device="cuda")
+    out = []
+    for lock in ("1", "0"):
+        monkeypatch.setenv("SCD_KPP_LOCKSTEP", lock)
+        km = KMeansEngine(k=12, max_iterations=5, n_init=5, random_state=11)
+        if mixed:
+            km.fit_mix(xt[~m], xt[m], dev(y[mask_lab]))
+        else:
+            km.fit(xt)
+        out.append((km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
 # ----------------------------------------------------------------------------------------------- k-means end to end
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_sskm_matches_reference_golden(ops, golden, tag):

@@ -51,6 +51,15 @@ if __name__ == "__main__":
     print("minupd %8.1f us  algorithmic %.1f MB -> %.0f GB/s" % (us, algo / 1e6, algo / us / 1e3))
     us = timeit(lambda: ops.kpp_draw(d2, 0.37))
     print("draw   %8.1f us" % us)
+    R = 10
+    d2m = d2.reshape(1, -1).expand(R, -1).contiguous()
+    cm = X[17:17 + R].contiguous()
+    us = timeit(lambda: ops.min_update_multi(X, cm, d2m))
+    print("minupd for %d restarts in lock-step %8.1f us  (%.1f us per restart), X read once: %.1f MB -> %.0f GB/s"
+          % (R, us, us / R, n * d * 4 / 1e6, n * d * 4 / us / 1e3))
+    rv = np.linspace(0.05, 0.95, R)
+    us = timeit(lambda: ops.kpp_draw_multi(d2m, rv))
+    print("draw for %d restarts in lock-step   %8.1f us  (%.1f us per restart)" % (R, us, us / R))
     sums, counts, _ = ops.kmeans_mstep(X, lab, C, k, 0)
     us = timeit(lambda: ops.kmeans_finalize(sums, counts, C))
     print("final  %8.1f us" % us)
