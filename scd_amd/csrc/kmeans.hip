@@ -1432,17 +1432,22 @@ extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, co
 //   scd_kmeans_min_update_multi   d2[r][i] = min(d2[r][i], ||x_i - c_r||^2), r < R (scd_kmeans_min_update is its R = 1 case, so the
 //                                 lock-step and the one-restart-at-a-time seedings see the same bits)
 //   scd_kpp_draw_multi            the draw of scd_kpp_draw for R vectors, blockIdx.y = restart
-// One thread per row, 256 rows per block; X goes through LDS in 32-column chunks (coalesced 128-byte row pieces in, one row per
-// thread out, row stride 36 dwords = conflict-free b128 on both sides), the RB centres of the pass as float64 in LDS (uniform
-// address: broadcast reads).  Thread-private float64 accumulators, columns in ascending order: no cross-lane reduction, and the
-// sum of a row does not depend on R, RB or the launch shape.  Float64 VALU-bound: (1 + 2 RB) ops per element.
-constexpr int MU_ROWS = 256, MU_COLS = 32, MU_LD = 36;
+// 256 rows per block; X goes through LDS in 32-column chunks (coalesced 128-byte row pieces in, row stride 36 dwords =
+// conflict-free b128 on both sides), the RB centres of the pass as float64 in LDS (uniform address: broadcast reads).
+// Thread-private float64 accumulators: no cross-lane reduction, and the sum of a row does not depend on R or RB.
+// Work split inside a 256-row block: a thread owns TWO rows (p and p + 128: a centre value read from LDS serves both - at
+// RB = 10 the broadcast centre reads, 8 cycles of LDS issue per ds_read_b128 whatever the address pattern, outweigh the float64
+// VALU work with one row per thread) and HALF of every chunk's columns (waves 0-1: columns 0-15, waves 2-3: 16-31: N / 64 waves
+// as with one row per thread, so the SIMDs stay evenly loaded).  A row's sum is (its low-half columns in ascending order) +
+// (its high-half columns in ascending order), whatever R and RB.
+constexpr int MU_COLS = 32, MU_LD = 36, MU_ROWS = 256;
 template <int RB, bool VEC>
 __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
                                                           int r0, int R, float* __restrict__ d2, long long ld) {
-    __shared__ __attribute__((aligned(16))) float xs[MU_ROWS * MU_LD];
+    __shared__ __attribute__((aligned(16))) float xs[MU_ROWS * MU_LD];       // reused for the high-half partials at the end
     __shared__ __attribute__((aligned(16))) double cs[RB * MU_COLS];
-    const int t = threadIdx.x;
+    static_assert(128 * 2 * RB * 8 <= MU_ROWS * MU_LD * 4, "partials must fit the x tile");
+    const int t = threadIdx.x, p = t & 127, half = t >> 7;
     const long long row0 = (long long)blockIdx.x * MU_ROWS;
     const int nch = (d + MU_COLS - 1) / MU_COLS;
     constexpr int NC = (RB * MU_COLS + 255) / 256;
@@ -1472,9 +1477,11 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
             prc[i] = (e < RB * MU_COLS && r < R && c < d) ? Cn[(size_t)r * d + c] : 0.f;
         }
     };
-    double acc[RB];
+    double acc[2][RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[j][r] = 0.0;
     fetch(0);
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();
@@ -1491,36 +1498,59 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
         __syncthreads();
         if (ch + 1 < nch) fetch(ch + 1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 xv = *(const float4*)(xs + t * MU_LD + q * 4);
-            const double x0 = (double)xv.x, x1 = (double)xv.y, x2 = (double)xv.z, x3 = (double)xv.w;
+        for (int q = 0; q < 4; ++q) {
+            const int col = 16 * half + 4 * q;
+            double x[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 xv = *(const float4*)(xs + (p + 128 * j) * MU_LD + col);
+                x[j][0] = (double)xv.x; x[j][1] = (double)xv.y; x[j][2] = (double)xv.z; x[j][3] = (double)xv.w;
+            }
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                const double2 c01 = *(const double2*)(cs + r * MU_COLS + q * 4);
-                const double2 c23 = *(const double2*)(cs + r * MU_COLS + q * 4 + 2);
-                double a = x0 - c01.x; acc[r] = fma(a, a, acc[r]);
-                a = x1 - c01.y; acc[r] = fma(a, a, acc[r]);
-                a = x2 - c23.x; acc[r] = fma(a, a, acc[r]);
-                a = x3 - c23.y; acc[r] = fma(a, a, acc[r]);
+                const double2 c01 = *(const double2*)(cs + r * MU_COLS + col);
+                const double2 c23 = *(const double2*)(cs + r * MU_COLS + col + 2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double a = x[j][0] - c01.x; acc[j][r] = fma(a, a, acc[j][r]);
+                    a = x[j][1] - c01.y; acc[j][r] = fma(a, a, acc[j][r]);
+                    a = x[j][2] - c23.x; acc[j][r] = fma(a, a, acc[j][r]);
+                    a = x[j][3] - c23.y; acc[j][r] = fma(a, a, acc[j][r]);
+                }
             }
         }
     }
-    const long long row = row0 + t;
-    if (row < n) {
+    __syncthreads();
+    double* part = (double*)xs;                       // [128][2][RB]
+    if (half) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (r0 + r < R) {
-                float* p = d2 + (size_t)(r0 + r) * ld + row;
-                *p = fminf(*p, (float)acc[r]);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) part[(p * 2 + j) * RB + r] = acc[j][r];
+    }
+    __syncthreads();
+    if (!half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long row = row0 + p + 128 * j;
+            if (row < n) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    if (r0 + r < R) {
+                        float* q = d2 + (size_t)(r0 + r) * ld + row;
+                        *q = fminf(*q, (float)(acc[j][r] + part[(p * 2 + j) * RB + r]));
+                    }
             }
+        }
     }
 }
 
 template <int RB>
-static void minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st) {
+static int minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st) {
     const unsigned g = (unsigned)scd_cdiv(n, MU_ROWS);
     if ((d & 3) == 0) minupd_tile_kernel<RB, true><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
     else minupd_tile_kernel<RB, false><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
+    return SCD_OK;
 }
 
 extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R,

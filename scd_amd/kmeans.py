@@ -241,8 +241,10 @@ class KMeansEngine:
             be.min_update_multi(data, rows.contiguous(), d2)
         picks = []
         ar = torch.arange(restarts, device=dev)
+        # float32(uniform) is what the draw compares with (the reference's `cumsum(prob) >= r` promotes r to prob's float32)
+        rv = torch.from_numpy(np.ascontiguousarray(rv.T.astype(np.float32))).to(dev)       # [k - m, restarts], one upload
         for t in range(k - m):
-            r = rv[:, t]
+            r = rv[t]
             if dd is None:
                 idx, _ = be.kpp_draw_multi(d2, r)
                 rows = x.index_select(0, idx.clamp(min=0))

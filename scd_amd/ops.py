@@ -272,7 +272,11 @@ def kpp_draw_multi(d2, r, total=None, prefix=None, want_idx=True, want_probsum=F
     probsum float64 [R] or None)."""
     _need_cuda(d2)
     rr, n = d2.shape
-    rdev = torch.as_tensor(np.asarray(r, dtype=np.float32)).to(d2.device)
+    if torch.is_tensor(r):                                 # already on the device (kpp_lockstep uploads the whole stream once)
+        rdev = r.to(device=d2.device, dtype=torch.float32).contiguous()
+    else:
+        rdev = torch.as_tensor(np.asarray(r, dtype=np.float32)).to(d2.device)
+    assert rdev.numel() == rr
     idx = torch.empty(rr, dtype=torch.int64, device=d2.device) if want_idx else None
     ps = torch.empty(rr, dtype=torch.float64, device=d2.device) if want_probsum else None
     nb = rr * _L().scd_kpp_draw_ws_bytes(n)

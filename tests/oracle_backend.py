@@ -81,7 +81,7 @@ class OracleBackend:
         return torch.cat([self.sum_f32(x[j]) for j in range(x.shape[0])])
 
     def kpp_draw_multi(self, d2, r, total=None, prefix=None, want_idx=True, want_probsum=False):
-        outs = [self.kpp_draw(d2[j], r[j], None if total is None else total[j], None if prefix is None else prefix[j],
+        outs = [self.kpp_draw(d2[j], float(r[j]), None if total is None else total[j], None if prefix is None else prefix[j],
                               want_idx, want_probsum) for j in range(d2.shape[0])]
         idx = torch.cat([o[0] for o in outs]) if want_idx else None
         ps = torch.cat([o[1] for o in outs]) if want_probsum else None
