@@ -166,10 +166,11 @@ def secondary_rooflines(out, wt, dev):
     n, d = feats.shape
     v = wt.shape[0]
     t = timeit(lambda: ops.sim_topk(feats, wt, 3, "softmax"), 5)
+    fb_rows = int(ops.sim_topk(feats, wt, 3, "softmax", return_fallback=True)[2].item())
     fl = 2.0 * n * v * d
     res.append({"kernel": "scd_sim_topk call (sim_topk_rb_kernel + sim_refine_kernel), %d x %d x %d" % (n, v, d), "bound": "mfma",
                 "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4),
-                "call_us": round(t * 1e6, 1)})
+                "call_us": round(t * 1e6, 1), "rows_through_exact_pass": fb_rows})
     x = feats.float()
     c = out["kmeans"].cluster_centers_.to(torch.float32).contiguous()
     k = int(c.shape[0])
@@ -191,7 +192,22 @@ def secondary_rooflines(out, wt, dev):
     cen = torch.nn.functional.normalize(torch.randn(k, d, device=dev, generator=g), dim=-1)
     yy = torch.randint(0, k, (n,), device=dev, generator=g)
     xc = torch.nn.functional.normalize(cen[yy] + (0.8 / d ** 0.5) * torch.randn(n, d, device=dev, generator=g), dim=-1)
-    res.append(estep_line("clustered synthetic features / converged centres", ops.KMeansData(xc), cen.contiguous(), True))
+    dc = ops.KMeansData(xc)
+    res.append(estep_line("clustered synthetic features / converged centres", dc, cen.contiguous(), True))
+    # (iii) the call as the Lloyd loop pays it from the third iteration on: scd_kmeans_finalize has already written the centre
+    # operands into the E-step workspace and the few flagged rows are re-evaluated in the stream kernel's tail.  Timed as
+    # (finalize + estep) - (finalize alone), same data as (ii).
+    lab = dc.estep(cen.contiguous())
+    sums, counts, _ = ops.kmeans_mstep(xc, lab, cen.contiguous(), k, 0)
+
+    def pair():
+        cnew, _ = ops.kmeans_finalize(sums, counts, cen, data=dc)
+        dc.estep(cnew, expect_few=True)
+    t = timeit(pair) - timeit(lambda: ops.kmeans_finalize(sums, counts, cen, data=dc))
+    res.append({"kernel": "scd_kmeans_estep call inside the Lloyd loop (operands handed over by scd_kmeans_finalize, refine in the "
+                          "kernel's tail), N=%d D=%d K=%d, clustered synthetic features" % (n, d, k), "bound": "hbm",
+                "achieved": round(by / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / t / 8e12, 4),
+                "call_us": round(t * 1e6, 1)})
     return res
 
 

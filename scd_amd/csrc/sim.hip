@@ -1011,14 +1011,14 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
 template <bool SOFTMAX>
 __global__ void __launch_bounds__(256) sim_exact_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, int d,
                                                         long long v, float scale, int k, const SimHdr* hdr,
-                                                        const int* fb_list, long long* idx_out, float* val_out) {
+                                                        const int* fb_list, long long* idx_out, float* val_out, int fb0) {
     __shared__ float fs[1024];
     __shared__ double cval[256 * TOPM];
     __shared__ int cidx[256 * TOPM];
     __shared__ double red_m[256];
     __shared__ double red_z[256];
     const int cnt = hdr->fb_cnt;
-    for (int fb = blockIdx.x; fb < cnt; fb += gridDim.x) {
+    for (int fb = fb0 + blockIdx.x; fb < cnt; fb += gridDim.x) {
         const long long img = fb_list[fb];
         __syncthreads();
         for (int j = threadIdx.x; j < d; j += 256) fs[j] = (float)F[img * d + j];
@@ -1083,9 +1083,164 @@ __global__ void __launch_bounds__(256) sim_exact_kernel(const half_t* __restrict
     }
 }
 
+// The first EX_ROWS fallback rows, spread over the whole chip (a handful of rows is the normal case, and one block per row - the
+// kernel above - keeps a single CU busy for 1.8 ms per row at V = 21,000): block b takes names [b V/256, (b+1) V/256) of EVERY such
+// row, one wave per name with the refine pass's dot64 (same lane split, same bits), a wave-uniform top-TOPM list per wave, merged per
+// block into part[row][block]; sim_exact_merge_kernel (one block per row) then selects the row's top k from the 256 x TOPM
+// candidates (ties to the lower name index) and, for softmax, combines the (max, sum) pairs.  Rows past EX_ROWS keep the
+// one-block-per-row kernel (then at least EX_ROWS CUs are busy).
+constexpr int EX_ROWS = 32, EX_BLOCKS = 256;
+struct ExPart {
+    double val[TOPM];
+    double m, z;
+    int idx[TOPM];
+};
+__device__ __forceinline__ void ex_insert(double (&lv)[TOPM], int (&li)[TOPM], double s, int vi) {
+    // candidates arrive in ascending name order or are merged with an explicit index test: (s, -vi) lexicographic
+    if (s > lv[TOPM - 1] || (s == lv[TOPM - 1] && li[TOPM - 1] >= 0 && vi < li[TOPM - 1])) {
+#pragma unroll
+        for (int j = TOPM - 1; j >= 1; --j) {
+            const bool up = s > lv[j - 1] || (s == lv[j - 1] && li[j - 1] >= 0 && vi < li[j - 1]);
+            const bool here = s > lv[j] || (s == lv[j] && li[j] >= 0 && vi < li[j]);
+            lv[j] = up ? lv[j - 1] : (here ? s : lv[j]);
+            li[j] = up ? li[j - 1] : (here ? vi : li[j]);
+        }
+        if (s > lv[0] || (s == lv[0] && li[0] >= 0 && vi < li[0])) { lv[0] = s; li[0] = vi; }
+    }
+}
+template <bool SOFTMAX>
+__global__ void __launch_bounds__(256) sim_exact_spread_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, int d,
+                                                               long long v, float scale, const SimHdr* hdr,
+                                                               const int* __restrict__ fb_list, ExPart* __restrict__ part) {
+    __shared__ double wv[4][TOPM];
+    __shared__ int wi[4][TOPM];
+    __shared__ double wm[4], wz[4];
+    const int cnt = hdr->fb_cnt < EX_ROWS ? hdr->fb_cnt : EX_ROWS;
+    if (cnt <= 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long chunk = (v + gridDim.x - 1) / gridDim.x;
+    const long long v0 = (long long)blockIdx.x * chunk, v1 = v0 + chunk < v ? v0 + chunk : v;
+    for (int fb = 0; fb < cnt; ++fb) {
+        const half_t* f = F + (long long)fb_list[fb] * d;
+        double lv[TOPM];
+        int li[TOPM];
+#pragma unroll
+        for (int j = 0; j < TOPM; ++j) { lv[j] = -INFINITY; li[j] = -1; }
+        double m = -INFINITY, z = 0.0;
+        for (long long vi = v0 + wave; vi < v1; vi += 4) {
+            const double s = dot64(f, Wt + vi * d, d, lane) * (double)scale;
+            if (SOFTMAX) {
+                const double mn = s > m ? s : m;
+                z = z * exp(m - mn) + exp(s - mn);
+                m = mn;
+            }
+            if (s > lv[TOPM - 1]) ex_insert(lv, li, s, (int)vi);      // NaN never enters
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < TOPM; ++j) { wv[wave][j] = lv[j]; wi[wave][j] = li[j]; }
+            wm[wave] = m;
+            wz[wave] = z;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double bv[TOPM];
+            int bi[TOPM];
+#pragma unroll
+            for (int j = 0; j < TOPM; ++j) { bv[j] = -INFINITY; bi[j] = -1; }
+            for (int w = 0; w < 4; ++w)
+                for (int j = 0; j < TOPM; ++j)
+                    if (wi[w][j] >= 0) ex_insert(bv, bi, wv[w][j], wi[w][j]);
+            double mm = -INFINITY, zz = 0.0;
+            if (SOFTMAX) {
+                for (int w = 0; w < 4; ++w) mm = wm[w] > mm ? wm[w] : mm;
+                for (int w = 0; w < 4; ++w)
+                    if (wz[w] > 0.0) zz += wz[w] * exp(wm[w] - mm);
+            }
+            ExPart* o = part + (size_t)fb * EX_BLOCKS + blockIdx.x;
+#pragma unroll
+            for (int j = 0; j < TOPM; ++j) { o->val[j] = bv[j]; o->idx[j] = bi[j]; }
+            o->m = mm;
+            o->z = zz;
+        }
+    }
+}
+template <bool SOFTMAX>
+__global__ void __launch_bounds__(256) sim_exact_merge_kernel(const SimHdr* hdr, const int* __restrict__ fb_list, const ExPart* __restrict__ part,
+                                                              int k, long long* idx_out, float* val_out) {
+    __shared__ double rv[4];
+    __shared__ int ri[4], rt[4];
+    __shared__ double sm[256], sz[256];
+    const int cnt = hdr->fb_cnt < EX_ROWS ? hdr->fb_cnt : EX_ROWS;
+    const int fb = blockIdx.x;
+    if (fb >= cnt) return;
+    const long long img = fb_list[fb];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const ExPart* pp = part + (size_t)fb * EX_BLOCKS + t;      // EX_BLOCKS == blockDim.x
+    double cv[TOPM];
+    int ci[TOPM];
+#pragma unroll
+    for (int j = 0; j < TOPM; ++j) { cv[j] = pp->val[j]; ci[j] = pp->idx[j]; }
+    double mm = 0.0, zz = 1.0;
+    if (SOFTMAX) {
+        sm[t] = pp->m;
+        sz[t] = pp->z;
+        __syncthreads();
+        if (t == 0) {                                   // fixed order: blocks ascending
+            double a = -INFINITY, b = 0.0;
+            for (int q = 0; q < 256; ++q) a = sm[q] > a ? sm[q] : a;
+            for (int q = 0; q < 256; ++q)
+                if (sz[q] > 0.0) b += sz[q] * exp(sm[q] - a);
+            sm[0] = a;
+            sz[0] = b;
+        }
+        __syncthreads();
+        mm = sm[0];
+        zz = sz[0];
+    }
+    int head = 0;                                        // the thread's list is sorted: its best remaining candidate is cv[head]
+    for (int out = 0; out < k; ++out) {
+        double bv = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int j = 0; j < TOPM; ++j)
+            if (j == head) { bv = cv[j]; bi = ci[j]; }
+        if (head >= TOPM) bi = -1;
+        int bt = t;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64), ot = __shfl_xor(bt, o, 64);
+            const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi));
+            if (take) { bv = ov; bi = oi; bt = ot; }
+        }
+        __syncthreads();
+        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; rt[wave] = bt; }
+        __syncthreads();
+        bv = rv[0]; bi = ri[0]; bt = rt[0];
+        for (int w = 1; w < 4; ++w)
+            if (ri[w] >= 0 && (bi < 0 || rv[w] > bv || (rv[w] == bv && ri[w] < bi))) { bv = rv[w]; bi = ri[w]; bt = rt[w]; }
+        if (bi < 0) break;                               // uniform: fewer than k ordered candidates (NaN rows)
+        if (t == 0) {
+            idx_out[img * k + out] = bi;
+            val_out[img * k + out] = SOFTMAX ? (float)(exp(bv - mm) / zz) : (float)bv;
+        }
+        if (t == bt) ++head;
+    }
+}
+template <bool SOFTMAX>
+static void sim_exact_launch(const half_t* f, const half_t* wt, int d, long long v, float scale, int k, const SimHdr* hdr, const int* fb,
+                             ExPart* part, long long* idx_out, float* val_out, hipStream_t st) {
+    sim_exact_spread_kernel<SOFTMAX><<<EX_BLOCKS, 256, 0, st>>>(f, wt, d, v, scale, hdr, fb, part);
+    sim_exact_merge_kernel<SOFTMAX><<<EX_ROWS, 256, 0, st>>>(hdr, fb, part, k, idx_out, val_out);
+    sim_exact_kernel<SOFTMAX><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, idx_out, val_out, EX_ROWS);
+}
+
 extern "C" size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k) {
     (void)d; (void)v; (void)k;
-    return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256;
+    return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256 +
+           scd_align(sizeof(ExPart) * EX_ROWS * EX_BLOCKS);
 }
 
 extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
@@ -1110,6 +1265,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     int* cidx = (int*)(w + 64 + csz);
     float* stats = (float*)(w + 64 + 2 * csz);
     int* fb = (int*)(w + 64 + 2 * csz + scd_align((size_t)n * 16));
+    ExPart* expart = (ExPart*)(w + 64 + 2 * csz + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256);
     const half_t* f = (const half_t*)F;
     const half_t* wt = (const half_t*)Wt;
     SCD_HIP(hipMemsetAsync(hdr, 0, 64, st));
@@ -1128,7 +1284,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
         sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                   \
         sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out); \
-        sim_exact_kernel<SM><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);                \
+        sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);                \
     }
         static const int sim_x_rb = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
         if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernel (tools/sim_bench.py)
@@ -1156,21 +1312,21 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     if (use_w4 && mode == SCD_SIM_SOFTMAX) {
         sim_topk_w4_kernel<true><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_launch<true>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
     } else if (use_w4) {
         sim_topk_w4_kernel<false><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_launch<false>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
     } else if (mode == SCD_SIM_SOFTMAX) {
         if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_kernel<true><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_launch<true>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
     } else {
         if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
         sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_kernel<false><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, (long long*)idx_out, val_out);
+        sim_exact_launch<false>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
     }
     if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));
     SCD_LAUNCH_CHECK();

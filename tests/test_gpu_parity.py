@@ -514,6 +514,31 @@ def test_sim_topk_shapes(ops, n, v, d, k):
     assert np.array_equal(a.cpu().numpy(), oi[:, 0])
 
 
+@pytest.mark.parametrize("n", [3, 100])
+@pytest.mark.parametrize("mode", ["raw", "softmax"])
+def test_sim_topk_fallback_rows_exact(ops, n, mode):
+    """Rows whose top-k cannot be certified from the candidate lists (here: 40 names that differ by single fp16 ulps, two of them
+    identical) go through the exact float64 pass: the first 32 spread over the whole chip (sim_exact_spread / merge), the rest one
+    block per row.  Same indices as the float64 oracle, ties to the lower index."""
+    rs = np.random.RandomState(17 + n)
+    d, v, k = 512, 3000, 5
+    base = (rs.randn(d) / np.sqrt(d)).astype(np.float16)
+    w = (rs.randn(d, v) / np.sqrt(d)).astype(np.float16)
+    for j in range(40):
+        col = base.copy()
+        pos = rs.randint(0, d, size=3)
+        col[pos] = np.nextafter(col[pos], np.float16(10), dtype=np.float16)
+        w[:, 100 + 7 * j] = col
+    w[:, 100 + 7 * 13] = w[:, 100 + 7 * 2]                       # an exact tie inside the cluster
+    f = (base[None, :].astype(np.float32) * 2 + rs.randn(n, d) * 0.01).astype(np.float16)
+    wt = ops.transpose_f16(dev(w))
+    idx, val, fb = ops.sim_topk(dev(f), wt, k, mode, return_fallback=True)
+    oi, ov = no.sim_topk(f, w, k, mode)
+    assert int(fb.item()) >= min(n, 3)                            # the construction does defeat the certificate
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.allclose(val.cpu().numpy(), ov, rtol=2e-4, atol=1e-6)
+
+
 def test_l2norm_and_gather(ops):
     rs = np.random.RandomState(1)
     x = rs.randn(77, 512).astype(np.float32) * 3
