@@ -202,6 +202,11 @@ int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const void* pixels,
 /* tokens int32 [B,77] -> out fp16 [B,out] */
 int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out,
                          int normalize, void* ws, size_t ws_bytes, void* stream);
+/* The same with only the first ctx_len positions of every prompt computed (tokens stays [B,77]).  Precondition: ctx_len >
+ * the EOT position (argmax over the 77 ids) of every row - then the outputs are bit-identical to scd_clip_encode_text (the tower is
+ * causal and only the EOT position is read, reference clip model.py encode_text), at ctx_len/77 of the work. */
+int scd_clip_encode_text_len(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, int ctx_len, void* out,
+                             int normalize, void* ws, size_t ws_bytes, void* stream);
 /* building block exposed for tests: C[m,n] = A[m,k] @ W[n,k]^T (+bias)(act)(+residual), fp16 in/out, fp32 accumulate */
 int scd_gemm_f16(scd_handle h, const void* A, const void* W, const float* bias, const void* residual, void* C,
                  int64_t m, int n, int k, int act, void* stream);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "scd_encoder_timing": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(C.c_double)]),
     "scd_vit_encode_image": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "scd_clip_encode_text": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "scd_clip_encode_text_len": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "scd_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
 }
 

@@ -200,7 +200,7 @@ def tokenize(texts, context_length=77, truncate=False):
     if isinstance(texts, str):
         texts = [texts]
     tk = _get_tokenizer()
-    out = torch.zeros(len(texts), context_length, dtype=torch.int32)
+    out = np.zeros((len(texts), context_length), dtype=np.int32)      # filled on the host row by row: a torch op per prompt cost more than the BPE
     for i, t in enumerate(texts):
         ids = [tk.sot] + tk.encode(t) + [tk.eot]
         if len(ids) > context_length:
@@ -208,5 +208,5 @@ def tokenize(texts, context_length=77, truncate=False):
                 raise RuntimeError("Input %s is too long for context length %d" % (t, context_length))
             ids = ids[:context_length]
             ids[-1] = tk.eot
-        out[i, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
-    return out
+        out[i, :len(ids)] = ids
+    return torch.from_numpy(out)

@@ -129,9 +129,15 @@ class CLIP:
         self._ready()
         return self.visual.enc.encode_image(image.to(self._dev))
 
-    def encode_text(self, text):
+    def encode_text(self, text, ctx_len=None):
+        """The package's encode_text.  Token ids handed over on the HOST (as clip.tokenize returns them) are trimmed for free: the
+        tower is causal and only the EOT position is read, so positions behind the batch's last EOT are not computed
+        (ops.Encoder.encode_text ctx_len: bit-identical features).  Ids already on the device are encoded at full length unless
+        the caller passes ctx_len (finding it would cost a device round trip)."""
         self._ready()
-        return self._text.encode_text(text.to(self._dev))
+        if ctx_len is None and not text.is_cuda and text.numel():
+            ctx_len = int(text.numpy().argmax(axis=-1).max()) + 1      # numpy: one thread, ~0.3 ms (a torch CPU op wakes the whole pool)
+        return self._text.encode_text(text.to(self._dev), ctx_len=ctx_len)
 
     def __call__(self, image):
         return self.encode_image(image)

@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
 }
 
 // text: x[b][t] = tok_emb[token] + pos[t]; eot_row[b] = b*T + argmax_t token (first maximum, like torch.argmax)
+// S = positions per row of `tokens` (77), T <= S = positions computed; the EOT position (argmax over all S) must be < T
 __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__ tokens, int batch, const half_t* __restrict__ emb,
-                                                         int vocab, const float* __restrict__ pos, long long rows, int T,
+                                                         int vocab, const float* __restrict__ pos, long long rows, int T, int S,
                                                          int width, half_t* __restrict__ out, int* __restrict__ eot_row) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__
     const long long b = r / T;
     const int t = (int)(r % T);
     int tok = 0;
-    if (b < batch) tok = tokens[b * T + t];
+    if (b < batch) tok = tokens[b * S + t];
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
     for (int c = lane * 4; c < width; c += 256) {
         const half4 e4 = *(const half4*)(emb + (size_t)tok * width + c);
@@ -183,11 +184,11 @@ __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__
     if (t == 0 && lane == 0) {
         int best = 0, bt = -2147483647;
         if (b < batch) {
-            for (int i = 0; i < T; ++i) {
-                const int v = tokens[b * T + i];
+            for (int i = 0; i < S; ++i) {
+                const int v = tokens[b * S + i];
                 if (v > bt) { bt = v; best = i; }
             }
-            eot_row[b] = (int)(b * T + best);
+            eot_row[b] = (int)(b * T + (best < T ? best : T - 1));
         }
     }
 }
@@ -675,14 +676,16 @@ __global__ void __launch_bounds__(256) gather2_rows_kernel(const half_t* __restr
 // need multiples of 256 images.  rows: token rows; prows: patch rows (im2col); bh: rows of the CLS / EOT head.
 struct EncPad {
     int batch, bh;
+    int tokens;          // positions per sequence that are computed: d.tokens, or fewer for trimmed text (scd_clip_encode_text_len)
     long long rows, prows;
 };
-static inline EncPad make_pad(const scd_encoder_desc& d, int batch) {
+static inline EncPad make_pad(const scd_encoder_desc& d, int batch, int tokens = 0) {
     EncPad p;
     p.batch = batch;
+    p.tokens = tokens > 0 ? tokens : d.tokens;
     p.bh = (batch + 255) / 256 * 256;
-    p.rows = ((long long)batch * d.tokens + 255) / 256 * 256;
-    p.prows = ((long long)batch * (d.tokens - 1) + 255) / 256 * 256;
+    p.rows = ((long long)batch * p.tokens + 255) / 256 * 256;
+    p.prows = ((long long)batch * (p.tokens - 1) + 255) / 256 * 256;
     return p;
 }
 
@@ -834,7 +837,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         // last block, fused path: only the CLS / EOT query is needed, so K and V are projected for all rows (two thirds of
         // the QKV GEMM), Q for the selected rows only, and the attention is one query per (image, head)
         static const int last_q_env = getenv("SCD_LAST_Q") ? atoi(getenv("SCD_LAST_Q")) : 1;
-        const bool last_q = last_sel && fuse && last_q_env && l == d.layers - 1 && d.width % 128 == 0 && d.tokens <= 256;
+        const bool last_q = last_sel && fuse && last_q_env && l == d.layers - 1 && d.width % 128 == 0 && pad.tokens <= 256;
         if (last_q) {
             const int bh = pad.bh;
             const size_t wk = (size_t)d.width * d.width;
@@ -847,7 +850,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             rc = scd_gemm_launch_ln(w.xsel, e->folded[l].wq, e->folded[l].bq, nullptr, w.hsel, bh, d.width, d.width, SCD_ACT_NONE, &lq, st);
             if (rc) return rc;
             const int items = bp * d.heads;
-            attention_single_query_kernel<<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.qkv, w.hsel, w.rows, w.ysel, d.tokens, d.width,
+            attention_single_query_kernel<<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.qkv, w.hsel, w.rows, w.ysel, pad.tokens, d.width,
                                                                                          d.heads, items, causal);
             SCD_HIP(hipMemsetAsync(w.stats_sel, 0, (size_t)bh * 16, st));
             scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr};
@@ -873,12 +876,14 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         }
         if (rc) return rc;
         static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
-        if (d.tokens > 192 && d.tokens <= 224 && !causal && attn_persist) {
+        if (pad.tokens > 192 && pad.tokens <= 224 && !causal && attn_persist) {
             { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel, 2 * 2 * 224 * 128); if (rc_) return rc_; }
             const int items = bp * d.heads;
-            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, items, attn_xmode());
-        } else if (d.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
-        else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, d.tokens, d.width, d.heads, causal, attn_xmode());
+            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
+        } else if (pad.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
+        else if (pad.tokens <= 32) attention_kernel<1><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
+        else if (pad.tokens <= 64) attention_kernel<2><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
+        else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         if (last_sel && l == d.layers - 1) {
             const int bh = pad.bh;
             gather2_rows_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.y, w.x, w.rows, bh, d.width, w.ysel, w.xsel);
@@ -1000,18 +1005,29 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
 
 extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
                                     void* ws, size_t ws_bytes, void* stream_) {
+    SCD_REQUIRE(e, "scd_clip_encode_text: null encoder");
+    return scd_clip_encode_text_len(h, e, tokens, batch, e->d.tokens, out, normalize, ws, ws_bytes, stream_);
+}
+
+// The text tower is causal and only the EOT position's output is used (model.py encode_text: x[arange, text.argmax(-1)]), so the
+// positions behind the last EOT of the batch never influence a result: with ctx_len >= 1 + max_b argmax_t tokens[b][t] only the
+// first ctx_len positions are computed.  Prompts are ~10-20 tokens of the 77: 4-5x fewer token rows through every GEMM, the same
+// bits out (masked keys contribute exact zeros to the softmax sums and to P V, and the GEMM rows are independent of M).
+extern "C" int scd_clip_encode_text_len(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, int ctx_len, void* out,
+                                        int normalize, void* ws, size_t ws_bytes, void* stream_) {
     SCD_REQUIRE(h && e && tokens && out && ws && batch > 0, "scd_clip_encode_text: bad arguments");
     { const int rc_ = scd_check_device(h, "scd_clip_encode_text"); if (rc_) return rc_; }
     SCD_REQUIRE(e->d.kind == 1, "scd_clip_encode_text: encoder is not a text tower");
+    SCD_REQUIRE(ctx_len >= 1 && ctx_len <= e->d.tokens, "scd_clip_encode_text_len: ctx_len=%d must be in [1, %d]", ctx_len, e->d.tokens);
     SCD_REQUIRE(ws_bytes >= scd_encoder_ws_bytes(e, batch), "scd_clip_encode_text: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     const scd_encoder_desc& d = e->d;
-    const EncPad pad = make_pad(d, batch);
+    const EncPad pad = make_pad(d, batch, ctx_len);
     EncWs w = carve(d, pad, (char*)ws);
     const long long rows = pad.rows;
     embed_text_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(tokens, batch, (const half_t*)e->w[W_PATCH], d.vocab,
-                                                                    (const float*)e->w[W_POS], rows, d.tokens, d.width, w.x, w.rows);
-    cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 1);
+                                                                    (const float*)e->w[W_POS], rows, pad.tokens, d.tokens, d.width, w.x, w.rows);
+    cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, pad.tokens, batch, 1);
     bool selected = false;
     int rc = run_blocks(e, w, pad, st, &selected);
     if (rc) return rc;

@@ -94,24 +94,26 @@ imagenet_templates = [
 ]
 
 
-def zeroshot_classifier(classnames, templates, model, names_per_batch=16):
+def zeroshot_classifier(classnames, templates, model, names_per_batch=64):
     """[embed_dim, n_names] fp16 on the device: per name normalise(encode_text(prompts)) -> mean -> normalise, stacked
     along dim=1.  The reference runs one 80x77 forward per name; here names are batched (names_per_batch*len(templates)
-    prompts per encode_text call) and the pooling is one fused kernel per batch."""
+    prompts per encode_text call) and the pooling is one fused kernel per batch.  64 names = 5,120 prompts per call keeps the
+    text tower at its large-batch rate (138 k prompts/s on one MI355X, tools/vocab_bench.py) with the host tokenisation of the
+    next batch running behind the device work."""
     from .. import clip
     n, t = len(classnames), len(templates)
     out = None
     for s in range(0, n, names_per_batch):
         names = classnames[s:s + names_per_batch]
         texts = [template.format(c) for c in names for template in templates]
-        emb = model.encode_text(clip.tokenize(texts).cuda())
+        emb = model.encode_text(clip.tokenize(texts))            # host ids: trimmed to the batch's longest prompt (clip/model.py)
         if out is None:
             out = torch.empty((emb.shape[1], n), dtype=torch.float16, device=emb.device)
         ops.prompt_pool(emb.contiguous(), len(names), t, out, s)
     return out
 
 
-def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_batch=16, build=None):
+def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_batch=64, build=None):
     """The vocabulary sharded over the ranks of `group` (one process per GPU): rank r builds the classifier columns of the
     contiguous name range [r*ceil(n/W), (r+1)*ceil(n/W)) with `zeroshot_classifier`, then ONE all-gather (RCCL over xGMI;
     name-major rows, the short last shard padded) gives every rank the full [embed_dim, n_names] matrix in the original

@@ -458,12 +458,18 @@ class Encoder:
                                         stream_ptr()))
         return out
 
-    def encode_text(self, tokens, normalize=False):
+    def encode_text(self, tokens, normalize=False, ctx_len=None):
+        """tokens int32 [B, 77] on the device.  ctx_len (> every row's EOT position): compute only the first ctx_len positions
+        (scd_clip_encode_text_len: same bits, ctx_len / 77 of the work)."""
         _need_cuda(tokens)
         tokens = tokens.to(torch.int32).contiguous()
         b = tokens.shape[0]
         out = torch.empty((b, self.out_dim), dtype=torch.float16, device=tokens.device)
         ws, nb = self._workspace(b)
-        check(_L().scd_clip_encode_text(handle(), self._enc, ptr(tokens), b, ptr(out), 1 if normalize else 0, ptr(ws), nb,
-                                        stream_ptr()))
+        if ctx_len is None or ctx_len >= tokens.shape[1]:
+            check(_L().scd_clip_encode_text(handle(), self._enc, ptr(tokens), b, ptr(out), 1 if normalize else 0, ptr(ws), nb,
+                                            stream_ptr()))
+        else:
+            check(_L().scd_clip_encode_text_len(handle(), self._enc, ptr(tokens), b, int(ctx_len), ptr(out), 1 if normalize else 0,
+                                                ptr(ws), nb, stream_ptr()))
         return out

@@ -638,6 +638,32 @@ def test_encoder_batch_invariance(ops):
     assert torch.equal(five, all13[4:9])
 
 
+@pytest.mark.parametrize("longest", [9, 32, 33, 64, 65, 76])
+def test_text_tower_trimmed_context_is_bit_identical(ops, longest):
+    """encode_text reads only the EOT position of a causal tower (clip model.py encode_text): computing the first
+    ctx_len > max EOT position token positions instead of all 77 gives the same bits (scd_clip_encode_text_len), through the
+    C ABI with device ids and through CLIP.encode_text with host ids (trimmed automatically)."""
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    sd = W.synthetic_clip_state_dict(seed=4, cfg=dict(v_layers=1, t_layers=3))
+    model = CLIP(sd).cuda().eval()
+    rs = np.random.RandomState(longest)
+    b = 37
+    tok = np.zeros((b, 77), dtype=np.int32)
+    lens = rs.randint(2, longest + 1, size=b)
+    lens[0] = longest                                      # EOT at position `longest`: ctx_len = longest + 1
+    for i in range(b):
+        tok[i, 0] = 49406
+        tok[i, 1:lens[i]] = rs.randint(1, 49405, size=lens[i] - 1)
+        tok[i, lens[i]] = 49407
+    t_host = torch.from_numpy(tok)
+    full = model.encode_text(t_host.cuda())                # device ids: all 77 positions
+    trimmed = model.encode_text(t_host)                    # host ids: ctx_len = longest + 1
+    explicit = model.encode_text(t_host.cuda(), ctx_len=min(77, longest + 3))
+    assert torch.equal(full, trimmed) and torch.equal(full, explicit)
+    assert bool(torch.isfinite(full.float()).all())
+
+
 def test_dino_tower_matches_oracle(ops):
     from scd_amd.clip import weights as W
     from scd_amd.clip.model import DinoViT

@@ -20,3 +20,10 @@ for _ in range(5): model.encode_text(tok)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print("encode_text B=%d: %.2f ms  -> %.0f prompts/s" % (B, ms, B / ms * 1e3))
+L = int(tok.argmax(-1).max()) + 1
+for _ in range(2): model.encode_text(tok, ctx_len=L)
+e0.record()
+for _ in range(5): model.encode_text(tok, ctx_len=L)
+e1.record(); torch.cuda.synchronize()
+ms2 = e0.elapsed_time(e1) / 5
+print("encode_text B=%d, only the first %d positions (scd_clip_encode_text_len): %.2f ms  -> %.0f prompts/s  (%.2fx)" % (B, L, ms2, B / ms2 * 1e3, ms / ms2))
