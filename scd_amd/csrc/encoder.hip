@@ -507,8 +507,12 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
                 }
             }
         }
-        if (query < T) {
-            half_t* orow = out + ((size_t)img * T + query) * width + head * 64;
+        // O leaves as whole 128-byte head slices: lane (query r, half hh) holds eight 8-byte pieces of its row, scattered over the
+        // row's eight 16-byte chunks; written straight from there every store instruction touched 32 rows with 16 bytes each
+        // (8 partial writes per cache line).  Through a per-wave LDS patch [32 rows][128 B] (chunk c of row r at c ^ (r & 7)) eight
+        // consecutive lanes write one row's slice, four 1-KB instructions per wave and item.
+        if (!(xmode & 8)) {
+            char* op = smem + 2 * 2 * KV + wave * 4096;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -516,8 +520,15 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
                     half4 o;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) o[q4] = (half_t)(oacc[db][4 * g + q4] * inv);
-                    *(half4*)(orow + db * 32 + 8 * g + 4 * hh) = o;
+                    *(half4*)(op + r * 128 + (((db * 4 + g) ^ (r & 7)) << 4) + 8 * hh) = o;
                 }
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int row = (lane >> 3) + 8 * i4, c = lane & 7;
+                const uint4 v4 = *(const uint4*)(op + row * 128 + ((c ^ (row & 7)) << 4));
+                const int qy = wave * 32 + row;
+                if (qy < T) *(uint4*)(out + ((size_t)img * T + qy) * width + head * 64 + c * 8) = v4;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = qn[s];
@@ -877,9 +888,10 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         if (rc) return rc;
         static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
         if (pad.tokens > 192 && pad.tokens <= 224 && !causal && attn_persist) {
-            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel, 2 * 2 * 224 * 128); if (rc_) return rc_; }
+            constexpr int attn_lds = 2 * 2 * 224 * 128 + 7 * 4096;      // K/V double buffer + the consumers' output patches
+            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel, attn_lds); if (rc_) return rc_; }
             const int items = bp * d.heads;
-            attention_persist_kernel<<<items < 256 ? items : 256, 512, 2 * 2 * 224 * 128, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
+            attention_persist_kernel<<<items < 256 ? items : 256, 512, attn_lds, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
         } else if (pad.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         else if (pad.tokens <= 32) attention_kernel<1><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         else if (pad.tokens <= 64) attention_kernel<2><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
