@@ -421,7 +421,10 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
         const int img = item / heads, head = item - img * heads;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (i + 1 < n_my) {
+        if (xmode & 16) {          // timing ablation: no Q loads
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qn[s] = qf[s];
+        } else if (i + 1 < n_my) {
             const int item2 = item + gridDim.x;
             const int img2 = item2 / heads, head2 = item2 - img2 * heads;
             const half_t* qbase = qkv + (size_t)img2 * T * ld + head2 * 64;
