@@ -164,6 +164,21 @@ class SimpleTokenizer:
             ids.extend(self.encoder[t] for t in self.bpe(tok).split(" "))
         return ids
 
+    def _cls(self, ch):
+        import regex as re
+        return "L" if re.fullmatch(r"\p{L}", ch) else "N" if re.fullmatch(r"\p{N}", ch) else "S" if ch.isspace() else "O"
+
+    def separable(self, a, b):
+        """True when no token of the pre-tokenisation pattern can span the junction of a text ending in character a and a text
+        starting with b, so that encode(x + y) == encode(x) + encode(y): tokens are runs of letters, single digits, runs of other
+        non-space characters, or the apostrophe contractions."""
+        ca, cb = self._cls(a), self._cls(b)
+        if ca == "S" or cb == "S":
+            return True
+        if a in "'&;#<|>" or b in "&;#<|>":          # contractions, html entities and the special tokens are matched as units
+            return False
+        return not ((ca == "L" and cb == "L") or (ca == "O" and cb == "O"))
+
 
 class HashTokenizer:
     """Stand-in used ONLY when the BPE merges file is absent (synthetic benchmarks): one id per word,
@@ -173,6 +188,9 @@ class HashTokenizer:
     def encode(self, text):
         import zlib
         return [1 + zlib.crc32(w.encode("utf-8")) % 49405 for w in text.lower().replace("_", " ").split()]
+
+    def separable(self, a, b):
+        return a.isspace() or b.isspace() or a == "_" or b == "_"      # one id per whitespace / underscore separated word
 
 
 _tokenizer = None
@@ -193,6 +211,79 @@ def _get_tokenizer():
                                     "the hash tokenizer stand-in must be requested explicitly (clip.allow_synthetic() or "
                                     "SCD_SYNTHETIC=1)")
     return _tokenizer
+
+
+def tokenize_templates(names, templates, context_length=77, truncate=False):
+    """tokenize([t.format(n) for n in names for t in templates]) - the prompt set of zeroshot_classifier - without running the
+    pre-tokeniser and the BPE over every prompt: a template's text before and after its single '{}' and every name are encoded
+    once and the id lists concatenated, wherever no token can span a junction (Tokenizer.separable: encode(x + y) == encode(x) +
+    encode(y) there).  Any other (name, template) pair goes through encode() of the formatted prompt.  Same rows, same order."""
+    tk = _get_tokenizer()
+    names = list(names)
+    plans = []
+    for t in templates:
+        parts = t.split("{}")
+        plain = len(parts) == 2 and "{" not in parts[0] + parts[1] and "}" not in parts[0] + parts[1]
+        if plain and (parts[0] == "" or parts[0][-1].isspace() or parts[0][-1] in ".,!?:\"(") and "&" not in t:
+            plans.append((parts[0], parts[1], tk.encode(parts[0]), tk.encode(parts[1])))
+        else:
+            plans.append(None)
+    n_names, n_t = len(names), len(templates)
+    out = np.zeros((n_names, n_t, context_length), dtype=np.int32)
+    sep = {}
+
+    def separable(a, b):
+        r = sep.get((a, b))
+        if r is None:
+            r = sep[(a, b)] = tk.separable(a, b)
+        return r
+
+    def slow(i, j):
+        ids = [tk.sot] + tk.encode(templates[j].format(names[i])) + [tk.eot]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError("Input %s is too long for context length %d" % (templates[j].format(names[i]), context_length))
+            ids = ids[:context_length]
+            ids[-1] = tk.eot
+        out[i, j, :len(ids)] = ids
+
+    simple = np.array([n != "" and n == n.strip() and "&" not in n and "{" not in n and "}" not in n for n in names], dtype=bool)
+    nid = [tk.encode(n) if ok else [] for n, ok in zip(names, simple)]
+    nlen = np.array([len(x) for x in nid], dtype=np.int64)
+    by_len = {}                                     # name-id matrices per id count: rows filled with one numpy assignment
+    for ln in np.unique(nlen[simple]) if simple.any() else []:
+        rows = np.nonzero(simple & (nlen == ln))[0]
+        by_len[int(ln)] = (rows, np.array([nid[i] for i in rows], dtype=np.int32).reshape(len(rows), int(ln)))
+    ufirst, ifirst = np.unique(np.array([n[:1] or " " for n in names]), return_inverse=True)
+    ulast, ilast = np.unique(np.array([n[-1:] or " " for n in names]), return_inverse=True)
+    for j, plan in enumerate(plans):
+        if plan is None:
+            for i in range(n_names):
+                slow(i, j)
+            continue
+        pre, suf, pid, sid = plan
+        ok = simple.copy()
+        if pre != "":
+            ok &= np.array([separable(pre[-1], c) for c in ufirst], dtype=bool)[ifirst]
+        if suf != "":
+            ok &= np.array([separable(c, suf[0]) for c in ulast], dtype=bool)[ilast]
+        lp, ls = len(pid), len(sid)
+        for ln, (rows, mat) in by_len.items():
+            keep = ok[rows]
+            if 2 + lp + ln + ls > context_length:          # too long: the slow path truncates or raises like tokenize()
+                ok[rows] = False
+                continue
+            r = rows[keep]
+            if not len(r):
+                continue
+            out[r, j, 0] = tk.sot
+            out[r, j, 1:1 + lp] = pid
+            out[r, j, 1 + lp:1 + lp + ln] = mat[keep]
+            out[r, j, 1 + lp + ln:1 + lp + ln + ls] = sid
+            out[r, j, 1 + lp + ln + ls] = tk.eot
+        for i in np.nonzero(~ok)[0]:
+            slow(i, j)
+    return torch.from_numpy(out.reshape(n_names * n_t, context_length))
 
 
 def tokenize(texts, context_length=77, truncate=False):

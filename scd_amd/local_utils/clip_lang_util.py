@@ -105,8 +105,8 @@ def zeroshot_classifier(classnames, templates, model, names_per_batch=64):
     out = None
     for s in range(0, n, names_per_batch):
         names = classnames[s:s + names_per_batch]
-        texts = [template.format(c) for c in names for template in templates]
-        emb = model.encode_text(clip.tokenize(texts))            # host ids: trimmed to the batch's longest prompt (clip/model.py)
+        # the prompts [template.format(c) for c in names for template in templates]; host ids: trimmed to the batch's longest prompt
+        emb = model.encode_text(clip.tokenize_templates(names, templates))
         if out is None:
             out = torch.empty((emb.shape[1], n), dtype=torch.float16, device=emb.device)
         ops.prompt_pool(emb.contiguous(), len(names), t, out, s)

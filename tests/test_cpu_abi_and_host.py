@@ -8,6 +8,7 @@ import subprocess
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import kmeans_oracle as ko
 from oracle import naming_oracle as no
@@ -331,6 +332,19 @@ def test_bpe_tokenizer_against_independent_implementation(tmp_path, monkeypatch)
     assert int(tok[0, 2 + len(ids):].abs().sum()) == 0
     with pytest.raises(RuntimeError, match="too long"):
         clip.tokenize(["fox " * 100])
+    # the prompt set of zeroshot_classifier assembled from once-encoded pieces (tokenize_templates) == tokenize of every prompt,
+    # for the BPE tokenizer and for the hash stand-in, including names / templates whose junctions are NOT separable
+    from scd_amd.local_utils.clip_lang_util import imagenet_templates
+    names = ["red fox", "b-flat clarinet", "carpenter's kit", "4x4", "c++", "st. bernard", "jack-o'-lantern", "name_with_underscore", "x&y",
+             " lead", "trail ", "", "(paren)", "end.", "don't", "UPPER Case", "na\u00efve caf\u00e9", "\uff13\u3041", "a{b}", "it's", "'quoted'", "zebra" * 30]
+    templates = list(imagenet_templates) + ["{}", "{} photo", "photo {}", "a {}'s toy", "({})", "x{}y", "a {}, a {{}}", "the {}&amp;co", "{}3", "3{}"]
+    for tkz in (ours, clip.HashTokenizer()):
+        monkeypatch.setattr(clip, "_tokenizer", tkz)
+        want = clip.tokenize([t.format(c) for c in names for t in templates], truncate=True)
+        got = clip.tokenize_templates(names, templates, truncate=True)
+        assert got.shape == want.shape and torch.equal(got, want), type(tkz).__name__
+    with pytest.raises(RuntimeError, match="too long"):
+        clip.tokenize_templates(["fox " * 100], ["a photo of a {}."])
 
 
 @pytest.mark.parametrize("mixed", [False, True])
