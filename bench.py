@@ -129,10 +129,10 @@ def dominant_kernel_roofline(ms, launches, flop):
     sec = ms / 1e3
     tf = flop / max(sec, 1e-12) / 1e12
     # HBM-side traffic per launch cannot be read without the profiler: it is taken from the committed PMC passes
-    # (profiles/r01_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script)
+    # (profiles/r02_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
             traffic = round(json.load(f)["traffic_bytes_per_launch"])
     except Exception:
         pass
