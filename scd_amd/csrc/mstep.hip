@@ -189,7 +189,36 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
             if (row < split) in0 += a; else in1 += a;
         }
     }
-    flush();
+    {   // merged last flush of the block's waves (see mstep_segment16_kernel)
+        __shared__ double fsum[4][MAXG * 64];
+        __shared__ int flab[4];
+        __shared__ long long frun[4];
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) fsum[wv][g * 64 + lane] = acc[g];
+        if (lane == 0) {
+            flab[wv] = (cur >= 0 && cur < k) ? cur : -1;
+            frun[wv] = run;
+        }
+        __syncthreads();
+        const int nw = (int)(((n - (long long)blockIdx.x * 4 * MSTEP_ROWS) + MSTEP_ROWS - 1) / MSTEP_ROWS);
+        const int lw = nw < 4 ? nw : 4;
+        bool leader = flab[wv] >= 0;
+        for (int w2 = 0; w2 < wv; ++w2) leader = leader && flab[w2] != flab[wv];
+        if (leader) {
+            long long tot_run = 0;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) acc[g] = 0.0;
+            for (int w2 = wv; w2 < lw; ++w2)
+                if (flab[w2] == flab[wv]) {
+                    tot_run += frun[w2];
+#pragma unroll
+                    for (int g = 0; g < MAXG; ++g) acc[g] += fsum[w2][g * 64 + lane];
+                }
+            run = tot_run;
+            flush();
+        }
+    }
     if (inertia) {
         in0 = wave_sum_f64(in0);
         in1 = wave_sum_f64(in1);
@@ -280,7 +309,45 @@ __global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __re
             if (row < split) in0 += a; else in1 += a;
         }
     }
-    flush();
+    // The last runs of the block's four waves usually belong to one cluster (256 consecutive sorted rows against ~1,000 per
+    // cluster): they are added up in LDS and leave as ONE set of float64 atomics (the kernel's time follows the number of
+    // flushes, ~12 ns per 768-column flush).  Wave w flushes for its label unless an earlier wave of the block ends in the same one.
+    {
+        __shared__ double fsum[4][MAXG2 * 128];
+        __shared__ int flab[4];
+        __shared__ long long frun[4];
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int g = 0; g < MAXG2; ++g) {
+            fsum[wv][g * 128 + 2 * lane] = acc[g][0];
+            fsum[wv][g * 128 + 2 * lane + 1] = acc[g][1];
+        }
+        if (lane == 0) {
+            flab[wv] = (cur >= 0 && cur < k) ? cur : -1;
+            frun[wv] = run;
+        }
+        __syncthreads();                 // (waves past the end of the keys have exited: they do not take part)
+        const int nw = (int)(((n - (long long)blockIdx.x * 4 * MSTEP_ROWS) + MSTEP_ROWS - 1) / MSTEP_ROWS);
+        const int lw = nw < 4 ? nw : 4;
+        bool leader = flab[wv] >= 0;
+        for (int w2 = 0; w2 < wv; ++w2) leader = leader && flab[w2] != flab[wv];
+        if (leader) {
+            long long tot_run = 0;
+#pragma unroll
+            for (int g = 0; g < MAXG2; ++g) acc[g][0] = acc[g][1] = 0.0;
+            for (int w2 = wv; w2 < lw; ++w2)
+                if (flab[w2] == flab[wv]) {
+                    tot_run += frun[w2];
+#pragma unroll
+                    for (int g = 0; g < MAXG2; ++g) {
+                        acc[g][0] += fsum[w2][g * 128 + 2 * lane];
+                        acc[g][1] += fsum[w2][g * 128 + 2 * lane + 1];
+                    }
+                }
+            run = tot_run;
+            flush();
+        }
+    }
     if (inertia) {
         in0 = wave_sum_f64(in0);
         in1 = wave_sum_f64(in1);
