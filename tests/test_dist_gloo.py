@@ -29,6 +29,12 @@ def _worker(rank, world, port, kind, q):
         cut_u, cut_l = 400, 100                                     # uneven shards
         su = slice(0, cut_u) if rank == 0 else slice(cut_u, None)
         sl = slice(0, cut_l) if rank == 0 else slice(cut_l, None)
+        if kind == "fit":                                            # no labelled rows: first centres are fetched across shards
+            km = KMeansEngine(k=k, max_iterations=5, n_init=3, random_state=7, backend=OracleBackend(), group=dist.group.WORLD)
+            sx = slice(0, 500) if rank == 0 else slice(500, None)
+            km.fit(torch.from_numpy(x[sx]))
+            q.put((rank, km.labels_.numpy(), km.cluster_centers_.numpy(), float(km.inertia_)))
+            return
         if kind == "sskm":
             km = KMeansEngine(k=k, max_iterations=6, n_init=2, random_state=3, backend=OracleBackend(), group=dist.group.WORLD)
         else:
@@ -71,6 +77,21 @@ def test_sharded_sskm_equals_single_process():
     lab_u = np.concatenate([res[0][0][100:], res[1][0][n_l - 100:]])
     assert np.array_equal(lab_l, okm.labels_[:n_l]) and np.array_equal(lab_u, okm.labels_[n_l:])
     assert np.array_equal(res[0][1], res[1][1])                      # identical centroids on every rank
+    assert np.allclose(res[0][1], okm.cluster_centers_, rtol=1e-6, atol=1e-7)
+    assert res[0][2] == res[1][2] == pytest.approx(float(okm.inertia_), rel=1e-6)
+
+
+def test_sharded_fit_equals_single_process():
+    """K_Means.fit over two row shards (lock-step seeding with the first centres fetched from their owner ranks, three
+    all-gathers per round for all restarts, one all-reduce per Lloyd iteration) == the single-process oracle run."""
+    from oracle import kmeans_oracle as ko, synth
+    res = _run("fit")
+    x, _, _ = synth.blob_case(900, 16, 6, 21)
+    okm = ko.K_Means(k=6, max_iterations=5, n_init=3, random_state=7)
+    okm.fit(x)
+    lab = np.concatenate([res[0][0], res[1][0]])
+    assert np.array_equal(lab, okm.labels_)
+    assert np.array_equal(res[0][1], res[1][1])
     assert np.allclose(res[0][1], okm.cluster_centers_, rtol=1e-6, atol=1e-7)
     assert res[0][2] == res[1][2] == pytest.approx(float(okm.inertia_), rel=1e-6)
 
