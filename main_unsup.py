@@ -174,6 +174,9 @@ def main(argv=None):
                 class_to_idx = {k: int(v) for k, v in json.load(fh).items()}
             # :398-502: class names that the vocabulary lacks are matched to their closest names by the text tower (row a7)
             cidx_to_cname = naming.resolve_class_names(args.dataset_name, args.corpus, class_to_idx, nouns, wt, model)
+        else:
+            print("(no --class_names: the semantic accuracies sACC / soft sACC and the name IoU of main_unsup.py:616-647 need the "
+                  "data set's class names and are not reported; cluster accuracies and the vote loop run as usual)")
         wn = wordnet_tables(args) if args.dataset_name != 'cub' else None
     mask_lab = np.asarray(mask_lab, dtype=bool)
     l_feats, u_feats = all_feats[mask_lab], all_feats[~mask_lab]
