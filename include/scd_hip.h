@@ -107,6 +107,15 @@ int scd_kmeans_mstep_f16(scd_handle h, const void* X16, const int32_t* labels, c
 int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old,
                         float* C_out, double* shift_out, int shift_mode, const void* prep, void* estep_ws,
                         size_t estep_ws_bytes, int64_t n, void* stream);
+/* One whole Lloyd iteration of the unconstrained K-Means (faster_mix_k_means_pytorch.py:187-214) = scd_kmeans_estep on the n_u
+ * unlabelled rows (labels_cat[n_cat - n_u ...] written; the first n_cat - n_u entries are the labelled rows' fixed cluster ids) +
+ * scd_kmeans_mstep[_f16] over the n_cat rows [labelled ; unlabelled] (X16_cat: their exact fp16 copy, or NULL) + scd_kmeans_finalize
+ * with the hand-over of the next E-step's centre operands, behind one call.  stats: device double [3] = {inertia labelled,
+ * inertia unlabelled, centre shift}.  C_out must differ from C_in; ws_e / ws_m as for the single calls. */
+int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,
+                          const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
+                          float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,
+                          size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream);
 /* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
  * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
  * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips

@@ -1684,3 +1684,29 @@ extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// One Lloyd iteration of the (unconstrained) semi-supervised K-Means behind ONE call (faster_mix_k_means_pytorch.py:187-214):
+// E-step of the unlabelled rows against C_in (labels written behind the labelled rows' fixed ones), M-step partial sums + inertia
+// over [labelled ; unlabelled], new centres + shift, and the next E-step's centre operands.  Nothing here is new arithmetic - it is
+// scd_kmeans_estep + scd_kmeans_mstep[_f16] + scd_kmeans_finalize with the buffers wired together - but a Lloyd iteration is
+// ~105 us of device work and the caller's per-call overhead (a Python caller: 15 tensor / FFI calls, ~185 us) otherwise bounds it.
+// stats[3] = {inertia of the labelled rows, inertia of the unlabelled rows, centre shift}, float64 on the device.
+extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,
+                                     const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
+                                     float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,
+                                     size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream) {
+    SCD_REQUIRE(h && X_u && prep_u && (X_cat || X16_cat) && labels_cat && C_in && C_out && sums && counts && stats && ws_e && ws_m,
+                "scd_kmeans_lloyd_step: null argument");
+    SCD_REQUIRE(n_u > 0 && n_cat >= n_u && C_in != C_out, "scd_kmeans_lloyd_step: bad arguments (n_u=%lld n_cat=%lld)", (long long)n_u,
+                (long long)n_cat);
+    const int64_t l_num = n_cat - n_u;
+    int rc = SCD_OK;
+    if (expect_few) rc = scd_kmeans_estep_hint(h, 1);
+    if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
+    if (!rc)
+        rc = X16_cat ? scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream)
+                     : scd_kmeans_mstep(h, X_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
+    if (!rc) rc = scd_kmeans_finalize(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream);
+    return rc;
+}

@@ -58,6 +58,9 @@ class HipBackend:
     def finalize(self, sums, counts, c_old, data=None):
         return self.ops.kmeans_finalize(sums, counts, c_old, data=data)
 
+    def lloyd_buffers(self, data_u, cat, cat16, k):
+        return self.ops.LloydBuffers(data_u, cat, cat16, k)
+
     def sum_f32(self, x):
         return self.ops.sum_f32(x)
 
@@ -350,6 +353,18 @@ class KMeansEngine:
         best = (None, None, None)
         pending = None                      # (it, labels snapshot, new centres, host buffer, event)
         n_done = 0
+        # without a process group the three calls of an iteration go out as ONE (scd_kmeans_lloyd_step): the Python call overhead
+        # of an iteration (185 us) otherwise exceeds its device time (105 us)
+        fused = None
+        if dd is None and hasattr(be, "lloyd_buffers"):
+            key = (data_u, cat.data_ptr(), self.k)
+            if getattr(self, "_lloyd_key", None) != key:
+                self._lloyd_buf = be.lloyd_buffers(data_u, cat, cat16, self.k)
+                self._lloyd_key = key
+            fused = self._lloyd_buf
+            fused.lab32[:l_num] = labels[:l_num]
+            fused.c0.copy_(centers)
+            centers = fused.c0              # iteration 0 reads the run's own start buffer and writes set 0
 
         def settle(p):
             nonlocal best
@@ -357,28 +372,36 @@ class KMeansEngine:
             host = p[3].numpy()
             inertia = np.float32(np.float32(host[1]) + np.float32(host[0]))
             if best[1] is None or inertia < best[1]:
-                best = (p[1], inertia, p[2])
+                best = (p[1], inertia, p[2].clone() if fused is not None else p[2])
             return bool(host[2] < self.tolerance)
 
         for it in range(self.max_iterations):
             old = centers
-            u_lab, _ = self._assign(data_u, old, it)
-            labels[l_num:] = u_lab.to(labels.dtype)
-            lab32 = labels.to(torch.int32).contiguous()
-            sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, self.k, l_num)
-            if dd:
-                packed = torch.cat([sums.reshape(-1), counts.to(torch.float64), inertia2])
-                dd.allreduce_(packed)
-                kd = sums.numel()
-                sums = packed[:kd].reshape(sums.shape)
-                counts = packed[kd:kd + self.k].round().to(torch.int64)
-                inertia2 = packed[kd + self.k:]
-            centers, shift = be.finalize(sums, counts, old, data_u)
             buf = ring[it & 1]
-            buf.copy_(torch.cat([inertia2, shift.reshape(1)]), non_blocking=True)
+            if fused is not None:
+                centers, stats = fused.c[it & 1], fused.stats[it & 1]
+                self.stats["estep_calls"] += 1
+                fused.step(old, centers, stats, it >= 2)
+                buf.copy_(stats, non_blocking=True)
+                snap = fused.lab32.clone()
+            else:
+                u_lab, _ = self._assign(data_u, old, it)
+                labels[l_num:] = u_lab.to(labels.dtype)
+                lab32 = labels.to(torch.int32).contiguous()
+                sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, self.k, l_num)
+                if dd:
+                    packed = torch.cat([sums.reshape(-1), counts.to(torch.float64), inertia2])
+                    dd.allreduce_(packed)
+                    kd = sums.numel()
+                    sums = packed[:kd].reshape(sums.shape)
+                    counts = packed[kd:kd + self.k].round().to(torch.int64)
+                    inertia2 = packed[kd + self.k:]
+                centers, shift = be.finalize(sums, counts, old, data_u)
+                buf.copy_(torch.cat([inertia2, shift.reshape(1)]), non_blocking=True)
+                snap, centers = labels.clone(), centers.clone()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-            cur = (it, labels.clone(), centers.clone(), buf, ev)
+            cur = (it, snap, centers, buf, ev)
             if pending is not None:
                 n_done = pending[0] + 1
                 if settle(pending):          # iteration `it` was launched on speculation: drop it
@@ -388,7 +411,7 @@ class KMeansEngine:
         if pending is not None:
             n_done = pending[0] + 1
             settle(pending)
-        return best[0], best[1], best[2], n_done
+        return best[0].to(labels.dtype), best[1], best[2], n_done
 
     # ------------------------------------------------------------------ reference API
     def fit_once(self, X, random_state, data=None, init_centers=None):

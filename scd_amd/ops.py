@@ -203,6 +203,35 @@ def kmeans_mstep(x, labels32, c_old, k, split=0, x16=None):
     return sums, counts, inertia
 
 
+class LloydBuffers:
+    """Device buffers of KMeansEngine's Lloyd loop through scd_kmeans_lloyd_step: two sets (the host reads set i while the
+    device fills set i + 1), allocated once per fit."""
+
+    def __init__(self, data_u, cat, cat16, k):
+        dev = cat.device
+        n_cat, d = cat.shape
+        self.data, self.cat, self.cat16, self.k = data_u, cat, cat16, k
+        self.lab32 = torch.empty(n_cat, dtype=torch.int32, device=dev)
+        self.c = [torch.empty((k, d), dtype=torch.float32, device=dev) for _ in range(2)]
+        # a run's initial centres get a buffer of their own: the hand-over of scd_kmeans_finalize is keyed on the centre POINTER, and
+        # one of self.c may still be registered (with the previous run's last centres) when the next restart begins
+        self.c0 = torch.empty((k, d), dtype=torch.float32, device=dev)
+        self.sums = torch.empty((k, d), dtype=torch.float64, device=dev)
+        self.counts = torch.empty(k, dtype=torch.int64, device=dev)
+        self.stats = [torch.empty(3, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.nb_e = _L().scd_kmeans_estep_ws_bytes(data_u.n, data_u.d, k)
+        self.ws_e = data_u.ws(("e", k), self.nb_e)
+        self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)
+        self.ws_m = _ws(self.nb_m, dev)
+
+    def step(self, c_in, c_out, stats, expect_few):
+        d = self.data
+        check(_L().scd_kmeans_lloyd_step(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat), ptr(self.cat16), self.cat.shape[0],
+                                         d.d, self.k, ptr(self.lab32), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
+                                         ptr(stats), 1 if expect_few else 0, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m,
+                                         stream_ptr()))
+
+
 def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):
     """shift_mode 0: (sum_k ||dc_k||)^2 (the reference's SSKM test); 1: sum_k ||dc_k||^2 (sklearn's center_shift_tot).
     data (a KMeansData): the centres' E-step operands are produced by the same launch, for the next data.estep(centres)."""
