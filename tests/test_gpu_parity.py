@@ -336,6 +336,48 @@ def test_kpp_lockstep_equals_sequential_restarts_gpu(ops, monkeypatch, mixed):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
 
 
+def test_lloyd_step_full_size_properties(ops):
+    """scd_kmeans_lloyd_step at the C2 size (126,976 x 512, K = 100; too large for the oracle), through properties that do not
+    depend on the size: its labels are those of the stand-alone E-step, the counts add up to N, the float64 column totals of the
+    per-cluster sums equal the column totals of X EXACTLY (fp16-exact rows: every partial sum is an integer multiple of 2^-24
+    below 2^29), its centres / statistics are those of the three single calls, and a second step from the new centres keeps
+    every label whose row did not move (shift -> 0 at a fixed point)."""
+    n, d, k = 126976, 512, 100
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cen = torch.nn.functional.normalize(torch.randn(k, d, device="cuda", generator=g), dim=-1)
+    y = torch.randint(0, k, (n,), device="cuda", generator=g)
+    x = (cen[y] + (0.8 / d ** 0.5) * torch.randn(n, d, device="cuda", generator=g)).half().float().contiguous()
+    data = ops.KMeansData(x)
+    x16 = ops.f16_exact(x)
+    assert x16 is not None
+    c0 = (cen + 0.02 * torch.randn(k, d, device="cuda", generator=g)).contiguous()      # near the blobs: no cluster runs empty
+    buf = ops.LloydBuffers(data, x, x16, k)
+    buf.c0.copy_(c0)
+    buf.step(buf.c0, buf.c[0], buf.stats[0], False)
+    lab = buf.lab32.clone()
+    assert torch.equal(lab, data.estep(c0))
+    assert int(buf.counts.sum()) == n and torch.equal(buf.counts, torch.bincount(lab.long(), minlength=k))
+    assert torch.equal(buf.sums.sum(0), x.double().sum(0))                       # checksum of checksums, exact
+    sums, counts, inertia = ops.kmeans_mstep(x, lab, c0, k, 0, x16=x16)
+    c1, shift = ops.kmeans_finalize(sums, counts, c0)
+    assert torch.equal(buf.c[0], c1) and torch.equal(buf.counts, counts)
+    st = buf.stats[0].cpu().numpy()
+    assert st[0] == 0.0 and st[1] == pytest.approx(float(inertia[1]), rel=1e-12) and st[2] == pytest.approx(float(shift), rel=1e-12)
+    # iterate to a fixed point: labels stop changing, the shift reaches exactly 0, and the step then reproduces itself
+    prev, it = lab, 0
+    while it < 60:
+        buf.step(buf.c[it & 1], buf.c[1 - (it & 1)], buf.stats[1 - (it & 1)], it >= 1)
+        cur = buf.lab32.clone()
+        it += 1
+        if torch.equal(cur, prev):
+            break
+        prev = cur
+    assert it < 60
+    buf.step(buf.c[it & 1], buf.c[1 - (it & 1)], buf.stats[1 - (it & 1)], True)
+    assert torch.equal(buf.lab32, prev) and float(buf.stats[1 - (it & 1)][2]) == 0.0
+    assert torch.equal(buf.c[0], buf.c[1])
+
+
 # ----------------------------------------------------------------------------------------------- k-means end to end
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_sskm_matches_reference_golden(ops, golden, tag):
