@@ -525,6 +525,7 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
                     for (int q4 = 0; q4 < 4; ++q4) o[q4] = (half_t)(oacc[db][4 * g + q4] * inv);
                     *(half4*)(op + r * 128 + (((db * 4 + g) ^ (r & 7)) << 4) + 8 * hh) = o;
                 }
+            asm volatile("" ::: "memory");      // the patch is re-read through another vector type: no compiler reordering across
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 const int row = (lane >> 3) + 8 * i4, c = lane & 7;
@@ -532,6 +533,7 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
                 const int qy = wave * 32 + row;
                 if (qy < T) *(uint4*)(out + ((size_t)img * T + qy) * width + head * 64 + c * 8) = v4;
             }
+            asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = qn[s];
