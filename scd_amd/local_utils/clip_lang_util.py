@@ -94,26 +94,42 @@ imagenet_templates = [
 ]
 
 
-def zeroshot_classifier(classnames, templates, model, names_per_batch=64):
+def zeroshot_classifier(classnames, templates, model, names_per_batch=256, length_groups=4):
     """[embed_dim, n_names] fp16 on the device: per name normalise(encode_text(prompts)) -> mean -> normalise, stacked
     along dim=1.  The reference runs one 80x77 forward per name; here names are batched (names_per_batch*len(templates)
-    prompts per encode_text call) and the pooling is one fused kernel per batch.  64 names = 5,120 prompts per call keeps the
-    text tower at its large-batch rate (138 k prompts/s on one MI355X, tools/vocab_bench.py) with the host tokenisation of the
-    next batch running behind the device work."""
+    prompts per step), the prompts of a step are encoded in `length_groups` groups of similar length - each group only up to ITS
+    longest prompt's EOT position (clip/model.py encode_text: the tower is causal, features are bit-identical whatever the
+    grouping) - and the pooling is one fused kernel per step.  The host tokenisation of the next step runs behind the device work."""
     from .. import clip
     n, t = len(classnames), len(templates)
     out = None
     for s in range(0, n, names_per_batch):
         names = classnames[s:s + names_per_batch]
-        # the prompts [template.format(c) for c in names for template in templates]; host ids: trimmed to the batch's longest prompt
-        emb = model.encode_text(clip.tokenize_templates(names, templates))
+        # the prompts [template.format(c) for c in names for template in templates], ids on the host
+        tok = clip.tokenize_templates(names, templates)
+        if getattr(model, "_dev", None) is None or length_groups <= 1 or tok.shape[0] < 8 * length_groups:
+            emb = model.encode_text(tok)
+        else:
+            eot = tok.numpy().argmax(axis=-1)           # (numpy on the host: a torch CPU op wakes the whole intra-op pool)
+            order = np.argsort(eot, kind="stable")
+            # ONE upload per step (ids + permutation): a pageable copy blocks the host until the stream reaches it, and per
+            # group that would serialise this step's encodes with the next step's tokenisation
+            dev_in = torch.from_numpy(np.concatenate([tok.numpy().reshape(-1), order.astype(np.int32)])).to(model._dev)
+            tok_d = dev_in[:tok.numel()].reshape(tok.shape)
+            order_d = dev_in[tok.numel():].to(torch.int64)
+            emb = None
+            for part, part_d in zip(np.array_split(order, length_groups), torch.tensor_split(order_d, length_groups)):
+                e = model.encode_text(tok_d.index_select(0, part_d), ctx_len=int(eot[part].max()) + 1)
+                if emb is None:
+                    emb = torch.empty((tok.shape[0], e.shape[1]), dtype=e.dtype, device=e.device)
+                emb.index_copy_(0, part_d, e)
         if out is None:
             out = torch.empty((emb.shape[1], n), dtype=torch.float16, device=emb.device)
         ops.prompt_pool(emb.contiguous(), len(names), t, out, s)
     return out
 
 
-def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_batch=64, build=None):
+def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_batch=256, build=None):
     """The vocabulary sharded over the ranks of `group` (one process per GPU): rank r builds the classifier columns of the
     contiguous name range [r*ceil(n/W), (r+1)*ceil(n/W)) with `zeroshot_classifier`, then ONE all-gather (RCCL over xGMI;
     name-major rows, the short last shard padded) gives every rank the full [embed_dim, n_names] matrix in the original

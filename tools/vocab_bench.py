@@ -10,7 +10,7 @@ from scd_amd.local_utils.clip_lang_util import imagenet_templates, zeroshot_clas
 from scd_amd import ops
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 2100
-NPB = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+NPB = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 clip.allow_synthetic()
 model, _ = clip.load("ViT-B/16", device="cuda")
 if len(sys.argv) > 3 and sys.argv[3] == "bpe":
