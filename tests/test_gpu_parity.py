@@ -733,6 +733,19 @@ def test_zeroshot_classifier_pooling(ops):
     ref = no.zeroshot_classifier(names, tmpl, lambda t: co.clip_encode_text(sd16, t.long()).numpy(), clip.tokenize)
     assert _cos(zs.float().cpu().t(), torch.from_numpy(ref).t()).min().item() > 1 - 1e-3
     assert np.allclose(np.linalg.norm(zs.float().cpu().numpy(), axis=0), 1.0, atol=2e-3)
+    # batching and length grouping are invisible in the result: whole vocabulary in one step with the prompts encoded in four
+    # length groups (each trimmed to its own longest prompt) == two names per step, one group == full-length encodes
+    names = names + ["soft-coated wheaten terrier", "x", "american black bear cub of the year"]
+    tmpl = clu.imagenet_templates
+    a = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=256, length_groups=4)
+    b = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=2, length_groups=1)
+    full = []
+    for c in names:
+        e = model.encode_text(clip.tokenize([t.format(c) for t in tmpl]).cuda())          # device ids: all 77 positions
+        o = torch.empty((e.shape[1], 1), dtype=torch.float16, device="cuda")
+        ops.prompt_pool(e.contiguous(), 1, len(tmpl), o, 0)
+        full.append(o)
+    assert torch.equal(a, b) and torch.equal(a, torch.cat(full, 1))
 
 
 # ----------------------------------------------------------------------------------------------- full-size properties
