@@ -661,6 +661,9 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_TN_MAJOR
 #define W4_TN_MAJOR 0   // MFMA order inside a sub-step: 0 = m-tile outer (eight MFMAs share the A fragment), 1 = n-tile outer
 #endif
+#ifndef W4_PROBE_VALU
+#define W4_PROBE_VALU 0
+#endif
 #ifndef W4_DEFER_STORES
 #define W4_DEFER_STORES 1
 #endif
@@ -810,6 +813,20 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #pragma unroll
             for (int q = 0; q < 8; ++q) rq[e][p][q] = (half_t)0.f;
 
+    // timing probe (build with -DW4_PROBE_VALU=n): n independent VALU instructions behind every MFMA - what an epilogue dealt over
+    // the next tile's MFMA stream would add to the wave's instruction stream
+    float pv0 = 1.f + lane, pv1 = 2.f + lane, pv2 = 3.f + lane, pv3 = 0.5f;
+#if W4_PROBE_VALU == 0
+#define W4_PROBE()
+#elif W4_PROBE_VALU == 1
+#define W4_PROBE() asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pv0));
+#elif W4_PROBE_VALU == 2
+#define W4_PROBE() asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1" : "+v"(pv0), "+v"(pv1));
+#elif W4_PROBE_VALU == 3
+#define W4_PROBE() asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2" : "+v"(pv0), "+v"(pv1), "+v"(pv2));
+#else
+#define W4_PROBE() asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_exp_f32 %1, %1\n\tv_fma_f32 %2, %2, %2, %2" : "+v"(pv0), "+v"(pv3), "+v"(pv2));
+#endif
     half8 fwA[8], fwB[8], faA[8], faB[8];   // W / A fragments of the even (A) and odd (B) sub-step
 #define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W4_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
@@ -835,6 +852,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));         \
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));          \
         HOOK(o_ * 8 + i_)                                                                                        \
+        W4_PROBE()                                                                                               \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);
 #define W4_H_NONE(i)
@@ -1100,6 +1118,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail refills must land before the LDS is handed to another block
+    if (W4_PROBE_VALU && pv0 + pv1 + pv2 + pv3 == 12345.678f) C[0] = (half_t)pv0;
+#undef W4_PROBE
 #undef W4_EVEN
 #undef W4_ODD
 #undef W4_SUB
