@@ -664,6 +664,9 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_PROBE_VALU
 #define W4_PROBE_VALU 0
 #endif
+#ifndef W4_TNW
+#define W4_TNW 8   // timing probe only (-DW4_TNW=4): the wave computes 4 of its 8 n-tiles - the main loop of a 256 x 128 block tile; results are wrong
+#endif
 #ifndef W4_DEFER_STORES
 #define W4_DEFER_STORES 1
 #endif
@@ -772,7 +775,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #pragma unroll
         for (int p = 0; p < 8; ++p) issue_a(p, slot);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) issue_w(p, slot);
+        for (int p = 0; p < W4_TNW; ++p) issue_w(p, slot);
     };
     // fragment addresses: tile t adds t * 2048; k-half j uses chunk (q16 + 4j) ^ sw
     const int fsw = (c16 >> 1) & 7;
@@ -801,7 +804,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     for (int p = 0; p < 8; ++p) issue_a(p, 1);
     if (!DMA_SPLIT) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) issue_w(p, 1);
+        for (int p = 0; p < W4_TNW; ++p) issue_w(p, 1);
     }
     issue_advance();
     constexpr int RD = LN == 2 ? 2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
@@ -847,17 +850,18 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_SUB(FW, FA, Z, HOOK) W4_SUB_RANGE(FW, FA, Z, HOOK, 0, 8)
 #define W4_SUB_RANGE(FW, FA, Z, HOOK, TM0, TM1)                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int o_ = (TM0); o_ < (TM1); ++o_) _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {     \
+    _Pragma("unroll") for (int o_ = (TM0); o_ < (TM1); ++o_) _Pragma("unroll") for (int i_ = 0; i_ < W4_TNW; ++i_) {     \
         const int tm = W4_TN_MAJOR ? i_ : o_, tn = W4_TN_MAJOR ? o_ : i_;                                        \
         if (Z) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));         \
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[tn][tm]) : "v"(FW[tn]), "v"(FA[tm]));          \
-        HOOK(o_ * 8 + i_)                                                                                        \
+        HOOK(o_ * W4_TNW + i_)                                                                                   \
         W4_PROBE()                                                                                               \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);
 #define W4_H_NONE(i)
     // even sub-step: reads the odd sub-step's fragments (k-half 1 of the same slot) under MFMAs 0..47 and issues the W part
     // of the refill that the previous odd sub-step began (the other slot), one fill per four MFMAs of the first half
+#if W4_TNW == 8
 #define W4_H_EVEN(i)                                                                                             \
     if (DMA_SPLIT && (i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);                             \
     if ((i) < 48 && (i) % 3 == 0) W4_RD(fwB[((i) / 3) & 7], fw1 + so, (((i) / 3) & 7) * 2048);                   \
@@ -875,6 +879,17 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) < 8) W4_RD(fwA[(((i) - L0) >> 1) & 7], fw0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
     if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) >= 8 && (((i) - L0) >> 1) < 16) W4_RD(faA[(((i) - L0) >> 1) & 7], fa0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
     if (LATE_BAR && DMA_SPLIT && (i) >= L0 && ((i) - L0) % LS == LS / 2 && ((i) - L0) / LS < 8) issue_a((((i) - L0) / LS) & 7, cslot);
+#else
+    // 32 MFMAs per sub-step: 12 fragment reads under the first 24, the W part of the refill (4 instructions per wave) every 8th
+#define W4_H_EVEN(i)                                                                                             \
+    if (DMA_SPLIT && ((i) & 7) == 2) issue_w(((i) >> 3) & 3, cslot ^ 1);                                         \
+    if ((i) < 24 && ((i) & 1) == 0 && ((i) >> 1) < 4) W4_RD(fwB[((i) >> 1) & 3], fw1 + so, (((i) >> 1) & 3) * 2048); \
+    if ((i) < 24 && ((i) & 1) == 0 && ((i) >> 1) >= 4) W4_RD(faB[(((i) >> 1) - 4) & 7], fa1 + so, ((((i) >> 1) - 4) & 7) * 2048);
+#define W4_H_ODD(i)                                                                                              \
+    if ((i) >= 8 && (((i) - 8) & 1) == 0 && (((i) - 8) >> 1) < 4) W4_RD(fwA[(((i) - 8) >> 1) & 3], fw0 + no, ((((i) - 8) >> 1) & 3) * 2048); \
+    if ((i) >= 8 && (((i) - 8) & 1) == 0 && (((i) - 8) >> 1) >= 4) W4_RD(faA[((((i) - 8) >> 1) - 4) & 7], fa0 + no, (((((i) - 8) >> 1) - 4) & 7) * 2048); \
+    if (DMA_SPLIT && (i) >= 8 && ((i) - 8) % 3 == 1 && ((i) - 8) / 3 < 8) issue_a((((i) - 8) / 3) & 7, cslot);
+#endif
 #define W4_EVEN(Z)                                                                                               \
     {                                                                                                            \
         const unsigned so = cslot * SLOT;                                                                        \
