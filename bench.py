@@ -50,7 +50,9 @@ def parse():
     p.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     p.add_argument("--images", type=int, default=None, help="images per GPU (default = the config's)")
     p.add_argument("--n-cluster", type=int, default=None, help="classes / clusters (default = the config's)")
-    p.add_argument("--batch", type=int, default=665)   # 665*197 rows = 512 GEMM row tiles: every GEMM fills the 256 CUs exactly
+    # 665*197 rows = 512 GEMM row tiles: every GEMM fills the 256 CUs exactly; six of those per launch (3,072 row tiles) amortise
+    # the ramp-up / tail of the ~60 launches per batch: +1.5-1.9 % over 665 on the same box, features bit-identical (tools/bigbatch_check.py)
+    p.add_argument("--batch", type=int, default=3990)
     p.add_argument("--vocab", type=int, default=VOCAB)
     p.add_argument("--no-cpu-baseline", action="store_true")
     a = p.parse_args()
@@ -130,10 +132,13 @@ def dominant_kernel_roofline(ms, launches, flop):
     tf = flop / max(sec, 1e-12) / 1e12
     # HBM-side traffic per launch cannot be read without the profiler: it is taken from the committed PMC passes
     # (profiles/r02_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script)
+    # at the default launch size (3,990 images = 786,432 rows); another --batch scales it by its rows per launch
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
-            traffic = round(json.load(f)["traffic_bytes_per_launch"])
+            pm = json.load(f)
+        rows_per_launch = flop / max(launches, 1) / (2.0 * 3072 * 768)
+        traffic = round(pm["traffic_bytes_per_launch"] * rows_per_launch / pm["rows"])
     except Exception:
         pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",

@@ -39,7 +39,7 @@ def _allgather_rows(t, group):
 
 
 def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2,
-        batch=665, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None):
+        batch=3990, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None):
     """One pass over `images` (this rank's shard).  Returns dict(feats, labels, cand_names, u_preds, name_idx)."""
     def mark(name):
         if timers is not None:
