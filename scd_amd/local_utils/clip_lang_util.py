@@ -94,7 +94,7 @@ imagenet_templates = [
 ]
 
 
-def zeroshot_classifier(classnames, templates, model, names_per_batch=256, length_groups=4):
+def zeroshot_classifier(classnames, templates, model, names_per_batch=256, length_groups=4, min_group=2048):
     """[embed_dim, n_names] fp16 on the device: per name normalise(encode_text(prompts)) -> mean -> normalise, stacked
     along dim=1.  The reference runs one 80x77 forward per name; here names are batched (names_per_batch*len(templates)
     prompts per step), the prompts of a step are encoded in `length_groups` groups of similar length - each group only up to ITS
@@ -107,7 +107,8 @@ def zeroshot_classifier(classnames, templates, model, names_per_batch=256, lengt
         names = classnames[s:s + names_per_batch]
         # the prompts [template.format(c) for c in names for template in templates], ids on the host
         tok = clip.tokenize_templates(names, templates)
-        if getattr(model, "_dev", None) is None or length_groups <= 1 or tok.shape[0] < 8 * length_groups:
+        groups = min(length_groups, tok.shape[0] // min_group)      # a group below ~2k prompts no longer fills the GEMMs
+        if getattr(model, "_dev", None) is None or groups <= 1:
             emb = model.encode_text(tok)
         else:
             eot = tok.numpy().argmax(axis=-1)           # (numpy on the host: a torch CPU op wakes the whole intra-op pool)
@@ -118,7 +119,7 @@ def zeroshot_classifier(classnames, templates, model, names_per_batch=256, lengt
             tok_d = dev_in[:tok.numel()].reshape(tok.shape)
             order_d = dev_in[tok.numel():].to(torch.int64)
             emb = None
-            for part, part_d in zip(np.array_split(order, length_groups), torch.tensor_split(order_d, length_groups)):
+            for part, part_d in zip(np.array_split(order, groups), torch.tensor_split(order_d, groups)):
                 e = model.encode_text(tok_d.index_select(0, part_d), ctx_len=int(eot[part].max()) + 1)
                 if emb is None:
                     emb = torch.empty((tok.shape[0], e.shape[1]), dtype=e.dtype, device=e.device)

@@ -737,7 +737,7 @@ def test_zeroshot_classifier_pooling(ops):
     # length groups (each trimmed to its own longest prompt) == two names per step, one group == full-length encodes
     names = names + ["soft-coated wheaten terrier", "x", "american black bear cub of the year"]
     tmpl = clu.imagenet_templates
-    a = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=256, length_groups=4)
+    a = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=256, length_groups=4, min_group=64)
     b = clu.zeroshot_classifier(names, tmpl, model, names_per_batch=2, length_groups=1)
     full = []
     for c in names:
