@@ -217,6 +217,18 @@ def gen_sklearn_kmeans():
         out["%s_inertia" % tag] = np.array(float(km.inertia_))
         out["%s_n_iter" % tag] = np.array(int(km.n_iter_))
         print("sklearn KMeans", tag, "inertia", km.inertia_, "n_iter", km.n_iter_)
+        # the call the reference makes (main_unsup.py:362, main_ptsup.py:381): k-means++ seeded, random_state=0.  Three pins:
+        # the public seeding function, the default call of this scikit-learn (n_init='auto' -> 1 start) and ten starts on one
+        # RandomState (n_init=10, the default of the scikit-learn 1.0.2 that requirements.txt pins)
+        from sklearn.cluster import kmeans_plusplus
+        _, picks = kmeans_plusplus(x, k, random_state=0)
+        out["%s_kpp_picks" % tag] = picks.astype(np.int64)
+        for name, kw in (("default", {}), ("n10", {"n_init": 10})):
+            kd = KMeans(n_clusters=k, random_state=0, **kw).fit(x)
+            out["%s_%s_labels" % (tag, name)] = kd.labels_
+            out["%s_%s_inertia" % (tag, name)] = np.array(float(kd.inertia_))
+            out["%s_%s_n_iter" % (tag, name)] = np.array(int(kd.n_iter_))
+            print("   ", name, "inertia", kd.inertia_, "n_iter", kd.n_iter_)
     np.savez_compressed(os.path.join(OUT, "kmeans_sklearn.npz"), **out)
 
 

@@ -276,17 +276,23 @@ def sklearn_lloyd(x, init, max_iter=300, tol=1e-4):
     return labels.astype(np.int32), inertia, centers, it + 1
 
 
-def sklearn_kpp(x, k, random_state):
-    """`_kmeans_plusplus` of scikit-learn 1.7.2 with this oracle's arithmetic: closest distances are float32(float64 exact),
+def sklearn_kpp(x, k, random_state, compat="1.7.2"):
+    """`_kmeans_plusplus` of scikit-learn with this oracle's arithmetic: closest distances are float32(float64 exact),
     the potential is float32(float64 sum) (sklearn: a float32 BLAS dot), candidates = searchsorted(cumsum_f64(d2), u * pot),
-    the candidate with the smallest new potential (float64 sum) wins.  RandomState consumption as in sklearn: one
-    choice(n, p=uniform), then uniform(size=2 + int(log k)) per added centre.  Returns the chosen row indices."""
+    the candidate with the smallest new potential (float64 sum) wins.  RandomState consumption as in sklearn: the first centre,
+    then 2 + int(log k) uniforms per added centre.  The first centre is `choice(n, p=uniform)` in scikit-learn 1.7.2 (compat
+    "1.7.2": pinned by tests/golden/kmeans_sklearn.npz `*_kpp_picks`, the output of sklearn.cluster.kmeans_plusplus) and
+    `randint(n)` in the 1.0.2 that /root/reference/requirements.txt pins (compat "1.0.2": restated from the public source,
+    that version is not installed here => unpinned).  Returns the chosen row indices."""
     rs = check_random_state(random_state)
     x = np.asarray(x, dtype=F32)
     n = x.shape[0]
     trials = 2 + int(np.log(k))
-    p = np.ones(n, dtype=F32)
-    picks = [int(rs.choice(n, p=p / p.sum()))]
+    if compat == "1.0.2":
+        picks = [int(rs.randint(n))]
+    else:
+        p = np.ones(n, dtype=F32)
+        picks = [int(rs.choice(n, p=p / p.sum()))]
     d2 = pairwise_distance64(x, x[picks[0]][None])[:, 0].astype(F32)
     for _ in range(1, k):
         pot = F32(d2.astype(F64).sum())
@@ -298,3 +304,39 @@ def sklearn_kpp(x, k, random_state):
         picks.append(int(cand[best]))
         d2 = dc[best]
     return np.array(picks)
+
+
+def _same_clustering(a, b, k):
+    """sklearn/cluster/_k_means_common.pyx `_is_same_clustering`: equal up to a permutation of the labels."""
+    mapping = np.full(k, -1, dtype=np.int64)
+    for la, lb in zip(a.tolist(), b.tolist()):
+        if mapping[la] == -1:
+            mapping[la] = lb
+        elif mapping[la] != lb:
+            return False
+    return True
+
+
+def sklearn_kmeans(x, k, random_state=0, n_init="auto", compat="1.7.2", max_iter=300, tol=1e-4):
+    """`KMeans(n_clusters=k, random_state=0[, n_init]).fit(x)` as /root/reference/main_unsup.py:362 / main_ptsup.py:381 call
+    it: n_init k-means++ starts on ONE RandomState, each followed by Lloyd; the kept start is the first with a strictly smaller
+    inertia (1.7.2: and a different clustering; 1.0.2: smaller than best * (1 - 1e-6)).  n_init 'auto' -> 1 (1.7.2) / 10 (the
+    1.0.2 default).  Pinned for compat "1.7.2" by the golden's `*_default_labels` and `*_n10_labels`.
+    Returns (labels int32, inertia, centres float32, n_iter)."""
+    rs = check_random_state(random_state)
+    x = np.asarray(x, dtype=F32)
+    if n_init == "auto":
+        n_init = 10 if compat == "1.0.2" else 1
+    best = None
+    for _ in range(n_init):
+        picks = sklearn_kpp(x, k, rs, compat)
+        lab, inertia, cent, n_iter = sklearn_lloyd(x, x[picks], max_iter, tol)
+        if best is None:
+            better = True
+        elif compat == "1.0.2":
+            better = inertia < best[1] * (1 - 1e-6)
+        else:
+            better = inertia < best[1] and not _same_clustering(lab, best[0], k)
+        if better:
+            best = (lab, inertia, cent, n_iter)
+    return best

@@ -2,20 +2,25 @@
 (/root/reference/main_unsup.py:362, main_ptsup.py:381: `KMeans(n_clusters=args.n_cluster, random_state=0).fit(u_feats).labels_`,
 the default of scripts/evaluate_unsupervised.sh), on the HIP k-means kernels instead of the host's Cython/OpenMP Lloyd.
 
-Restated from scikit-learn 1.7.2 (third-party, not under /root/reference; sklearn/cluster/_kmeans.py):
-  * `_kmeans_plusplus`: first centre `random_state.choice(n, p=uniform)`, then per centre 2 + floor(ln k) candidates drawn with
-    `uniform(size=L) * pot` -> searchsorted on the cumulative closest distances; the candidate with the smallest new potential wins.
-    The RandomState is consumed exactly as sklearn consumes it (one choice, then L uniforms per centre);
-  * `_kmeans_single_lloyd`: E-step, centre update, empty clusters re-seeded with the points farthest from their centres
-    (`_relocate_empty_clusters_dense`), stop on unchanged labels (strict) or `sum_k ||dc_k||^2 <= tol * mean(var(X))`, and one more
-    E-step when the stop was not strict; n_init='auto' -> 1 run for k-means++, max_iter 300, tol 1e-4.
+Which scikit-learn: /root/reference/requirements.txt pins scikit-learn 1.0.2; this image has 1.7.2.  The two differ in what the
+reference's call means, so the class takes `sklearn_compat` (default: the reference's pin; env SCD_SKLEARN_COMPAT overrides):
+  * "1.0.2" (default): n_init defaults to 10 starts on ONE RandomState, the first k-means++ centre is `random_state.randint(n)`,
+    a start replaces the best when `inertia < best * (1 - 1e-6)`.  Restated from the public source; that version is not
+    installed here, so this mode is checked against the oracle's restatement only ("parity unpinned" for the seeding stream);
+  * "1.7.2": n_init 'auto' -> 1 start for k-means++, first centre `random_state.choice(n, p=uniform)`, a start replaces the
+    best when its inertia is smaller and its clustering differs (`_is_same_clustering`).  Pinned against scikit-learn 1.7.2
+    itself: `kmeans_plusplus` picks, the default call's labels and the n_init=10 call's labels (tests/golden/kmeans_sklearn.npz).
+Common to both (sklearn/cluster/_kmeans.py, third-party, not under /root/reference):
+  * `_kmeans_plusplus`: per added centre 2 + floor(ln k) candidates drawn with `uniform(size=L) * pot` -> searchsorted on the
+    cumulative closest distances; the candidate with the smallest new potential wins; the RandomState is consumed as sklearn does;
+  * `_kmeans_single_lloyd` (1.0.2's default `elkan` takes the same decisions in exact arithmetic): E-step, centre update, empty
+    clusters re-seeded with the points farthest from their centres (`_relocate_empty_clusters_dense`), stop on unchanged labels
+    (strict) or `sum_k ||dc_k||^2 <= tol * mean(var(X))`, one more E-step when the stop was not strict; max_iter 300, tol 1e-4.
 sklearn subtracts the column means from a float32 X first, for the accuracy of its float32 GEMM-form distances; distances here are
 decided on float64 values (DESIGN.md "decision semantics"), which are translation invariant, so X is used as it is.
-
-Parity: Lloyd from an explicit `init` array is pinned label-for-label against sklearn 1.7.2 (tests/golden/kmeans_sklearn.npz).
-The seeding cannot be bit-pinned to sklearn's: its potentials are float32 BLAS dot products whose summation order decides
-which row a uniform lands on once in ~1/(N * 1e-7) draws; the algorithm and the random stream are the same.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -23,11 +28,21 @@ from . import ops
 from .kmeans import check_random_state
 
 
+def _same_clustering(a, b, k):
+    """sklearn `_is_same_clustering`: every label of `a` maps to ONE label of `b` (device tensors, int32)."""
+    pairs = torch.unique(a.long() * k + b.long()).numel()
+    return pairs == torch.unique(a).numel()
+
+
 class KMeans:
     def __init__(self, n_clusters=8, *, init="k-means++", n_init="auto", max_iter=300, tol=1e-4, verbose=0, random_state=None,
-                 copy_x=True, algorithm="lloyd"):
-        if algorithm not in ("lloyd", "auto", "full"):
-            raise ValueError("only algorithm='lloyd' is implemented on the HIP path (got %r)" % (algorithm,))
+                 copy_x=True, algorithm="lloyd", sklearn_compat=None):
+        compat = sklearn_compat or os.environ.get("SCD_SKLEARN_COMPAT", "1.0.2")
+        if compat not in ("1.0.2", "1.7.2"):
+            raise ValueError("sklearn_compat must be '1.0.2' (the reference's pin) or '1.7.2' (got %r)" % (compat,))
+        self.sklearn_compat = compat
+        if algorithm not in ("lloyd", "auto", "full", "elkan"):
+            raise ValueError("algorithm must be 'lloyd' / 'full' / 'auto' / 'elkan' (all run the Lloyd kernels; got %r)" % (algorithm,))
         self.n_clusters = n_clusters
         self.init = init
         self.n_init = n_init
@@ -43,8 +58,11 @@ class KMeans:
         x = data.x
         n, k = x.shape[0], self.n_clusters
         n_local_trials = 2 + int(np.log(k))
-        p = np.ones(n, dtype=np.float32)
-        first = int(rs.choice(n, p=p / p.sum()))
+        if self.sklearn_compat == "1.0.2":
+            first = int(rs.randint(n))
+        else:
+            p = np.ones(n, dtype=np.float32)
+            first = int(rs.choice(n, p=p / p.sum()))
         centers = torch.empty((k, x.shape[1]), dtype=torch.float32, device=x.device)
         centers[0] = x[first]
         d2 = torch.full((n,), float("inf"), dtype=torch.float32, device=x.device)
@@ -126,7 +144,7 @@ class KMeans:
         explicit = not isinstance(self.init, str)
         n_init = self.n_init
         if n_init == "auto":
-            n_init = 1 if (explicit or self.init == "k-means++") else 10
+            n_init = 10 if self.sklearn_compat == "1.0.2" else (1 if (explicit or self.init == "k-means++") else 10)
         if explicit:
             n_init = 1
         best = None
@@ -141,7 +159,13 @@ class KMeans:
             else:
                 raise ValueError("init must be 'k-means++', 'random' or an array")
             labels, inertia, centers, n_iter = self._lloyd(data, centers, tol_abs)
-            if best is None or inertia < best[1]:
+            if best is None:
+                better = True
+            elif self.sklearn_compat == "1.0.2":
+                better = inertia < best[1] * (1 - 1e-6)
+            else:
+                better = inertia < best[1] and not _same_clustering(labels, best[0], self.n_clusters)
+            if better:
                 best = (labels, inertia, centers, n_iter)
         self.labels_ = best[0].cpu().numpy().astype(np.int32)
         self.inertia_ = best[1]

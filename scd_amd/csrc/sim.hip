@@ -306,237 +306,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) sim_topk_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Four-wave variant (SCD_SIM_W4=1; same speed as the eight-wave kernel today): one wave per SIMD with the whole 512-register file.  Block = 256 images, wave w owns
-// 64 of them (two 32-image sets): the 2 x 32 image fragments (d <= 512) live in 256 AGPRs and are read by the MFMAs
-// directly as the B operand (v_mfma ... v[A], a[B], v[C]: asm, because left to itself hipcc treats AGPRs as spill space
-// and copies four registers in front of every MFMA), the 2 x 4 accumulators (64 images x 128 names) in 128 VGPRs.
-// Every A fragment read from LDS now feeds two MFMAs (half the LDS traffic of the eight-wave kernel), there are four
-// waves at the barrier instead of eight, and the W^T sub-tiles [128 names][64 d] stream through an 8-slot LDS-DMA ring
-// (a whole tile ahead).  Hazards the compiler cannot see (the MFMAs are asm): accumulators are (re)started by MFMAs with
-// C = 0, never by VALU writes; the tile epilogue reads them behind s_nop padding; A fragments come from asm ds_reads
-// with counted waits that carry the fragments as operands.
-template <bool SOFTMAX>
-__global__ void __launch_bounds__(256) sim_topk_w4_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
-                                                          long long n, int d, long long v, float scale,
-                                                          float* __restrict__ cand_val, int* __restrict__ cand_idx,
-                                                          float* __restrict__ stats, int xmode) {
-    constexpr int NS = 8;                                             // ring slots of 16 KB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int r = lane & 31, hh = lane >> 5;
-    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-
-    half8 bf[2][32];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
-        const half_t* frow = F + (img < n ? img : n - 1) * d + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            if (16 * s < d) {
-                bf[q][s] = *(const half8*)(frow + 16 * s);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bf[q][s][e] = (half_t)0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int s = 0; s < 32; ++s) asm volatile("" : "+a"(bf[q][s]));       // resident in AGPRs from here on
-
-    float lv0[TOPM], lv1[TOPM];
-    int li0[TOPM], li1[TOPM];
-    float sm_m0 = -INFINITY, sm_m1 = -INFINITY, sm_z0 = 0.f, sm_z1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < TOPM; ++j) {
-        lv0[j] = -INFINITY; lv1[j] = -INFINITY;
-        li0[j] = -1; li1[j] = -1;
-    }
-
-    const int nd = d >> 6;
-    const int ntiles = (int)((v + 127) / 128);
-    const int steps = ntiles * nd;
-    // ring fill: wave w stages rows 32w .. 32w+31 of a sub-tile, 4 instructions x 8 rows; lane -> (row lane/8, chunk lane%8)
-    unsigned voff[4], voff_last[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int rowl = wave * 32 + p * 8 + (lane >> 3);
-        const int col = ((lane & 7) ^ ((rowl >> 1) & 7)) << 3;
-        long long vr = (long long)(ntiles - 1) * 128 + rowl;
-        vr = vr < v ? vr : v - 1;                            // padded names re-read the last row; masked in the epilogue
-        voff[p] = (unsigned)((rowl * d + col) * 2);
-        voff_last[p] = (unsigned)(((int)(vr - (long long)(ntiles - 1) * 128) * d + col) * 2);
-    }
-    int itile = 0, idc = 0, istep = 0;                       // sub-step being issued
-    auto issue_one = [&](int p) {
-        if (istep >= steps) return;
-        const half_t* base = Wt + (size_t)itile * 128 * d + idc * 64;      // wave-uniform: scalar arithmetic
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     ::"s"(sbase + (istep & (NS - 1)) * 16384 + wave * 4096 + p * 1024), "v"(itile == ntiles - 1 ? voff_last[p] : voff[p]), "s"(base) : "memory");
-    };
-    auto issue_advance = [&]() {
-        ++istep;
-        if (++idc == nd) { idc = 0; ++itile; }
-    };
-#pragma unroll 1
-    for (int pre = 0; pre < NS - 1; ++pre) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) issue_one(p);
-        issue_advance();
-    }
-
-    f32x16 acc[2][4];
-    const unsigned fbase = sbase + r * 128;
-    const int fsw = (r >> 1) & 7;
-    // fragment (cb, k16) of the slot: row cb*32 + r, 16-B chunk (2 k16 + hh) ^ ((row >> 1) & 7)
-#define SW_RD(DST, SL, CB, K16) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((SL) + ((((2 * (K16) + hh) ^ fsw)) << 4)), "n"((CB) * 4096))
-#define SW_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR[0]), "+v"(FR[1]), "+v"(FR[2]), "+v"(FR[3]))
-#define SW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
-#define SW_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
-    int s = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-#pragma unroll
-        for (int dcc = 0; dcc < 8; ++dcc) {
-            if (dcc < nd) {
-                // my part of sub-step s has landed: at most min(NS - 2, steps - 1 - s) younger sub-steps (4 fills each) fly
-                const int younger = steps - 1 - s;
-                if (younger >= NS - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * 4) : "memory");
-                else if (younger >= 3) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-                else if (younger == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                 // everyone's has; the slot of sub-step s-1 is free
-                asm volatile("" ::: "memory");
-                const unsigned sl = fbase + (s & (NS - 1)) * 16384;
-                half8 fr[3][4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) SW_RD(fr[0][cb], sl, cb, 0);
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) SW_RD(fr[1][cb], sl, cb, 1);
-#pragma unroll
-                for (int k16 = 0; k16 < 4; ++k16) {
-                    if (k16 + 2 < 4) {
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) SW_RD(fr[(k16 + 2) % 3][cb], sl, cb, k16 + 2);
-                        SW_WAIT(8, fr[k16 % 3]);
-                    } else if (k16 + 1 < 4) {
-                        SW_WAIT(4, fr[k16 % 3]);
-                    } else {
-                        SW_WAIT(0, fr[k16 % 3]);
-                    }
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            if ((xmode & 2) && !(dcc == 0 && k16 == 0)) continue;      // xmode 2: ablation without the MFMAs
-                            if (dcc == 0 && k16 == 0) SW_MFMA0(acc[q][cb], fr[k16 % 3][cb], bf[q][dcc * 4 + k16]);
-                            else SW_MFMA(acc[q][cb], fr[k16 % 3][cb], bf[q][dcc * 4 + k16]);
-                        }
-                    issue_one(k16);                           // one ring-fill instruction per k16 group (sub-step s+NS-1)
-                }
-                issue_advance();
-                ++s;
-            }
-        }
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
-                                             "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]));   // MFMA -> VALU read
-        {
-            // tile epilogue on UNSCALED dot products (scale > 0 is applied when the lists are written): one max3 tree per
-            // 32-name block decides whether any of its 16 values can enter the list; only the last tile has padded names.
-            const long long vbase = (long long)tile * 128 + 4 * hh;
-            const bool last = tile == ntiles - 1;
-            // (written out per image set: a q loop is "too large to unroll" for hipcc and the lists would go to scratch)
-            // The admission threshold is shared by the two lanes that serve one image (r and r+32 see different names):
-            // a value has to beat the larger of the two lists' 8th entries.  Everything rejected is <= that threshold, which
-            // only grows and ends as max(list_A[7], list_B[7]) - exactly the bound sim_refine_kernel certifies against - and
-            // the number of list insertions (the expensive, divergent part) drops by almost half.
-            auto epi = [&](float (&lvq)[TOPM], int (&liq)[TOPM], float& smm, float& smz, const f32x16 (&accq)[4]) {
-                float thr = lvq[TOPM - 1];
-                {
-                    const unsigned u = __float_as_uint(thr);
-                    const auto pr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                    thr = fmaxf(thr, __uint_as_float((lane & 32) ? pr[0] : pr[1]));
-                }
-                float qv = -INFINITY;
-                int qi = -1;
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    f32x16 a = accq[cb];
-                    if (last) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (vbase + cb * 32 + (i & 3) + 8 * (i >> 2) >= v) a[i] = -INFINITY;
-                    }
-                    // candidates are parked in a one-entry per-lane queue; the wave-wide list insertion runs when some lane
-                    // needs its slot again and once per tile (see sim_topk_kernel)
-                    float bm = fmaxf(fmaxf(a[0], a[1]), a[2]);
-#pragma unroll
-                    for (int i = 3; i < 15; i += 2) bm = fmaxf(fmaxf(bm, a[i]), a[i + 1]);
-                    bm = fmaxf(bm, a[15]);
-                    if (__any(bm > thr)) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float val = a[i];
-                            if (__any(val > thr)) {
-                                if (__any(val > thr && qi >= 0)) {
-                                    if (qi >= 0) topm_insert(lvq, liq, qv, qi);
-                                    qi = -1;
-                                    thr = fmaxf(thr, lvq[TOPM - 1]);
-                                }
-                                if (val > thr) {
-                                    qv = val;
-                                    qi = (int)(vbase + cb * 32 + (i & 3) + 8 * (i >> 2));
-                                }
-                            }
-                        }
-                    }
-                    if (SOFTMAX) {
-                        if (bm > -INFINITY) {
-                            const float mn = fmaxf(smm, bm);
-                            float z = smz * __expf((smm - mn) * scale);
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) z += __expf((a[i] - mn) * scale);
-                            smz = z;
-                            smm = mn;
-                        }
-                    }
-                }
-                if (__any(qi >= 0)) {
-                    if (qi >= 0) topm_insert(lvq, liq, qv, qi);
-                }
-            };
-            if (!(xmode & 1) || last) {          // xmode 1: timing ablation without the tile epilogue (results are wrong)
-                epi(lv0, li0, sm_m0, sm_z0, acc[0]);
-                epi(lv1, li1, sm_m1, sm_z1, acc[1]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    auto emit = [&](int q, const float (&lvq)[TOPM], const int (&liq)[TOPM], float smm, float smz) {
-        const long long img = (long long)blockIdx.x * 256 + wave * 64 + q * 32 + r;
-        if (img < n) {
-            float* cv = cand_val + (img * 2 + hh) * TOPM;
-            int* ci = cand_idx + (img * 2 + hh) * TOPM;
-#pragma unroll
-            for (int j = 0; j < TOPM; ++j) {
-                cv[j] = lvq[j] * scale;
-                ci[j] = liq[j];
-            }
-            if (SOFTMAX) {
-                stats[(img * 2 + hh) * 2] = smm * scale;
-                stats[(img * 2 + hh) * 2 + 1] = smz;
-            }
-        }
-    };
-    emit(0, lv0, li0, sm_m0, sm_z0);
-    emit(1, lv1, li1, sm_m1, sm_z1);
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Row-block kernel (d == 512, the CLIP embedding width; default).  Same outputs as the kernels above, different schedule:
 //   * one wave per SIMD (256 threads, 512 registers); wave w owns 64 images (two 32-image sets) whose 2 x 32 B fragments live
 //     in 256 AGPRs and feed the MFMAs directly;
@@ -853,6 +622,306 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
 #undef RB_MFMA0
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eight-wave row-block kernel (round 3; default at d == 512).  Same unit structure, ring, keys and lists as sim_topk_rb_kernel,
+// but TWO waves per SIMD with 32 images each (128 AGPRs of B fragments + <= 128 VGPRs): the four-wave kernel's lone wave per SIMD
+// has to issue everything itself - 64 MFMAs (8 issue cycles each), ~170-290 vector instructions of epilogue, 32 fragment reads,
+// 8 ring fills (60-100 cycles of issue each) and the waits - in ONE in-order stream per unit, ~4,100-4,700 cycles against 2,048
+// of matrix work (PMC, profiles/r02_pmc_sim_rb.txt: matrix pipe busy 47 %).  With a partner wave on the SIMD the matrix pipe takes
+// the other wave's MFMA while this one sits in a fill, a wait or its epilogue; per wave a unit is 32 MFMAs on ONE accumulator
+// set (two sets alternate between units), 4 ring fills, 16 values per lane:
+//   step  2..9   two values into the (largest, second) key pair
+//   step  10     widen the winner; softmax reference maximum
+//   step 11..26  one list entry (max, min on doubles) and one softmax term per step;  step 27: the rare second-key loop
+__device__ __forceinline__ float rb_swap32(float v, int lane) {         // the value held by lane l ^ 32
+    const unsigned u = __float_as_uint(v);
+    const auto p = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((lane & 32) ? p[0] : p[1]);
+}
+#define RB8_EMARGIN 4.2f                   /* sim_refine_kernel certifies against (other half's entry KS) - 3.9 E: keep it below this */
+template <bool SOFTMAX, int TM, int KS, int XM = 0>
+__global__ void __launch_bounds__(512) sim_topk_rb8_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
+                                                           long long v, float scale, float* __restrict__ cand_val,
+                                                           int* __restrict__ cand_idx, float* __restrict__ stats,
+                                                           const unsigned* __restrict__ wmax2_bits) {
+    constexpr int D = 512, UB = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    half8 bf[32];
+    float f2 = 0.f;
+    const long long img = (long long)blockIdx.x * 256 + wave * 32 + r;
+    {
+        // eight fragments at a time (the "memory" clobber keeps the next batch's loads behind the pins): loaded all at once the
+        // 32 fragments need 128 VGPRs on their way to the AGPRs, and the kernel has 128 in all
+        const half_t* frow = F + (img < n ? img : n - 1) * D + 8 * hh;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) bf[s] = *(const half8*)(frow + 16 * s);
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f2 = fmaf((float)bf[s][q], (float)bf[s][q], f2);
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) asm volatile("" : "+a"(bf[s]) : : "memory");   // resident in AGPRs from here on
+        }
+    }
+    // The two lanes of an image (r, r + 32: different names) share what they know: once the OTHER lane's list holds KS + 1 values of
+    // at least t, a value below t - 4 E (E = sim_refine_kernel's bound on |approximate - exact|) cannot be among the image's KS + 1
+    // largest exact values, so it is neither listed nor looked at again.  That lifts a lane's admission threshold from its own TM-th
+    // best to about the image's (KS + 1)-th best and makes the second-key path below 7 x rarer (it stalls the other seven waves at
+    // the unit's barrier whenever one wave takes it).  Everything dropped this way is <= max(list_A[KS], list_B[KS]) - 4 E, which is
+    // what sim_refine_kernel adds to its certificate (argument ks).
+    f2 += rb_swap32(f2, lane);
+    const float e4 = RB8_EMARGIN * 1.5f * ((float)D * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * sqrtf(f2) * sqrtf(__uint_as_float(*wmax2_bits)) * 1.001f + 1e-30f;
+
+    double L[TM];                                              // the lane's TM best (key | name index), descending
+    float thr = -INFINITY;                                     // float view of L[TM-1]
+    float tsh = -INFINITY, te = -INFINITY;                     // (other lane's entry KS) - 4 E; te = max(thr, tsh): what a value must beat
+    float m1, m2, smm = -INFINITY, smz = 0.f, nmc;
+    double tk;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) L[j] = -INFINITY;
+    const float c2 = scale * 1.4426950408889634f;              // exp((a - m) * scale) = exp2((a - m) * c2)
+
+    const int nunits = (int)((v + 31) / 32);
+    // ring fill: wave w stages rows 4w .. 4w+3 of a unit, one 1-KB instruction per row; lane l fetches source chunk l ^ (row & 15)
+    // = (l ^ (4w & 12)) ^ p for row 4w + p: ONE per-lane register, the row is wave-uniform (four per-row offset registers, and the
+    // kernel spills: a scratch reload in the loop is a vmcnt(0) that drains the ring)
+    const unsigned bsw = (unsigned)((lane ^ ((4 * wave) & 12)) << 4);
+    const half_t* fbase = Wt;
+    unsigned fm0 = 0;
+    int frows = 32;                                            // valid rows of the unit being filled (< 32 only for the last one)
+    auto fill_unit = [&](int unit) {
+        fbase = Wt + (size_t)unit * 32 * D;
+        fm0 = sbase + (unit & 3) * UB + 4 * wave * 1024;
+        const long long left = v - (long long)unit * 32;
+        frows = left < 32 ? (int)left : 32;
+    };
+    auto fill = [&](int p) {
+        int srow = 4 * wave + p;                                                // wave-uniform
+        srow = srow < frows ? srow : frows - 1;                                 // padded names re-read row v-1; masked in the epilogue
+        const unsigned off = (bsw ^ (unsigned)(p << 4)) + (unsigned)srow * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(fm0 + p * 1024), "v"(off), "s"(fbase) : "memory");
+    };
+    unsigned fa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = sbase + (unsigned)(r * 1024 + ((32 * j) ^ (16 * (hh ^ (r & 15)))));
+
+#define RB_RD(DST, J, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[J]), "n"(IMM))
+#define RB_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
+#define RB_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define RB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
+
+    auto key = [](float a, int i) { return __uint_as_float((__float_as_uint(a) & 0xfffffff0u) | (unsigned)i); };
+    auto name_of = [&](int unit, int i) { return unit * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh; };
+    auto p_top2 = [&](const f32x16& a, int i) {
+        const float k = key(a[i], i);
+        if (i == 0) {
+            m1 = k;
+            m2 = -INFINITY;
+        } else {
+            const float n1 = rb_max(m1, k);
+            m2 = rb_med3(m1, m2, k);
+            m1 = n1;
+        }
+    };
+    auto widen = [&](float k, int unit) {
+        const int i = (int)(__float_as_uint(k) & 15u);
+        return __hiloint2double(__double2hiint((double)k), name_of(unit, i));
+    };
+    auto p_ins = [&](int j) {
+        const double hi = rb_max64(L[j], tk);
+        if (j + 1 < TM) tk = rb_min64(L[j], tk);
+        L[j] = hi;
+        if (j + 1 == TM) {
+            thr = (float)L[TM - 1];
+            te = rb_max(thr, tsh);
+        }
+    };
+    auto p_ins_all = [&]() {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) p_ins(j);
+    };
+    auto p_share = [&]() {
+        tsh = rb_swap32((float)L[KS], lane) - e4;
+        te = rb_max(thr, tsh);
+    };
+    auto p_rest = [&](const f32x16& a, int unit) {             // rare: the lane's second key beats what it has to beat as well
+        if (!__any(m2 > te)) return;
+        tk = m2 > te ? widen(m2, unit) : (double)-INFINITY;
+        p_ins_all();
+        int cnt = 0;                                           // a third one?  (keys, as everywhere: the key bits are part of E)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cnt += key(a[i], i) > te ? 1 : 0;
+        if (!__any(cnt > 2)) return;
+        float bound = m2;
+        for (;;) {
+            float c = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float kk = key(a[i], i);
+                c = (kk < bound && kk > c) ? kk : c;
+            }
+            if (!__any(c > te)) break;
+            if (c > te) {
+                tk = widen(c, unit);
+                p_ins_all();
+            }
+            bound = c;
+        }
+    };
+    auto p_sm_begin = [&]() {
+        const float mref = rb_max(smm, m1);
+        smz = smz * __builtin_amdgcn_exp2f((smm - mref) * c2);
+        smm = mref;
+        nmc = -mref * c2;
+    };
+    auto p_sm_add = [&](const f32x16& a, int i) { smz += __builtin_amdgcn_exp2f(fmaf(a[i], c2, nmc)); };
+
+    f32x16 acc[2];
+    f32x4 acc16[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    half8 fr[4];
+    auto body = [&](auto has_prev, auto parity, int u) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool EPI = decltype(has_prev)::value && !(XM & 1);
+        // my fills of unit u+1 have landed (those of u+2 may fly); after the barrier everybody's have, and slot (u-1)&3 is free
+        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = u + 1 < nunits;
+        const bool fills = u + 3 < nunits;
+        if (fills) fill_unit(u + 3);
+        static_for<0, 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s == 29) {
+                const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[j] += delta;
+            }
+            if constexpr (s < 29) RB_RD(fr[(s + 3) & 3], (s + 3) & 7, ((s + 3) >> 3) * 256);
+            else if (more) RB_RD(fr[(s + 3) & 3], (s + 3 - 32) & 7, 0);
+            if (s < 29 || more) RB_WAIT(2, fr[(s + 1) & 3]);
+            else if (s == 29) RB_WAIT(1, fr[(s + 1) & 3]);
+            else if (s == 30) RB_WAIT(0, fr[(s + 1) & 3]);
+            if constexpr (XM & 256) {                              // timing only: the same stream on 16x16x32 MFMAs (two per fragment)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc16[2 * (s & 1)]) : "v"(fr[s & 3]), "a"(bf[s]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc16[2 * (s & 1) + 1]) : "v"(fr[s & 3]), "a"(bf[s ^ 1]));
+            } else if constexpr (!(XM & 4)) {
+                if constexpr (XM & 16) __builtin_amdgcn_s_setprio(1);
+                if (s == 0) RB_MFMA0(acc[P], fr[s & 3], bf[s]);
+                else RB_MFMA(acc[P], fr[s & 3], bf[s]);
+                if constexpr (XM & 16) __builtin_amdgcn_s_setprio(0);
+            }
+            if constexpr (!(XM & 2))
+                if ((s & 7) == 7 && fills) fill(s >> 3);
+            if constexpr (EPI) {
+                if constexpr (s >= 2 && s < 10) {
+                    p_top2(acc[1 - P], 2 * (s - 2));
+                    p_top2(acc[1 - P], 2 * (s - 2) + 1);
+                } else if constexpr (s == 10) {
+                    if constexpr (!(XM & 32)) tk = widen(m1, u - 1);
+                    if (SOFTMAX) p_sm_begin();
+                } else if constexpr (s >= 11 && s < 27) {
+                    if constexpr (s - 11 < TM && !(XM & 32)) p_ins(s - 11);
+                    if (SOFTMAX) p_sm_add(acc[1 - P], s - 11);
+                } else if constexpr (s == 27) {
+                    if constexpr (!(XM & 96)) p_rest(acc[1 - P], u - 1);
+                } else if constexpr (s == 28 && P == 0) {
+                    if constexpr (!(XM & 128)) p_share();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // prologue: units 0..2 in flight, the first three fragments of unit 0
+#pragma unroll 1
+    for (int pre = 0; pre < 3; ++pre)
+        if (pre < nunits) {
+            fill_unit(pre);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fill(p);
+        }
+    if (nunits > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // unit 0 has landed
+    else if (nunits > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RB_RD(fr[0], 0, 0);
+    RB_RD(fr[1], 1, 0);
+    RB_RD(fr[2], 2, 0);
+    RB_WAIT(2, fr[0]);
+    if constexpr (XM & (4 | 256)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = acc[1][i] = 0.f;
+    }
+
+    body(no{}, P0{}, 0);
+    int u = 1;
+    for (; u + 1 < nunits; u += 2) {
+        body(yes{}, P1{}, u);
+        body(yes{}, P0{}, u + 1);
+    }
+    const bool odd_tail = u < nunits;
+    if (odd_tail) body(yes{}, P1{}, u);
+    // epilogue of the last unit (the only one with padded names), not hidden behind anything; in place on its accumulator set
+    auto tail = [&](auto parity) {
+        constexpr int P = decltype(parity)::value;
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[P]));                  // MFMA -> VALU read
+        const int lu = nunits - 1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((long long)name_of(lu, i) >= v) acc[P][i] = RB_NEG;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p_top2(acc[P], i);
+        tk = widen(m1, lu);
+        p_ins_all();
+        p_rest(acc[P], lu);
+        if (SOFTMAX) {
+            p_sm_begin();
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((long long)name_of(lu, i) < v) smz += __builtin_amdgcn_exp2f(fmaf(acc[P][i], c2, nmc));
+        }
+    };
+    if (odd_tail) tail(P1{});
+    else tail(P0{});
+    if constexpr (XM & 256) {
+        asm volatile("s_nop 15" : "+v"(acc16[0]), "+v"(acc16[1]), "+v"(acc16[2]), "+v"(acc16[3]));
+        smz += acc16[0][0] + acc16[1][0] + acc16[2][0] + acc16[3][0];
+    }
+    if (img < n) {
+        float* cv = cand_val + (img * 2 + hh) * TM;
+        int* ci = cand_idx + (img * 2 + hh) * TM;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int idx = __double2loint(L[j]);
+            const bool ok = L[j] > -INFINITY && (long long)idx < v;
+            cv[j] = ok ? (float)L[j] * scale : -INFINITY;
+            ci[j] = ok ? idx : -1;
+        }
+        if (SOFTMAX) {
+            stats[(img * 2 + hh) * 2] = smm * scale;
+            stats[(img * 2 + hh) * 2 + 1] = smz;
+        }
+    }
+#undef RB_RD
+#undef RB_WAIT
+#undef RB_MFMA
+#undef RB_MFMA0
+}
+
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
 __global__ void __launch_bounds__(256) wmax_kernel(const half_t* __restrict__ Wt, long long v, int d, unsigned* out_bits) {
     __shared__ float red[4];
@@ -896,7 +965,7 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
                                                          long long n, int d, long long v, float scale, int k,
                                                          const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                          const float* __restrict__ stats, SimHdr* hdr, int* fb_list,
-                                                         long long* idx_out, float* val_out) {
+                                                         long long* idx_out, float* val_out, int ks) {
     const int lane = threadIdx.x & 63;
     const long long img = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (img >= n) return;
@@ -980,6 +1049,8 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
     float astar = -INFINITY;
     if (i0 >= 0) astar = fmaxf(astar, a0);
     if (i1 >= 0) astar = fmaxf(astar, a1);
+    // sim_topk_rb8_kernel also drops what lies 4.2 E below the other half list's entry ks (ks < 0: the other kernels do not)
+    if (ks >= 0) astar = fmaxf(astar, fmaxf(__shfl(mya, ks, 64), __shfl(mya, TM + ks, 64)) - 3.9f * E);
     // exact value of the k-th ranked candidate
     double kth = -INFINITY;
     {
@@ -1083,18 +1154,27 @@ __global__ void __launch_bounds__(256) sim_exact_kernel(const half_t* __restrict
     }
 }
 
-// The first EX_ROWS fallback rows, spread over the whole chip (a handful of rows is the normal case, and one block per row - the
-// kernel above - keeps a single CU busy for 1.8 ms per row at V = 21,000): block b takes names [b V/256, (b+1) V/256) of EVERY such
-// row, one wave per name with the refine pass's dot64 (same lane split, same bits), a wave-uniform top-TOPM list per wave, merged per
-// block into part[row][block]; sim_exact_merge_kernel (one block per row) then selects the row's top k from the 256 x TOPM
-// candidates (ties to the lower name index) and, for softmax, combines the (max, sum) pairs.  Rows past EX_ROWS keep the
-// one-block-per-row kernel (then at least EX_ROWS CUs are busy).
-constexpr int EX_ROWS = 32, EX_BLOCKS = 256;
+// Uncertified rows, spread over the whole chip (a handful of rows is the normal case; the one-block-per-row kernel above keeps a
+// single CU busy for 1.8 ms per row at V = 21,000, and round 2's one-wave-per-name version of this kernel paid a 1-KB gather and a
+// 64-lane float64 butterfly per (row, name): 75 us for two rows, 1.3 ms for twenty).  Block c takes names [128 c, 128 c + 128) of
+// EVERY such row: the chunk of W^T is staged ONCE in LDS (rows padded to 1040 B: conflict-free 16-B reads at one name per lane), two
+// rows at a time meet it - thread t: name t & 127 of row slot t >> 7 (wave-uniform: the row's fp16 copy in LDS is a broadcast read),
+// a 512-term float64 dot product per thread, no cross-lane reduction - and the chunk's TOPM best per row are found by RANK: every
+// thread counts the values of its row slot that order before its own ((value desc, name asc); 128 broadcast LDS reads) and the
+// threads of rank < TOPM write part[row][chunk].  sim_exact_merge_kernel (one block per row) then selects the row's top k from the
+// chunks' lists and, for softmax, combines the (max, sum) pairs in chunk order.  Rows past the cap keep the one-block-per-row kernel.
+constexpr int EXC = 128, EX_LDW = 1040;
+constexpr int EX_LDS = EXC * EX_LDW + 2 * 1024 + 2 * EXC * 8 + 2 * 4 * 16;
 struct ExPart {
     double val[TOPM];
     double m, z;
     int idx[TOPM];
 };
+static inline int ex_nchunks(long long v) { return (int)((v + EXC - 1) / EXC); }
+static inline int ex_rows_cap(long long v) {                     // rows the chunk kernels serve: part[] stays <= 64 MB
+    long long r = (64ll << 20) / (long long)sizeof(ExPart) / ex_nchunks(v);
+    return (int)(r < 4 ? 4 : (r > 256 ? 256 : r));
+}
 __device__ __forceinline__ void ex_insert(double (&lv)[TOPM], int (&li)[TOPM], double s, int vi) {
     // candidates arrive in ascending name order or are merged with an explicit index test: (s, -vi) lexicographic
     if (s > lv[TOPM - 1] || (s == lv[TOPM - 1] && li[TOPM - 1] >= 0 && vi < li[TOPM - 1])) {
@@ -1109,91 +1189,131 @@ __device__ __forceinline__ void ex_insert(double (&lv)[TOPM], int (&li)[TOPM], d
     }
 }
 template <bool SOFTMAX>
-__global__ void __launch_bounds__(256) sim_exact_spread_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, int d,
-                                                               long long v, float scale, const SimHdr* hdr,
-                                                               const int* __restrict__ fb_list, ExPart* __restrict__ part) {
-    __shared__ double wv[4][TOPM];
-    __shared__ int wi[4][TOPM];
-    __shared__ double wm[4], wz[4];
-    const int cnt = hdr->fb_cnt < EX_ROWS ? hdr->fb_cnt : EX_ROWS;
+__global__ void __launch_bounds__(256) sim_exact_chunk_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, int d,
+                                                              long long v, float scale, const SimHdr* hdr,
+                                                              const int* __restrict__ fb_list, ExPart* __restrict__ part,
+                                                              int rows_cap, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cnt = hdr->fb_cnt < rows_cap ? hdr->fb_cnt : rows_cap;
     if (cnt <= 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long chunk = (v + gridDim.x - 1) / gridDim.x;
-    const long long v0 = (long long)blockIdx.x * chunk, v1 = v0 + chunk < v ? v0 + chunk : v;
-    for (int fb = 0; fb < cnt; ++fb) {
-        const half_t* f = F + (long long)fb_list[fb] * d;
-        double lv[TOPM];
-        int li[TOPM];
+    char* wl = smem;                                              // [EXC][EX_LDW] bytes
+    char* fl = smem + EXC * EX_LDW;                               // [2][1024] bytes
+    double* vals = (double*)(fl + 2 * 1024);                      // [2][EXC]
+    double* red = vals + 2 * EXC;                                 // [2 slots][2 waves][m, z]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const long long v0 = (long long)chunk * EXC;
+    const int nv = v - v0 < EXC ? (int)(v - v0) : EXC;
+    const int pr = d >> 3;                                        // 16-B pieces per row
+    for (int p = tid; p < nv * pr; p += 256) {
+        const int row = p / pr, c = p - row * pr;
+        *(half8*)(wl + row * EX_LDW + c * 16) = *(const half8*)(Wt + (v0 + row) * d + c * 8);
+    }
+    const int slot = tid >> 7, name = tid & 127;
+    for (int fb0 = 0; fb0 < cnt; fb0 += 2) {
+        __syncthreads();                                          // W staged / the previous pair is done with fl, vals, red
+        for (int p = tid; p < 2 * pr; p += 256) {
+            const int rr = p / pr, c = p - rr * pr;
+            if (fb0 + rr < cnt) *(half8*)(fl + rr * 1024 + c * 16) = *(const half8*)(F + (long long)fb_list[fb0 + rr] * d + c * 8);
+        }
+        __syncthreads();
+        const int fb = fb0 + slot;                                // wave-uniform
+        const bool active = fb < cnt && name < nv;
+        double sv = -INFINITY;
+        if (active) {
+            double acc = 0.0;
+            for (int j = 0; j < pr; ++j) {
+                const half8 a = *(const half8*)(fl + slot * 1024 + j * 16);
+                const half8 w8 = *(const half8*)(wl + name * EX_LDW + j * 16);
 #pragma unroll
-        for (int j = 0; j < TOPM; ++j) { lv[j] = -INFINITY; li[j] = -1; }
+                for (int q = 0; q < 8; ++q) acc = fma((double)(float)a[q], (double)(float)w8[q], acc);
+            }
+            sv = acc * (double)scale;
+        }
+        vals[slot * EXC + name] = sv;
+        ExPart* o = part + (size_t)(fb < cnt ? fb : 0) * nchunks + chunk;
+        if (fb < cnt && name < TOPM) { o->val[name] = -INFINITY; o->idx[name] = -1; }       // ranks nobody takes (NaN, short chunk)
         double m = -INFINITY, z = 0.0;
-        for (long long vi = v0 + wave; vi < v1; vi += 4) {
-            const double s = dot64(f, Wt + vi * d, d, lane) * (double)scale;
-            if (SOFTMAX) {
-                const double mn = s > m ? s : m;
-                z = z * exp(m - mn) + exp(s - mn);
-                m = mn;
+        if (SOFTMAX && fb < cnt) {                               // (max, sum) of the chunk: wave butterfly, then the slot's two waves
+            m = sv;                                               // NaN never becomes the maximum; it does poison the sum, as exp() would
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double om = __shfl_xor(m, off, 64);
+                m = om > m ? om : m;
             }
-            if (s > lv[TOPM - 1]) ex_insert(lv, li, s, (int)vi);      // NaN never enters
+            if (lane == 0) red[(slot * 2 + (wave & 1)) * 2] = m;
         }
         __syncthreads();
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < TOPM; ++j) { wv[wave][j] = lv[j]; wi[wave][j] = li[j]; }
-            wm[wave] = m;
-            wz[wave] = z;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double bv[TOPM];
-            int bi[TOPM];
-#pragma unroll
-            for (int j = 0; j < TOPM; ++j) { bv[j] = -INFINITY; bi[j] = -1; }
-            for (int w = 0; w < 4; ++w)
-                for (int j = 0; j < TOPM; ++j)
-                    if (wi[w][j] >= 0) ex_insert(bv, bi, wv[w][j], wi[w][j]);
-            double mm = -INFINITY, zz = 0.0;
+        if (fb < cnt) {
             if (SOFTMAX) {
-                for (int w = 0; w < 4; ++w) mm = wm[w] > mm ? wm[w] : mm;
-                for (int w = 0; w < 4; ++w)
-                    if (wz[w] > 0.0) zz += wz[w] * exp(wm[w] - mm);
-            }
-            ExPart* o = part + (size_t)fb * EX_BLOCKS + blockIdx.x;
+                const double m0 = red[(slot * 2) * 2], m1 = red[(slot * 2 + 1) * 2];
+                m = m1 > m0 ? m1 : m0;
+                z = active ? exp(sv - m) : 0.0;
+                if (m == -INFINITY) z = 0.0;
 #pragma unroll
-            for (int j = 0; j < TOPM; ++j) { o->val[j] = bv[j]; o->idx[j] = bi[j]; }
-            o->m = mm;
-            o->z = zz;
+                for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+                if (lane == 0) red[(slot * 2 + (wave & 1)) * 2 + 1] = z;
+            }
+            int rank = 1 << 20;
+            if (active && sv == sv) {                             // NaN never enters
+                rank = 0;
+                for (int o2 = 0; o2 < nv; ++o2) {
+                    const double ov = vals[slot * EXC + o2];
+                    rank += (ov > sv || (ov == sv && o2 < name)) ? 1 : 0;
+                }
+            }
+            if (rank < TOPM) { o->val[rank] = sv; o->idx[rank] = (int)(v0 + name); }
+        }
+        if (SOFTMAX) {
+            __syncthreads();
+            if (fb < cnt && name == 0) {
+                o->m = m;
+                o->z = red[(slot * 2) * 2 + 1] + red[(slot * 2 + 1) * 2 + 1];
+            }
         }
     }
 }
 template <bool SOFTMAX>
 __global__ void __launch_bounds__(256) sim_exact_merge_kernel(const SimHdr* hdr, const int* __restrict__ fb_list, const ExPart* __restrict__ part,
-                                                              int k, long long* idx_out, float* val_out) {
+                                                              int k, long long* idx_out, float* val_out, int rows_cap, int nchunks) {
     __shared__ double rv[4];
     __shared__ int ri[4], rt[4];
     __shared__ double sm[256], sz[256];
-    const int cnt = hdr->fb_cnt < EX_ROWS ? hdr->fb_cnt : EX_ROWS;
+    const int cnt = hdr->fb_cnt < rows_cap ? hdr->fb_cnt : rows_cap;
     const int fb = blockIdx.x;
     if (fb >= cnt) return;
     const long long img = fb_list[fb];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const ExPart* pp = part + (size_t)fb * EX_BLOCKS + t;      // EX_BLOCKS == blockDim.x
     double cv[TOPM];
     int ci[TOPM];
 #pragma unroll
-    for (int j = 0; j < TOPM; ++j) { cv[j] = pp->val[j]; ci[j] = pp->idx[j]; }
+    for (int j = 0; j < TOPM; ++j) { cv[j] = -INFINITY; ci[j] = -1; }
+    double tm = -INFINITY, tz = 0.0;
+    for (int c = t; c < nchunks; c += 256) {                    // chunks in ascending order per thread
+        const ExPart* pp = part + (size_t)fb * nchunks + c;
+#pragma unroll
+        for (int j = 0; j < TOPM; ++j)
+            if (pp->idx[j] >= 0) ex_insert(cv, ci, pp->val[j], pp->idx[j]);
+        if (SOFTMAX) {
+            const double pm = pp->m, pz = pp->z;
+            const double mn = pm > tm ? pm : tm;
+            if (mn > -INFINITY) tz = (tm > -INFINITY ? tz * exp(tm - mn) : 0.0) + (pm > -INFINITY ? pz * exp(pm - mn) : 0.0);
+            if (pz != pz) tz = pz;                               // a NaN logit poisons the sum
+            tm = mn;
+        }
+    }
     double mm = 0.0, zz = 1.0;
     if (SOFTMAX) {
-        sm[t] = pp->m;
-        sz[t] = pp->z;
+        sm[t] = tm;
+        sz[t] = tz;
         __syncthreads();
-        if (t == 0) {                                   // fixed order: blocks ascending
-            double a = -INFINITY, b = 0.0;
-            for (int q = 0; q < 256; ++q) a = sm[q] > a ? sm[q] : a;
+        if (t == 0) {                                   // fixed order: threads ascending
+            double a2 = -INFINITY, b2 = 0.0;
+            for (int q = 0; q < 256; ++q) a2 = sm[q] > a2 ? sm[q] : a2;
             for (int q = 0; q < 256; ++q)
-                if (sz[q] > 0.0) b += sz[q] * exp(sm[q] - a);
-            sm[0] = a;
-            sz[0] = b;
+                if (sz[q] > 0.0 || sz[q] != sz[q]) b2 += sz[q] * exp(sm[q] - a2);
+            sm[0] = a2;
+            sz[0] = b2;
         }
         __syncthreads();
         mm = sm[0];
@@ -1230,17 +1350,20 @@ __global__ void __launch_bounds__(256) sim_exact_merge_kernel(const SimHdr* hdr,
     }
 }
 template <bool SOFTMAX>
-static void sim_exact_launch(const half_t* f, const half_t* wt, int d, long long v, float scale, int k, const SimHdr* hdr, const int* fb,
-                             ExPart* part, long long* idx_out, float* val_out, hipStream_t st) {
-    sim_exact_spread_kernel<SOFTMAX><<<EX_BLOCKS, 256, 0, st>>>(f, wt, d, v, scale, hdr, fb, part);
-    sim_exact_merge_kernel<SOFTMAX><<<EX_ROWS, 256, 0, st>>>(hdr, fb, part, k, idx_out, val_out);
-    sim_exact_kernel<SOFTMAX><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, idx_out, val_out, EX_ROWS);
+static int sim_exact_launch(const half_t* f, const half_t* wt, int d, long long v, float scale, int k, const SimHdr* hdr, const int* fb,
+                            ExPart* part, long long* idx_out, float* val_out, hipStream_t st) {
+    const int nch = ex_nchunks(v), cap = ex_rows_cap(v);
+    { const int rc_ = scd_set_max_lds((const void*)sim_exact_chunk_kernel<SOFTMAX>, EX_LDS); if (rc_) return rc_; }
+    sim_exact_chunk_kernel<SOFTMAX><<<nch, 256, EX_LDS, st>>>(f, wt, d, v, scale, hdr, fb, part, cap, nch);
+    sim_exact_merge_kernel<SOFTMAX><<<cap, 256, 0, st>>>(hdr, fb, part, k, idx_out, val_out, cap, nch);
+    sim_exact_kernel<SOFTMAX><<<256, 256, 0, st>>>(f, wt, d, v, scale, k, hdr, fb, idx_out, val_out, cap);
+    return SCD_OK;
 }
 
 extern "C" size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k) {
     (void)d; (void)v; (void)k;
     return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256 +
-           scd_align(sizeof(ExPart) * EX_ROWS * EX_BLOCKS);
+           scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v));
 }
 
 extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
@@ -1273,60 +1396,68 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
-    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 4>, 65536 + 16384); if (rc_) return rc_; }
-    { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 4>, 65536 + 16384); if (rc_) return rc_; }
-    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 1;
+    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 8;      // 8: eight-wave kernel (default), 1: four-wave, 0: tile kernel
+    const bool sm = mode == SCD_SIM_SOFTMAX;
     if (use_rb && d == 512 && v < (1ll << 28)) {
-        // row-block kernel (default at the CLIP width): units of 32 names x K = 512, epilogue hidden behind the next unit's MFMAs
-        const bool sm = mode == SCD_SIM_SOFTMAX;
+        // row-block kernels (the CLIP width): units of 32 names x K = 512, epilogue hidden behind the next unit's MFMAs
+#define RB_TAIL(SM, TMV, KSV)                                                                                                   \
+        sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV); \
+        { const int rc_ = sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; }
 #define RB_GO(SM, TMV)                                                                                                          \
     {                                                                                                                           \
         { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
-        sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                   \
-        sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out); \
-        sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);                \
+        sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                             \
+        RB_TAIL(SM, TMV, -1)                                                                                                    \
+    }
+#define RB8_GO(SM, TMV, KSV)                                                                                                    \
+    {                                                                                                                           \
+        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<SM, TMV, KSV, 0>, 131072); if (rc_) return rc_; }        \
+        sim_topk_rb8_kernel<SM, TMV, KSV><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits);     \
+        RB_TAIL(SM, TMV, KSV)                                                                                                   \
     }
         static const int sim_x_rb = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
-        if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernel (tools/sim_bench.py)
-            switch (sim_x_rb) {
+        if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernels (tools/sim_bench.py)
+            switch (sim_x_rb + (use_rb == 8 ? 1000 : 0)) {
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
+#define RB8_X(X) case 1000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
+                        sim_topk_rb8_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); break;
                 RB_X(1) RB_X(3) RB_X(4)
+                RB8_X(1) RB8_X(3) RB8_X(64) RB8_X(257) RB8_X(259)
 #undef RB_X
+#undef RB8_X
             }
             SCD_LAUNCH_CHECK();
             return SCD_OK;
         }
-        if (k == 1) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }   // two half lists of 4; k >= 2: 8 (certification needs margin)
-        else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
+        if (use_rb == 8) {
+            // entries per half list TM >= k + 2 (a row fails its certificate only when one half holds the image's TM + 1 best and two
+            // gaps among them are inside the error bound); KS + 1 >= k: the entry of the other half's list the shared threshold uses
+            if (k == 1) { if (sm) RB8_GO(true, 4, 0) else RB8_GO(false, 4, 0) }
+            else if (k <= 3) { if (sm) RB8_GO(true, 5, 2) else RB8_GO(false, 5, 2) }
+            else if (k <= 5) { if (sm) RB8_GO(true, 8, 4) else RB8_GO(false, 8, 4) }
+            else { if (sm) RB8_GO(true, 8, 7) else RB8_GO(false, 8, 7) }
+        } else {
+            // k == 1: two half lists of 4; k >= 2: 8 (certification needs margin)
+            if (k == 1) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
+            else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
+        }
+#undef RB8_GO
+#undef RB_TAIL
 #undef RB_GO
         if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));
         SCD_LAUNCH_CHECK();
         return SCD_OK;
     }
-    static const int use_w4 = getenv("SCD_SIM_W4") ? atoi(getenv("SCD_SIM_W4")) : 0;
-    static const int sim_x = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
-    static const int sim_nw = getenv("SCD_SIM_NW") ? atoi(getenv("SCD_SIM_NW")) : 8;
-    { const int rc_ = scd_set_max_lds((const void*)sim_topk_w4_kernel<true>, 131072); if (rc_) return rc_; }
-    { const int rc_ = scd_set_max_lds((const void*)sim_topk_w4_kernel<false>, 131072); if (rc_) return rc_; }
-    if (use_w4 && mode == SCD_SIM_SOFTMAX) {
-        sim_topk_w4_kernel<true><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_launch<true>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
-    } else if (use_w4) {
-        sim_topk_w4_kernel<false><<<g1, 256, 131072, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_launch<false>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
-    } else if (mode == SCD_SIM_SOFTMAX) {
-        if (sim_nw == 4) sim_topk_kernel<true, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        else sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_launch<true>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
+    // d < 512: the eight-wave tile kernel (256 images x 128 names sub-tiles)
+    if (sm) {
+        sim_topk_kernel<true, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, 0);
+        sim_refine_kernel<true, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, -1);
+        { const int rc_ = sim_exact_launch<true>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; }
     } else {
-        if (sim_nw == 4) sim_topk_kernel<false, 4><<<(unsigned)scd_cdiv(n, 128), 256, 65536 + 16384, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        else sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, sim_x);
-        sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out);
-        sim_exact_launch<false>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st);
+        sim_topk_kernel<false, 8><<<g1, 512, 65536 + 32768, st>>>(f, wt, n, d, v, scale, cval, cidx, stats, 0);
+        sim_refine_kernel<false, TOPM><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, -1);
+        { const int rc_ = sim_exact_launch<false>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; }
     }
     if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));
     SCD_LAUNCH_CHECK();

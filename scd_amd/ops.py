@@ -90,12 +90,12 @@ def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
     v = wt.shape[0]
     idx = torch.empty((n, k), dtype=torch.int64, device=f.device)
     val = torch.empty((n, k), dtype=torch.float32, device=f.device)
-    fb = torch.zeros(1, dtype=torch.int32, device=f.device)
+    fb = torch.empty(1, dtype=torch.int32, device=f.device) if return_fallback else None      # written by the library when asked for
     nb = _L().scd_sim_topk_ws_bytes(n, d, v, k)
     ws = _ws(nb, f.device)
     m = SIM_SOFTMAX if mode == "softmax" else SIM_RAW
-    check(_L().scd_sim_topk(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb), ptr(ws), nb,
-                            stream_ptr()))
+    check(_L().scd_sim_topk(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb),
+                            ptr(ws), nb, stream_ptr()))
     if return_fallback:
         return idx, val, fb
     return idx, val
