@@ -19,6 +19,9 @@ SOURCES = ["api.cpp", "munkres.cpp", "munkres_sparse.cpp", "transport.cpp", "com
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
          "-fno-gpu-rdc"]
+# per-file additions.  sim.hip: no SLP vectorisation - hipcc pairs scalar float ops of the hand-placed epilogue slots into
+# v_pk_*_f32 (an anti-lever beside MFMAs, MI355X guide) and spills the packed operands it builds for them inside the ring loop
+EXTRA = {"sim.hip": ["-fno-slp-vectorize"]}
 
 
 def _digest(paths):
@@ -27,6 +30,7 @@ def _digest(paths):
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA.items())).encode())
     return h.hexdigest()
 
 
@@ -51,7 +55,7 @@ def build(force=False, verbose=True):
         d = _digest([src]) + hdr_dig
         if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == d:
             return obj
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[scd_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -922,6 +922,350 @@ __global__ void __launch_bounds__(512) sim_topk_rb8_kernel(const half_t* __restr
 #undef RB_MFMA0
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-block kernel on 16x16x32 tiles (round 3; default at d == 512 for k <= 3).  Ring, fills, keys and lists as in
+// sim_topk_rb8_kernel (eight waves, 32 images per wave, units of 32 names x K = 512, one barrier per unit), different matrix
+// instruction: on random operands this chip holds 1.65 GHz through a v_mfma_f32_16x16x32_f16 loop fed by ds_read_b128 and 1.41 GHz
+// through the 32x32x16 loop at the same cycles per FLOP (tools/micro/mfma_rate.hip: 1616 vs 1439 TFLOP/s), and the bare loop of the
+// rb8 kernel runs 8 % faster on it (profiles/r03_sim_ablations.txt).  What changes with the tile:
+//   * a unit is 16 k32-steps x (2 name tiles x 2 image tiles) = 64 MFMAs per wave on four 4-register accumulators; the A fragment of
+//     name tile tj / step ks is row 16 tj + (l & 15), 16-B chunk 4 ks + (l >> 4) of the slot (chunk ^ (row & 15) swizzle as before:
+//     conflict-free, FOUR per-lane address registers instead of eight); the B fragments are [ks][ti] in 128 AGPRs;
+//   * a lane holds, per unit, 8 values of TWO images (16 ti + (l & 15)): names 16 tj + 4 (l >> 4) + e.  So a lane keeps two lists,
+//     each over a QUARTER of the vocabulary, and the four lanes of an image (l, l ^ 16, l ^ 32, l ^ 48) share their admission
+//     threshold through v_permlane16_swap / v_permlane32_swap;
+//   * lists hold TM entries, the best four of each leave the kernel (16 candidates per image, the lane layout of
+//     sim_refine4_kernel) together with ONE bound per image: the largest approximate value any name outside the 16 can have
+//     (the lists' last entries and the shared threshold).  The refine pass certifies against that number.
+// Epilogue of unit u - 1, dealt over the 64 MFMAs of unit u (h = 4 ks + m):
+//   h  4..19  one value into the (largest, second) key pair of image tile h & 1
+//   h 20, 21  widen the winners; softmax reference maxima
+//   h 22..    one list entry per slot (tile 0, then tile 1) and, h 22..37, one softmax term per slot
+//   h 40, 44  the rare second-key paths;  h 48 (every other unit): thresholds exchanged between the four lanes of an image
+__device__ __forceinline__ float rc_swap16(float v, int lane) {         // the value held by lane l ^ 16
+    const unsigned u = __float_as_uint(v);
+    const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((lane & 16) ? p[0] : p[1]);
+}
+template <bool SOFTMAX, int TM, int KS, int XM = 0>
+__global__ void __launch_bounds__(512) sim_topk_rc_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
+                                                          long long v, float scale, float* __restrict__ cand_val,
+                                                          int* __restrict__ cand_idx, float* __restrict__ stats,
+                                                          float* __restrict__ bound, const unsigned* __restrict__ wmax2_bits) {
+    constexpr int D = 512, UB = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int jl = lane & 15, g = lane >> 4;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    half8 bf[16][2];                                           // [k32 step][image tile]
+    float f2[2] = {0.f, 0.f};
+    long long img[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) img[ti] = (long long)blockIdx.x * 256 + wave * 32 + 16 * ti + jl;
+    {
+        const half_t* frow0 = F + (img[0] < n ? img[0] : n - 1) * D + 8 * g;
+        const half_t* frow1 = F + (img[1] < n ? img[1] : n - 1) * D + 8 * g;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                          // eight fragments at a time (see sim_topk_rb8_kernel)
+#pragma unroll
+            for (int ks = 4 * b; ks < 4 * b + 4; ++ks) {
+                bf[ks][0] = *(const half8*)(frow0 + 32 * ks);
+                bf[ks][1] = *(const half8*)(frow1 + 32 * ks);
+            }
+#pragma unroll
+            for (int ks = 4 * b; ks < 4 * b + 4; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f2[ti] = fmaf((float)bf[ks][ti][q], (float)bf[ks][ti][q], f2[ti]);
+#pragma unroll
+            for (int ks = 4 * b; ks < 4 * b + 4; ++ks) {
+                asm volatile("" : "+a"(bf[ks][0]) : : "memory");
+                asm volatile("" : "+a"(bf[ks][1]) : : "memory");
+            }
+        }
+    }
+    // 4 E of the wave's largest image (a scalar register; per lane it was spilled, and its reload in the loop drained the ring)
+    float e4;
+    {
+        float fm = fmaxf(f2[0] + rc_swap16(f2[0], lane), f2[1] + rc_swap16(f2[1], lane));
+        fm += rb_swap32(fm, lane);                             // >= both images' squared norms (cheap upper bound: one exchange less)
+        fm = wave_max_f32(fm);
+        const float e = RB8_EMARGIN * 1.5f * ((float)D * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * sqrtf(fm) * sqrtf(__uint_as_float(*wmax2_bits)) * 1.001f + 1e-30f;
+        int e4i;                                               // asm: the builtin is folded into the arithmetic above and the value re-derived in a VGPR
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(e4i) : "v"(__float_as_int(e)));
+        e4 = __int_as_float(e4i);
+    }
+    // State per image tile: the list, the shared threshold and the softmax pair; everything else (key pair, widened winner) is
+    // scratch of the tile being worked on - the two tiles of a unit are served one after the other so that it is (117 VGPRs with
+    // both tiles' scratch alive at once, and the softmax variant spilled B fragments).
+    double L[2][TM];                                           // per image tile: the lane's TM best (key | name index), descending
+    float tsh[2] = {-INFINITY, -INFINITY};                     // (largest entry KS of the image's four lanes) - 4 E
+    float nm[2] = {INFINITY, INFINITY}, smz[2] = {0.f, 0.f};   // softmax: nm = -(reference maximum) * c2, sum relative to it
+    float m1, m2;
+    double tk;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) L[ti][j] = -INFINITY;
+    const float c2 = scale * 1.4426950408889634f;
+
+    const int nunits = (int)((v + 31) / 32);
+    const unsigned bsw = (unsigned)((lane ^ ((4 * wave) & 12)) << 4);
+    const half_t* fbase = Wt;
+    unsigned fm0 = 0;
+    int frows = 32;
+    auto fill_unit = [&](int unit) {
+        fbase = Wt + (size_t)unit * 32 * D;
+        fm0 = sbase + (unit & 3) * UB + 4 * wave * 1024;
+        const long long left = v - (long long)unit * 32;
+        frows = left < 32 ? (int)left : 32;
+    };
+    auto fill = [&](int p) {
+        int srow = 4 * wave + p;
+        srow = srow < frows ? srow : frows - 1;
+        const unsigned off = (bsw ^ (unsigned)(p << 4)) + (unsigned)srow * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(fm0 + p * 1024), "v"(off), "s"(fbase) : "memory");
+    };
+    // A fragment (tj, ks = 4 a + b): fa[b] + a * 256 + tj * 16384
+    unsigned fa[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fa[b] = sbase + (unsigned)(jl * 1024 + (((4 * b + g) ^ jl) << 4));
+
+#define RC_RD(DST, B, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[B]), "n"(IMM))
+#define RC_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
+#define RC_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define RC_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
+
+    auto key = [](float a, int p) { return __uint_as_float((__float_as_uint(a) & 0xfffffff8u) | (unsigned)p); };
+    auto name_of = [&](int unit, int p) { return unit * 32 + 16 * (p >> 2) + 4 * g + (p & 3); };
+    // value p = 4 tj + e of image tile ti sits in acc[tj][ti][e]
+    auto p_top2 = [&](float a, int p) {
+        const float kk = key(a, p);
+        if (p == 0) {
+            m1 = kk;
+            m2 = -INFINITY;
+        } else {
+            const float n1 = rb_max(m1, kk);
+            m2 = rb_med3(m1, m2, kk);
+            m1 = n1;
+        }
+    };
+    auto widen = [&](float kk, int unit) {
+        const int p = (int)(__float_as_uint(kk) & 7u);
+        return __hiloint2double(__double2hiint((double)kk), name_of(unit, p));
+    };
+    auto p_ins = [&](int ti, int j) {
+        const double hi = rb_max64(L[ti][j], tk);
+        if (j + 1 < TM) tk = rb_min64(L[ti][j], tk);
+        L[ti][j] = hi;
+    };
+    auto p_ins_all = [&](int ti) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) p_ins(ti, j);
+    };
+    auto te_of = [&](int ti) { return rb_max((float)L[ti][TM - 1], tsh[ti]); };    // what a value of tile ti has to beat
+    auto p_share = [&](int ti) {                               // the four lanes of an image: the largest of their entries KS
+        float t = (float)L[ti][KS];
+        t = rb_max(t, rc_swap16(t, lane));
+        t = rb_max(t, rb_swap32(t, lane));
+        tsh[ti] = t - e4;
+    };
+    f32x4 acc[2][2][2];                                        // [parity][name tile][image tile]
+    half8 fr[4];                                               // fragment s = 2 ks + tj lives in fr[s & 3] (three in flight)
+    auto p_rest = [&](auto parity, auto tic, int unit) {       // rare: the lane's second key beats what it has to beat as well
+        constexpr int Q = decltype(parity)::value, ti = decltype(tic)::value;
+        float te = te_of(ti);
+        if (!__any(m2 > te)) return;
+        tk = m2 > te ? widen(m2, unit) : (double)-INFINITY;
+        p_ins_all(ti);
+        te = te_of(ti);
+        int cnt = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) cnt += key(acc[Q][p >> 2][ti][p & 3], p) > te ? 1 : 0;
+        if (!__any(cnt > 2)) return;
+        float bnd = m2;
+        for (;;) {
+            float c = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float kk = key(acc[Q][p >> 2][ti][p & 3], p);
+                c = (kk < bnd && kk > c) ? kk : c;
+            }
+            if (!__any(c > te)) break;
+            if (c > te) {
+                tk = widen(c, unit);
+                p_ins_all(ti);
+            }
+            te = te_of(ti);
+            bnd = c;
+        }
+    };
+    auto p_sm_begin = [&](int ti) {                            // new reference maximum, old sum rescaled to it
+        const float t = -m1 * c2;
+        const float nn = fminf(nm[ti], t);
+        smz[ti] = smz[ti] * __builtin_amdgcn_exp2f(nn - nm[ti]);                 // first unit: 0 * exp2(-inf) = 0
+        nm[ti] = nn;
+    };
+    auto p_sm_add = [&](float a, int ti) { smz[ti] += __builtin_amdgcn_exp2f(fmaf(a, c2, nm[ti])); };
+
+    using yes = std::true_type;
+    using no = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto body = [&](auto has_prev, auto parity, int u) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool EPI = decltype(has_prev)::value && !(XM & 1);
+        using PREV = std::integral_constant<int, 1 - P>;
+        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = u + 1 < nunits;
+        const bool fills = u + 3 < nunits;
+        if (fills) fill_unit(u + 3);
+        static_for<0, 32>([&](auto sc_) {
+            // fragment step s = 2 ks + tj: two MFMAs (image tiles 0, 1).  Reads run three fragments ahead; the wait of step s
+            // retires the fragment of step s + 1 (a whole step before its first use, see sim_topk_rb_kernel)
+            constexpr int s = decltype(sc_)::value, ks = s >> 1, tj = s & 1;
+            if (s == 29) {
+                const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fa[b] += delta;
+            }
+            constexpr int sn = (s + 3) & 31, kn = sn >> 1;      // fragment being fetched (of unit u + 1 when s >= 29)
+            if (s < 29 || more) RC_RD(fr[(s + 3) & 3], kn & 3, (kn >> 2) * 256 + (sn & 1) * 16384);
+            if (s < 29 || more) RC_WAIT(2, fr[(s + 1) & 3]);
+            else if (s == 29) RC_WAIT(1, fr[(s + 1) & 3]);
+            else if (s == 30) RC_WAIT(0, fr[(s + 1) & 3]);
+            static_for<0, 2>([&](auto tc) {
+                constexpr int ti = decltype(tc)::value, h = 2 * s + ti;
+                if constexpr (!(XM & 4)) {
+                    if (ks == 0) RC_MFMA0(acc[P][tj][ti], fr[s & 3], bf[ks][ti]);
+                    else RC_MFMA(acc[P][tj][ti], fr[s & 3], bf[ks][ti]);
+                }
+                if constexpr (!(XM & 2))
+                    if ((h & 15) == 15 && fills) fill(h >> 4);
+                if constexpr (EPI) {
+                    // tile t2 = h / 20 (h < 40): its slots are h0 = h - 20 t2 - 4: 0..7 key pair, 8 widen, 9.. list entries and,
+                    // 9..16, softmax terms, 18 the second-key path
+                    constexpr int t2 = h >= 24 ? 1 : 0, h0 = h - 20 * t2 - 4;
+                    if constexpr (h >= 4 && h < 44) {
+                        if constexpr (h0 >= 0 && h0 < 8) {
+                            p_top2(acc[1 - P][h0 >> 2][t2][h0 & 3], h0);
+                        } else if constexpr (h0 == 8) {
+                            tk = widen(m1, u - 1);
+                            if (SOFTMAX) p_sm_begin(t2);
+                        }
+                        if constexpr (h0 >= 9 && h0 < 9 + TM) p_ins(t2, h0 - 9);
+                        if constexpr (h0 >= 9 && h0 < 17) {
+                            if (SOFTMAX) p_sm_add(acc[1 - P][(h0 - 9) >> 2][t2][(h0 - 9) & 3], t2);
+                        }
+                        if constexpr (h0 == 18 && !(XM & 64)) {
+                            if constexpr (t2 == 0) p_rest(PREV{}, P0{}, u - 1);
+                            else p_rest(PREV{}, P1{}, u - 1);
+                        }
+                    }
+                    // (two slots: in one, hipcc packs the two subtractions into a v_pk_add_f32 whose (e4, e4) operand it then spills)
+                    if constexpr (h == 48 && P == 0 && !(XM & 128)) p_share(0);
+                    if constexpr (h == 50 && P == 0 && !(XM & 128)) p_share(1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < 3; ++pre)
+        if (pre < nunits) {
+            fill_unit(pre);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fill(p);
+        }
+    if (nunits > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nunits > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RC_RD(fr[0], 0, 0);
+    RC_RD(fr[1], 0, 16384);
+    RC_RD(fr[2], 1, 0);
+    RC_WAIT(2, fr[0]);
+    if constexpr (XM & 4) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q >> 2][(q >> 1) & 1][q & 1][e] = 0.f;
+    }
+
+    body(no{}, P0{}, 0);
+    int u = 1;
+    for (; u + 1 < nunits; u += 2) {
+        body(yes{}, P1{}, u);
+        body(yes{}, P0{}, u + 1);
+    }
+    const bool odd_tail = u < nunits;
+    if (odd_tail) body(yes{}, P1{}, u);
+    // epilogue of the last unit (the only one with padded names), not hidden behind anything; in place on its accumulator set
+    auto tail = [&](auto parity) {
+        constexpr int P = decltype(parity)::value;
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[P][0][0]), "+v"(acc[P][0][1]), "+v"(acc[P][1][0]), "+v"(acc[P][1][1]));
+        const int lu = nunits - 1;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+                if ((long long)name_of(lu, p) >= v) acc[P][p >> 2][ti][p & 3] = RB_NEG;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) p_top2(acc[P][p >> 2][ti][p & 3], p);
+            tk = widen(m1, lu);
+            p_ins_all(ti);
+            if (ti == 0) p_rest(parity, P0{}, lu);
+            else p_rest(parity, P1{}, lu);
+            if (SOFTMAX) {
+                p_sm_begin(ti);
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    if ((long long)name_of(lu, p) < v) smz[ti] += __builtin_amdgcn_exp2f(fmaf(acc[P][p >> 2][ti][p & 3], c2, nm[ti]));
+            }
+        }
+    };
+    if (odd_tail) tail(P1{});
+    else tail(P0{});
+    // the best four of each list leave the kernel: candidate slot 4 g + j of the image; everything else is below `bound`
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        p_share(ti);                                            // the final threshold: every lane of the image holds the same one
+        float bq = rb_max(tsh[ti], (float)L[ti][TM - 1]);       // dropped by the threshold, or pushed out of / never into the list
+        bq = rb_max(bq, rc_swap16(bq, lane));
+        bq = rb_max(bq, rb_swap32(bq, lane));
+        if (img[ti] < n) {
+            float* cv = cand_val + (img[ti] * 4 + g) * 4;
+            int* ci = cand_idx + (img[ti] * 4 + g) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool have = j < TM;
+                const double e = have ? L[ti][j < TM ? j : 0] : (double)-INFINITY;
+                const int idx = __double2loint(e);
+                const bool ok = have && e > -INFINITY && (long long)idx < v;
+                cv[j] = ok ? (float)e * scale : -INFINITY;
+                ci[j] = ok ? idx : -1;
+            }
+            if (g == 0) bound[img[ti]] = bq > -INFINITY ? bq * scale : -INFINITY;
+            if (SOFTMAX) {
+                stats[(img[ti] * 4 + g) * 2] = -nm[ti] * 0.6931471805599453f;   // reference maximum * scale = -nm / log2(e)
+                stats[(img[ti] * 4 + g) * 2 + 1] = smz[ti];
+            }
+        }
+    }
+#undef RC_RD
+#undef RC_WAIT
+#undef RC_MFMA
+#undef RC_MFMA0
+}
+
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
 __global__ void __launch_bounds__(256) wmax_kernel(const half_t* __restrict__ Wt, long long v, int d, unsigned* out_bits) {
     __shared__ float red[4];
@@ -1072,6 +1416,142 @@ __global__ void __launch_bounds__(256) sim_refine_kernel(const half_t* __restric
             const float m0 = stats[img * 4], z0 = stats[img * 4 + 1], m1 = stats[img * 4 + 2], z1 = stats[img * 4 + 3];
             const float mm = fmaxf(m0, m1);
             const float z = z0 * __expf(m0 - mm) + z1 * __expf(m1 - mm);
+            o = __expf((float)mye - mm) / z;
+        }
+        val_out[img * k + rank] = o;
+    }
+}
+
+// pass 2 at d == 512 (round 3): FOUR images per wave, 16 lanes each - lane j of a group owns candidate j (2 TM <= 16), the group's
+// lanes split an image / vocabulary row into 4 x 16-B pieces per lane (whole 256-B segments per load instruction and group), the
+// float64 dot products reduce over 16 lanes (four butterfly steps instead of six) and every ranking step serves four images.  Same
+// decisions as sim_refine_kernel: which candidates are recomputed (approximate value within 2 E of the k-th largest), (value desc,
+// index asc) order, the certificate against the lists' last entries and the shared threshold of sim_topk_rb8_kernel (ks).
+__device__ __forceinline__ double grp16_sum_f64(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <bool SOFTMAX, int TM>
+__global__ void __launch_bounds__(256) sim_refine4_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt,
+                                                          long long n, long long v, float scale, int k,
+                                                          const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                          const float* __restrict__ stats, SimHdr* hdr, int* fb_list,
+                                                          long long* idx_out, float* val_out, int ks,
+                                                          const float* __restrict__ bound, int nstat) {
+    constexpr int D = 512, NC = 2 * TM;
+    const int lane = threadIdx.x & 63, j = lane & 15, gb = lane & 48;
+    const long long img0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = img0 < n;
+    const long long img = live ? img0 : n - 1;
+    int myi = -1;
+    float mya = -INFINITY;
+    if (j < NC) {
+        myi = cand_idx[img * NC + j];
+        mya = cand_val[img * NC + j];
+    }
+    half8 fv[4];
+    const half_t* f = F + img * D + 8 * j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fv[q] = *(const half8*)(f + 128 * q);
+    double f2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double x = (double)(float)fv[q][e];
+            f2 = fma(x, x, f2);
+        }
+    f2 = grp16_sum_f64(f2);
+    const float wmax = sqrtf(__uint_as_float(hdr->wmax2_bits));
+    const float E = 1.5f * fabsf(scale) * ((float)D * 5.9604645e-8f + 2.4e-7f + 2.0e-6f) * (float)sqrt(f2) * wmax + 1e-30f;
+    // the k-th largest approximate value of the image
+    int ra = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float oa = __shfl(mya, gb | c, 64);
+        const int oi = __shfl(myi, gb | c, 64);
+        if (oi >= 0 && (oa > mya || (oa == mya && c < j))) ++ra;
+    }
+    float kap;
+    {
+        const unsigned gm = (unsigned)(__ballot(ra == k - 1 && myi >= 0) >> gb) & 0xffffu;
+        const float t = __shfl(mya, gm ? (gb | (__ffs((int)gm) - 1)) : lane, 64);
+        kap = gm ? t : -INFINITY;
+    }
+    const unsigned need = (unsigned)(__ballot(myi >= 0 && mya >= kap - 2.f * E) >> gb) & 0xffffu;   // uniform inside a group
+    // exact values of the needed candidates, four rows per pass in flight
+    double mye = -INFINITY;
+    unsigned rem = need;
+    while (__any(rem != 0)) {
+        int cc[4];
+        half8 wv[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            cc[t] = rem ? __ffs((int)rem) - 1 : -1;
+            rem = rem ? (rem & (rem - 1)) : 0;
+            const int ci = __shfl(myi, gb | (cc[t] >= 0 ? cc[t] : 0), 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[t][q] = fv[q];
+            if (cc[t] >= 0) {
+                const half_t* w = Wt + (long long)ci * D + 8 * j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[t][q] = *(const half8*)(w + 128 * q);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!__any(cc[t] >= 0)) break;                         // wave-uniform
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sacc = fma((double)(float)fv[q][e], (double)(float)wv[t][q][e], sacc);
+            const double ev = (double)scale * grp16_sum_f64(sacc);
+            if (cc[t] == j) mye = ev;
+        }
+    }
+    // rank of each recomputed candidate among them: (value desc, index asc)
+    const bool need_l = need >> j & 1;
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double oe = __shfl(mye, gb | c, 64);
+        const int oi = __shfl(myi, gb | c, 64);
+        if ((need >> c & 1) && (oe > mye || (oe == mye && oi < myi))) ++rank;
+    }
+    // certification: a non-candidate of half h has approx <= list_h[TM-1]; a list that is not full has no non-candidates
+    const float a0 = __shfl(mya, gb | (TM - 1), 64), a1 = __shfl(mya, gb | (NC - 1), 64);
+    const int i0 = __shfl(myi, gb | (TM - 1), 64), i1 = __shfl(myi, gb | (NC - 1), 64);
+    float astar = -INFINITY;
+    if (i0 >= 0) astar = fmaxf(astar, a0);
+    if (i1 >= 0) astar = fmaxf(astar, a1);
+    if (ks >= 0) astar = fmaxf(astar, fmaxf(__shfl(mya, gb | ks, 64), __shfl(mya, gb | (TM + ks), 64)) - 3.9f * E);
+    if (bound) astar = bound[img];                              // sim_topk_rc_kernel: what a name outside the 16 candidates can reach
+    double kth;
+    {
+        const unsigned gm = (unsigned)(__ballot(rank == k - 1 && need_l) >> gb) & 0xffffu;
+        const double t = __shfl(mye, gm ? (gb | (__ffs((int)gm) - 1)) : lane, 64);
+        kth = gm ? t : -INFINITY;
+    }
+    const bool certified = (astar == -INFINITY) || (kth > (double)astar + (double)E);
+    if (!live) return;
+    if (!certified) {
+        if (j == 0) {
+            const int pos = atomicAdd(&hdr->fb_cnt, 1);
+            fb_list[pos] = (int)img;
+        }
+        return;
+    }
+    if (need_l && rank < k) {
+        idx_out[img * k + rank] = myi;
+        float o = (float)mye;
+        if (SOFTMAX) {
+            const float* st = stats + img * 2 * nstat;            // nstat (max, sum) pairs: two half lists or four quarter lists
+            float mm = st[0];
+            for (int q = 1; q < nstat; ++q) mm = fmaxf(mm, st[2 * q]);
+            float z = 0.f;
+            for (int q = 0; q < nstat; ++q) z += st[2 * q + 1] * __expf(st[2 * q] - mm);
             o = __expf((float)mye - mm) / z;
         }
         val_out[img * k + rank] = o;
@@ -1304,20 +1784,23 @@ __global__ void __launch_bounds__(256) sim_exact_merge_kernel(const SimHdr* hdr,
     }
     double mm = 0.0, zz = 1.0;
     if (SOFTMAX) {
-        sm[t] = tm;
-        sz[t] = tz;
-        __syncthreads();
-        if (t == 0) {                                   // fixed order: threads ascending
-            double a2 = -INFINITY, b2 = 0.0;
-            for (int q = 0; q < 256; ++q) a2 = sm[q] > a2 ? sm[q] : a2;
-            for (int q = 0; q < 256; ++q)
-                if (sz[q] > 0.0 || sz[q] != sz[q]) b2 += sz[q] * exp(sm[q] - a2);
-            sm[0] = a2;
-            sz[0] = b2;
+        // fixed butterfly order (a serial loop over the 256 partials on one thread took 40 us)
+        double a2 = tm;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(a2, o, 64);
+            a2 = om > a2 ? om : a2;
         }
+        if (lane == 0) sm[wave] = a2;
         __syncthreads();
-        mm = sm[0];
-        zz = sz[0];
+        a2 = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        double b2 = (tz > 0.0 || tz != tz) ? tz * exp(tm - a2) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b2 += __shfl_xor(b2, o, 64);
+        if (lane == 0) sz[wave] = b2;
+        __syncthreads();
+        mm = a2;
+        zz = (sz[0] + sz[1]) + (sz[2] + sz[3]);
     }
     int head = 0;                                        // the thread's list is sorted: its best remaining candidate is cv[head]
     for (int out = 0; out < k; ++out) {
@@ -1362,7 +1845,7 @@ static int sim_exact_launch(const half_t* f, const half_t* wt, int d, long long 
 
 extern "C" size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k) {
     (void)d; (void)v; (void)k;
-    return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256 +
+    return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 32) + scd_align((size_t)n * 4) * 2 + 256 +
            scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v));
 }
 
@@ -1387,8 +1870,9 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     float* cval = (float*)(w + 64);
     int* cidx = (int*)(w + 64 + csz);
     float* stats = (float*)(w + 64 + 2 * csz);
-    int* fb = (int*)(w + 64 + 2 * csz + scd_align((size_t)n * 16));
-    ExPart* expart = (ExPart*)(w + 64 + 2 * csz + scd_align((size_t)n * 16) + scd_align((size_t)n * 4) + 256);
+    int* fb = (int*)(w + 64 + 2 * csz + scd_align((size_t)n * 32));
+    float* bnd = (float*)(w + 64 + 2 * csz + scd_align((size_t)n * 32) + scd_align((size_t)n * 4));
+    ExPart* expart = (ExPart*)(w + 64 + 2 * csz + scd_align((size_t)n * 32) + scd_align((size_t)n * 4) * 2 + 256);
     const half_t* f = (const half_t*)F;
     const half_t* wt = (const half_t*)Wt;
     SCD_HIP(hipMemsetAsync(hdr, 0, 64, st));
@@ -1396,18 +1880,27 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
-    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 8;      // 8: eight-wave kernel (default), 1: four-wave, 0: tile kernel
+    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 16;     // 16: 16x16x32 tiles for k <= 3, 8: eight-wave 32x32x16 kernel, 1: four-wave, 0: tile kernel
     const bool sm = mode == SCD_SIM_SOFTMAX;
     if (use_rb && d == 512 && v < (1ll << 28)) {
         // row-block kernels (the CLIP width): units of 32 names x K = 512, epilogue hidden behind the next unit's MFMAs
+        static const int refine4 = getenv("SCD_SIM_REFINE4") ? atoi(getenv("SCD_SIM_REFINE4")) : 1;
 #define RB_TAIL(SM, TMV, KSV)                                                                                                   \
-        sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV); \
+        if (refine4) sim_refine4_kernel<SM, TMV><<<(unsigned)scd_cdiv(n, 16), 256, 0, st>>>(f, wt, n, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV, nullptr, 2); \
+        else sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV); \
         { const int rc_ = sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; }
 #define RB_GO(SM, TMV)                                                                                                          \
     {                                                                                                                           \
         { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
         sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                             \
         RB_TAIL(SM, TMV, -1)                                                                                                    \
+    }
+#define RC_GO(SM, TMV, KSV)                                                                                                     \
+    {                                                                                                                           \
+        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rc_kernel<SM, TMV, KSV, 0>, 131072); if (rc_) return rc_; }         \
+        sim_topk_rc_kernel<SM, TMV, KSV><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, bnd, &hdr->wmax2_bits); \
+        sim_refine4_kernel<SM, 8><<<(unsigned)scd_cdiv(n, 16), 256, 0, st>>>(f, wt, n, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, -1, bnd, 4); \
+        { const int rc_ = sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; } \
     }
 #define RB8_GO(SM, TMV, KSV)                                                                                                    \
     {                                                                                                                           \
@@ -1417,20 +1910,28 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     }
         static const int sim_x_rb = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
         if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernels (tools/sim_bench.py)
-            switch (sim_x_rb + (use_rb == 8 ? 1000 : 0)) {
+            switch (sim_x_rb + (use_rb == 8 ? 1000 : use_rb == 16 ? 2000 : 0)) {
+#define RC_X(X) case 2000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rc_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
+                        sim_topk_rc_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, bnd, &hdr->wmax2_bits); break;
+                RC_X(1) RC_X(3) RC_X(64) RC_X(128)
+#undef RC_X
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
 #define RB8_X(X) case 1000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb8_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); break;
                 RB_X(1) RB_X(3) RB_X(4)
-                RB8_X(1) RB8_X(3) RB8_X(64) RB8_X(257) RB8_X(259)
+                RB8_X(1) RB8_X(3) RB8_X(64)
 #undef RB_X
 #undef RB8_X
             }
             SCD_LAUNCH_CHECK();
             return SCD_OK;
         }
-        if (use_rb == 8) {
+        if (use_rb == 16 && k <= 3) {
+            // 16x16x32 tiles, four quarter lists per image: TM = k + 2 entries each, the best four leave the kernel
+            if (k == 1) { if (sm) RC_GO(true, 3, 0) else RC_GO(false, 3, 0) }
+            else { if (sm) RC_GO(true, 5, 2) else RC_GO(false, 5, 2) }
+        } else if (use_rb >= 8) {
             // entries per half list TM >= k + 2 (a row fails its certificate only when one half holds the image's TM + 1 best and two
             // gaps among them are inside the error bound); KS + 1 >= k: the entry of the other half's list the shared threshold uses
             if (k == 1) { if (sm) RB8_GO(true, 4, 0) else RB8_GO(false, 4, 0) }
@@ -1443,6 +1944,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
             else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
         }
 #undef RB8_GO
+#undef RC_GO
 #undef RB_TAIL
 #undef RB_GO
         if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));

@@ -8,10 +8,10 @@ run() { # name, timeout, cmd...
   echo "[$name] rc=$rc"; grep -E "sim_topk\[|passed|failed|Error|error" $out/$name.log | tail -n 8
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timeout: stopping"; exit 1; fi
 }
-SCD_SIM_RB=8 run test_rb8 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sim_topk or vote_loop or match_missing or textual or zero_shot"
+SCD_SIM_RB=${RB:-8} run test_rb8 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sim_topk or vote_loop or match_missing or textual or zero_shot"
 for k in ${KS:-3 5 1}; do
   [ -n "${AB4:-}" ] && SCD_SIM_RB=1 run bench_rb4_k$k 120 python tools/sim_bench.py 126976 $k
-  SCD_SIM_RB=8 run bench_rb8_k$k 120 python tools/sim_bench.py 126976 $k
+  SCD_SIM_RB=${RB:-8} run bench_rb8_k$k 120 python tools/sim_bench.py 126976 $k
 done
 for x in ${XS:-}; do
   SCD_SIM_RB=8 SCD_SIM_X=$x run bench_rb8_x$x 120 python tools/sim_bench.py 126976 3
