@@ -1268,18 +1268,32 @@ __global__ void __launch_bounds__(512) sim_topk_rc_kernel(const half_t* __restri
 
 // max ||w_v||^2 over the vocabulary (error-bound scale), one wave per row
 __global__ void __launch_bounds__(256) wmax_kernel(const half_t* __restrict__ Wt, long long v, int d, unsigned* out_bits) {
+    // 16 lanes per row (8 below d = 128), each with d / 128 16-B pieces (whole 256-B segments per load instruction and row), eight
+    // rows per wave in flight and a four-step butterfly: one wave per row with a 64-lane butterfly was latency-bound (14 us at V = 21,000)
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lpr = d >= 128 ? 16 : 8, rpw = 64 / lpr, sub = lane / lpr, jl = lane % lpr;
     float best = 0.f;
-    for (long long row = (long long)blockIdx.x * 4 + wave; row < v; row += (long long)gridDim.x * 4) {
-        float s = 0.f;
-        for (int j = lane * 8; j < d; j += 512) {
-            const half8 w8 = *(const half8*)(Wt + row * d + j);
+    for (long long row0 = ((long long)blockIdx.x * 4 + wave) * 2 * rpw; row0 < v; row0 += (long long)gridDim.x * 4 * 2 * rpw) {
+        float sacc[2] = {0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s = fmaf((float)w8[q], (float)w8[q], s);
+        for (int t = 0; t < 2; ++t) {
+            const long long row = row0 + t * rpw + sub;
+            if (row < v)
+                for (int j = jl * 8; j < d; j += lpr * 8) {
+                    const half8 w8 = *(const half8*)(Wt + row * d + j);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sacc[t] = fmaf((float)w8[q], (float)w8[q], sacc[t]);
+                }
         }
-        best = fmaxf(best, wave_sum_f32(s));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float sv = sacc[t];
+            for (int o = lpr >> 1; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+            best = fmaxf(best, sv);
+        }
     }
+    best = wave_max_f32(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f));
@@ -1913,7 +1927,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
             switch (sim_x_rb + (use_rb == 8 ? 1000 : use_rb == 16 ? 2000 : 0)) {
 #define RC_X(X) case 2000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rc_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rc_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, bnd, &hdr->wmax2_bits); break;
-                RC_X(1) RC_X(3) RC_X(64) RC_X(128)
+                RC_X(1) RC_X(3) RC_X(64) RC_X(1024)
 #undef RC_X
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;

@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/sim_pmc; mkdir -p $out
-export SCD_SIM_RB=${SCD_SIM_RB:-8}
+export SCD_SIM_RB=${SCD_SIM_RB:-16}
 for x in 0 1 3; do
   export SCD_SIM_X=$x
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU \

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 k=${1:-3}; tag=${2:-rb8}
 out=$R/gpurun_out/sim_stats_$tag; mkdir -p $out
-export SCD_SIM_RB=${SCD_SIM_RB:-8}
+export SCD_SIM_RB=${SCD_SIM_RB:-16}
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out --output-format csv -- python3 $R/tools/sim_bench.py 126976 $k > $out/run.log 2>&1
 rc=$?; echo "[stats k=$k] rc=$rc"; grep sim_topk $out/run.log
 f=$(find $out -name "*kernel_stats.csv" | head -n 1)

@@ -14,3 +14,10 @@ for mode in ("raw", "softmax"):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print("sim_topk[%s] k=%d n=%d v=%d: %.3f ms  %.1f TFLOP/s  fallback rows %d" % (mode, k, n, v, ms, 2.0 * n * v * d / ms / 1e9, int(fb)))
+if len(sys.argv) > 3:          # the same product on the same tensors through torch.mm (hipBLASLt), logits materialised, no top-k
+    for _ in range(2): torch.mm(f, wt.t())
+    e0.record()
+    for _ in range(5): torch.mm(f, wt.t())
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("torch.mm (hipBLASLt) n=%d v=%d d=%d: %.3f ms  %.1f TFLOP/s  (writes the %d x %d fp16 logits: %.1f GB)" % (n, v, d, ms, 2.0 * n * v * d / ms / 1e9, n, v, n * v * 2 / 1e9))
