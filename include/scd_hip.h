@@ -76,10 +76,18 @@ int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* pre
 size_t scd_kmeans_estep_ws_bytes(int64_t n, int d, int k);
 int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float* C, int64_t n, int d, int k,
                      int32_t* labels_out, int32_t* refine_rows_out, void* ws, size_t ws_bytes, void* stream);
-/* Hint for the NEXT scd_kmeans_estep on this handle (consumed by it): the caller expects few rows inside the filter's error bound
- * (Lloyd iterations after the first two; converged centres).  Those rows are then re-evaluated in the tail of the filter kernel
- * instead of by a refine launch.  Results are identical either way; a wrong hint only costs time. */
-int scd_kmeans_estep_hint(scd_handle h, int expect_few_refined_rows);
+/* Hints for the NEXT scd_kmeans_estep on this handle (one-shot: that call consumes them whichever path it takes).  Results are
+ * identical with or without them.
+ *   SCD_ESTEP_FEW                     few rows are expected inside the filter's error bound (Lloyd iterations after the first two;
+ *                                     converged centres): they are re-evaluated in the tail of the filter kernel instead of by a
+ *                                     refine launch.  A wrong hint only costs time.
+ *   SCD_ESTEP_CENTRES_FROM_FINALIZE   the caller vouches that the centres it will pass are the C_out of the last
+ *                                     scd_kmeans_finalize on this handle (same buffer, NOT modified since, same E-step workspace):
+ *                                     that call has already written the E-step's centre operands and the prep launch is skipped.
+ *                                     Without the flag a matching pointer is not trusted (the address may have been recycled). */
+#define SCD_ESTEP_FEW 1
+#define SCD_ESTEP_CENTRES_FROM_FINALIZE 2
+int scd_kmeans_estep_hint(scd_handle h, int flags);
 /* d2_out[i] = ||x_i - c_{labels[i]}||^2 (float64 sum rounded to float32) */
 int scd_kmeans_rowdist(scd_handle h, const float* X, const float* C, const int32_t* labels, int64_t n, int d, int k,
                        float* d2_out, void* stream);

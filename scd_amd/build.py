@@ -40,22 +40,27 @@ def _deps():
     return hdrs
 
 
-def build(force=False, verbose=True):
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(force=False, verbose=True, ablate=False):
+    """ablate=True: lib/libscd_hip_ablate.so with -DSCD_ABLATE (timing ablations and the A/B kernels of earlier rounds; load it
+    through SCD_HIP_LIB).  The default library contains neither."""
+    objdir = OBJDIR + ("_ablate" if ablate else "")
+    lib = os.path.join(LIBDIR, "libscd_hip_ablate.so") if ablate else LIB
+    flags = FLAGS + (["-DSCD_ABLATE"] if ablate else [])
+    os.makedirs(objdir, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    stamp = os.path.join(LIBDIR, "build.sha256")
+    stamp = os.path.join(LIBDIR, "build_ablate.sha256" if ablate else "build.sha256")
     dig = _digest(srcs + _deps())
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
     hdr_dig = _digest(_deps())
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
         tag = obj + ".sha256"
         d = _digest([src]) + hdr_dig
         if not force and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == d:
             return obj
-        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + flags + EXTRA.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[scd_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,7 +72,7 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
     if verbose:
         print("[scd_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -75,8 +80,8 @@ def build(force=False, verbose=True):
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

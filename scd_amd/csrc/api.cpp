@@ -53,6 +53,7 @@ extern "C" int scd_create(int device, scd_handle* out) {
     c->prep_C = c->prep_ws = nullptr;
     c->prep_k = c->prep_d = 0;
     c->estep_few = 0;
+    c->prep_ok = 0;
     SCD_HIP(hipMalloc(&c->scratch, SCD_SCRATCH_BYTES));
     SCD_HIP(hipMemset(c->scratch, 0, SCD_SCRATCH_BYTES));
     *out = c;
@@ -60,6 +61,7 @@ extern "C" int scd_create(int device, scd_handle* out) {
 }
 
 extern "C" int scd_destroy(scd_handle h) {
+    if (h) scd_comm_destroy(h);             // the communicator map is keyed by the handle: a later handle at the same address must not inherit it
     if (h && h->scratch) hipFree(h->scratch);
     delete h;
     return SCD_OK;

@@ -104,6 +104,7 @@ extern "C" int scd_comm_destroy(scd_handle h) {
 }
 
 extern "C" int scd_allreduce_centroids(scd_handle h, double* packed, int64_t count, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_allreduce_centroids");
     SCD_REQUIRE(h && packed && count > 0, "scd_allreduce_centroids: bad arguments");
     ncclComm_t c = comm_of(h);
     SCD_REQUIRE(c, "scd_allreduce_centroids: scd_comm_init has not been called on this handle");
@@ -112,6 +113,7 @@ extern "C" int scd_allreduce_centroids(scd_handle h, double* packed, int64_t cou
 }
 
 extern "C" int scd_allgather_text(scd_handle h, const void* w_shard, int64_t shard_elems, void* w_full, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_allgather_text");
     SCD_REQUIRE(h && w_shard && w_full && shard_elems > 0, "scd_allgather_text: bad arguments");
     ncclComm_t c = comm_of(h);
     SCD_REQUIRE(c, "scd_allgather_text: scd_comm_init has not been called on this handle");

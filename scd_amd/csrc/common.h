@@ -16,6 +16,7 @@ struct scd_ctx {
     const void* prep_C;
     const void* prep_ws;
     int prep_k, prep_d;
+    int prep_ok;            // scd_kmeans_estep_hint(SCD_ESTEP_CENTRES_FROM_FINALIZE): the caller vouches that the next E-step's centres are prep_C's, unmodified
     int estep_few;          // scd_kmeans_estep_hint: the next E-step re-evaluates its (few) flagged rows in the filter kernel's tail
 };
 #define SCD_SCRATCH_BYTES (262144 + 64)
@@ -45,6 +46,23 @@ int scd_check_device(const struct scd_ctx* h, const char* who);
     } while (0)
 
 #define SCD_LAUNCH_CHECK() SCD_HIP(hipGetLastError())
+// first statement of every entry point that launches on the handle's device
+#define SCD_DEVICE_ENTRY(h, who)                                \
+    do {                                                        \
+        SCD_REQUIRE((h) != nullptr, who ": null handle");       \
+        const int rc_dev_ = scd_check_device((h), who);         \
+        if (rc_dev_) return rc_dev_;                            \
+    } while (0)
+
+// Environment switches that can change RESULTS (timing ablations: kernels with pieces removed) or that select kernels kept only for
+// A/B measurements exist in builds with -DSCD_ABLATE (`python -m scd_amd.build --ablate` -> lib/libscd_hip_ablate.so, loaded through
+// SCD_HIP_LIB).  The default library does not read these variables and does not contain the code behind them.
+#ifdef SCD_ABLATE
+#include <stdlib.h>
+#define SCD_ABLATE_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define SCD_ABLATE_ENV(name, dflt) (dflt)
+#endif
 
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

@@ -738,6 +738,7 @@ static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
 
 extern "C" int scd_encoder_create(scd_handle h, const scd_encoder_desc* desc, const void* const* weights, int n_weights,
                                   scd_encoder** out) {
+    SCD_DEVICE_ENTRY(h, "scd_encoder_create");
     SCD_REQUIRE(h && desc && weights && out, "scd_encoder_create: null argument");
     const scd_encoder_desc& d = *desc;
     SCD_REQUIRE(d.kind >= 0 && d.kind <= 2, "scd_encoder_create: bad kind %d", d.kind);
@@ -825,7 +826,7 @@ extern "C" size_t scd_encoder_ws_bytes(const scd_encoder* e, int batch) {
 }
 
 static int attn_xmode() {
-    static const int x = getenv("SCD_ATTN_X") ? atoi(getenv("SCD_ATTN_X")) : 0;   // timing ablations only
+    static const int x = SCD_ABLATE_ENV("SCD_ATTN_X", 0);   // timing ablations only
     return x;
 }
 
@@ -1022,6 +1023,7 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
 
 extern "C" int scd_clip_encode_text(scd_handle h, const scd_encoder* e, const int32_t* tokens, int batch, void* out, int normalize,
                                     void* ws, size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_clip_encode_text");
     SCD_REQUIRE(e, "scd_clip_encode_text: null encoder");
     return scd_clip_encode_text_len(h, e, tokens, batch, e->d.tokens, out, normalize, ws, ws_bytes, stream_);
 }

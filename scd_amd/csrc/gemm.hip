@@ -406,6 +406,10 @@ __global__ void __launch_bounds__(BM * 2, 2) gemm_dma_kernel(const half_t* __res
     }
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+#ifdef SCD_ABLATE   // A/B kernel (SCD_GEMM_MFMA=16): not in the default build
 // ------------------------------------------------------------------------------------------------
 // Same block tile / ring / schedule as gemm_dma_kernel<256>, but on v_mfma_f32_16x16x32_f16 (the shape on which gfx950
 // sustains the higher clock under load): a 32-deep sub-step is ONE k-step of 8(m) x 4(n) 16x16 tiles = 32 MFMAs per wave.
@@ -413,9 +417,6 @@ __global__ void __launch_bounds__(BM * 2, 2) gemm_dma_kernel(const half_t* __res
 // pc = chunk ^ ((-(row>>2)) & 3): every ds_read_b128 lane group then touches 16 distinct 16-B slots.
 // MFMA group 0 = m-tiles 0-3, group 1 = m-tiles 4-7; the A fragments of group 1 are read while group 0 computes, and
 // the W + A(0-3) fragments of the next sub-step while group 1 computes.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef float float2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
 template <int ACT, bool HAS_BIAS, bool HAS_RES>
 __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
@@ -629,6 +630,8 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
         }
     }
 }
+
+#endif  // SCD_ABLATE
 
 // ------------------------------------------------------------------------------------------------
 // Four-wave kernel: 256x256 block tile, one wave per SIMD, each wave a 128(m) x 128(n) sub-tile whose 256 accumulator
@@ -1147,6 +1150,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #undef W4_LGKM
 }
 
+#ifdef SCD_ABLATE   // A/B kernel (SCD_GEMM_MFMA=8): not in the default build
 // ------------------------------------------------------------------------------------------------
 // Eight-wave sibling of gemm_w4_kernel (SCD_GEMM_MFMA=8, A/B candidate): the same 256x256 block tile, 64-deep chunks, LDS
 // image, tile order, non-temporal stores and LayerNorm folding, but two waves per SIMD with 128(m) x 64(n) wave tiles
@@ -1416,6 +1420,8 @@ gemm_w8_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#endif  // SCD_ABLATE
+
 // n-tiles per group: the W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
 // re-reads the activations once.  Estimate the beyond-L2 traffic of each candidate and keep the cheapest.
 static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
@@ -1435,6 +1441,7 @@ static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
     return ng;
 }
 
+#ifdef SCD_ABLATE
 template <int ACT, bool B, bool RR, int LN>
 static int launch_w8(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                      const scd_gemm_ln* ln, hipStream_t st) {
@@ -1442,7 +1449,7 @@ static int launch_w8(const half_t* A, const half_t* W, const float* bias, const 
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
     { const int rc_ = scd_set_max_lds((const void*)gemm_w8_kernel<ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
-    static const int xenv = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int xenv = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;
     const bool nt = nt_env >= 0 ? nt_env != 0 : 2.0 * M * (double)N > 64e6;
     const int xmode = xenv | (nt ? 512 : 0);
@@ -1455,6 +1462,8 @@ static int launch_w8(const half_t* A, const half_t* W, const float* bias, const 
     return SCD_OK;
 }
 
+#endif  // SCD_ABLATE
+
 template <int NT, int ACT, bool B, bool RR, int LN>
 static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                      const scd_gemm_ln* ln, hipStream_t st) {
@@ -1462,13 +1471,13 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
     { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
-    static const int xenv = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int xenv = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;   // -1: by size
     const bool nt = nt_env >= 0 ? nt_env != 0 : 2.0 * M * (double)N > 64e6;   // C beyond what L2 (32 MB) could keep anyway
     const int xmode = xenv | (nt ? 512 : 0);
     const int ng = choose_ng(M, K, tiles_n, total, 256);
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
-    static const int stagger_env = getenv("SCD_GEMM_STAGGER") ? atoi(getenv("SCD_GEMM_STAGGER")) : 0;   // ticks per phase, experiment
+    static const int stagger_env = SCD_ABLATE_ENV("SCD_GEMM_STAGGER", 0);   // ticks per phase, experiment
     const int stagger = stagger_env;
     gemm_w4_kernel<NT, ACT, B, RR, LN><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
                                                                LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
@@ -1492,7 +1501,8 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
 // the LayerNorm-folded variants exist for the shapes the encoders use: bias, no residual (LN = 1) and bias + residual (LN = 2)
 static int launch_w4_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K, int act,
                         const scd_gemm_ln* ln, hipStream_t st) {
-    static const int w8 = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) == 8 : 0;
+#ifdef SCD_ABLATE
+    static const int w8 = SCD_ABLATE_ENV("SCD_GEMM_MFMA", 4) == 8;
     if (w8) {
         if (ln->stats_in) {
             if (!bias || R || ln->stats_out) return SCD_EINVAL;
@@ -1503,6 +1513,7 @@ static int launch_w4_ln(const half_t* A, const half_t* W, const float* bias, con
         if (!bias || !R || act != SCD_ACT_NONE) return SCD_EINVAL;
         return launch_w8<SCD_ACT_NONE, true, true, 2>(A, W, bias, R, C, M, N, K, ln, st);
     }
+#endif
     if (ln->stats_in) {
         if (!bias || R || ln->stats_out) return SCD_EINVAL;
         if (act == SCD_ACT_NONE) return launch_w4<8, SCD_ACT_NONE, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
@@ -1517,23 +1528,36 @@ template <int BM, int ACT, bool B, bool RR>
 static int launch_dma(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
                       hipStream_t st) {
     constexpr int LDS = BM == 256 ? 4 * (256 * 64 + 16384) + 8 * 4096 : 3 * (128 * 64 + 16384) + 4 * 2048;   // 160 KB / 80 KB
+#ifdef SCD_ABLATE
     { const int rc_ = scd_set_max_lds((const void*)gemm_dma_kernel<BM, ACT, B, RR>, LDS); if (rc_) return rc_; }
+#else
+    if constexpr (BM != 256) { const int rc_ = scd_set_max_lds((const void*)gemm_dma_kernel<BM, ACT, B, RR>, LDS); if (rc_) return rc_; }
+#endif
     const int tiles_n = N / 256, total = (M / BM) * tiles_n;
     const int resident = BM == 256 ? 256 : 512;
     const int grid = total < resident ? (total >= 8 ? total / 8 * 8 : total) : resident;
-    static const int xmode = getenv("SCD_GEMM_X") ? atoi(getenv("SCD_GEMM_X")) : 0;
+    static const int xmode = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
     const int ng = choose_ng(M, K, tiles_n, total, resident);
-    static const int mfma_sel = getenv("SCD_GEMM_MFMA") ? atoi(getenv("SCD_GEMM_MFMA")) : 4;   // 4: four-wave kernel (default); 16 / 32: eight-wave kernels
-    const bool mfma16 = mfma_sel == 16;
+#ifdef SCD_ABLATE
+    static const int mfma_sel = SCD_ABLATE_ENV("SCD_GEMM_MFMA", 4);   // 4: four-wave kernel (default); 8 / 16 / 32: eight-wave kernels
     if (BM == 256 && mfma_sel == 4) return launch_w4<8, ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
     if (BM == 256 && mfma_sel == 8) return launch_w8<ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
-    if (BM == 256 && mfma16) {
+    if (BM == 256 && mfma_sel == 16) {
         { const int rc_ = scd_set_max_lds((const void*)gemm_dma16_kernel<ACT, B, RR>, 163840); if (rc_) return rc_; }
         gemm_dma16_kernel<ACT, B, RR><<<grid, 512, 163840, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
         return SCD_OK;
     }
     gemm_dma_kernel<BM, ACT, B, RR><<<grid, BM * 2, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
     return SCD_OK;
+#else
+    // default build: 256-row tiles go to the four-wave kernel; the eight-wave DMA kernel serves M % 256 == 128 only
+    if constexpr (BM == 256) {
+        return launch_w4<8, ACT, B, RR, 0>(A, W, bias, R, C, M, N, K, nullptr, st);
+    } else {
+        gemm_dma_kernel<BM, ACT, B, RR><<<grid, BM * 2, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng);
+        return SCD_OK;
+    }
+#endif
 }
 template <int BM, int ACT>
 static int launch_dma_act(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
@@ -1580,7 +1604,7 @@ int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const h
                 "gemm: shape m=%lld n=%d k=%d must be multiples of 128/128/64", (long long)M, N, K);
     SCD_REQUIRE(C != (half_t*)A, "gemm: C must not alias A");
     SCD_REQUIRE(act == SCD_ACT_NONE || act == SCD_ACT_QUICKGELU || act == SCD_ACT_GELU, "gemm: bad activation %d", act);
-    static const int force = getenv("SCD_GEMM_TILE") ? atoi(getenv("SCD_GEMM_TILE")) : 0;    // 64 -> legacy 128x128 kernel
+    static const int force = SCD_ABLATE_ENV("SCD_GEMM_TILE", 0);    // 64 -> legacy 128x128 kernel, 128 -> 128-row DMA kernel
     if (N % 256 == 0 && force != 64) {
         int rc = -1;
         // BM=256 (one 8-wave block per CU) measures a few % ahead of BM=128 (two 4-wave blocks per CU) on the ViT shapes
@@ -1600,6 +1624,7 @@ int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const h
 
 extern "C" int scd_gemm_f16(scd_handle h, const void* A, const void* W, const float* bias, const void* residual, void* C,
                             int64_t m, int n, int k, int act, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_gemm_f16");
     SCD_REQUIRE(h, "scd_gemm_f16: null handle");
     return scd_gemm_launch((const half_t*)A, (const half_t*)W, bias, (const half_t*)residual, (half_t*)C, m, n, k, act,
                            (hipStream_t)stream);

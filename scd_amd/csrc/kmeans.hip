@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) center_kernel(const float* __restrict__ X
 }
 
 extern "C" int scd_kmeans_prepare(scd_handle h, const float* X, int64_t n, int d, void* prep, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_prepare");
     SCD_REQUIRE(h && X && prep && n > 0 && d > 0, "scd_kmeans_prepare: bad arguments (n=%lld d=%d)", (long long)n, d);
     hipStream_t st = (hipStream_t)stream_;
     const int dp = dpad(d);
@@ -888,6 +889,13 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     SCD_REQUIRE(n > 0 && d > 0 && k > 0 && k < 32768 && n < (1ll << 31), "scd_kmeans_estep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
     SCD_REQUIRE(ws_bytes >= scd_kmeans_estep_ws_bytes(n, d, k), "scd_kmeans_estep: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
+    // one-shot hints and the finalize hand-over are consumed by THIS call whichever path it takes (left set by a call that took the
+    // legacy path, they would apply to an unrelated later call on the handle)
+    const bool few_hint = h->estep_few != 0;
+    const bool handover = h->prep_ok && h->prep_C == C && h->prep_ws == ws && h->prep_k == k && h->prep_d == d;
+    h->estep_few = 0;
+    h->prep_ok = 0;
+    h->prep_C = nullptr;
     const int dp = dpad(d), kp = kpad(k);
     char* w = (char*)ws;
     EHdr* eh = (EHdr*)w;
@@ -908,21 +916,19 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     if (use_stream && kp <= 2048 && dp <= 768) {
         // streaming filter (D <= 768): centre prep (unless scd_kmeans_finalize has just produced these very centres and their
         // operands into this workspace), one filter launch per 128 centres, refine; no memset
-        const bool prepared = h->prep_C == C && h->prep_ws == ws && h->prep_k == k && h->prep_d == d;
-        h->prep_C = nullptr;
+        const bool prepared = handover;
         if (!prepared) prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
         const long long g32 = (n + 31) / 32;               // units of 32 rows
         long long grid = g32 < h->n_cu ? g32 : h->n_cu;
         if (grid < scd_cdiv(g32, ES_RMAX / 32)) grid = scd_cdiv(g32, ES_RMAX / 32);
         const half_t* xh = (const half_t*)(p + xh_off);
         const float* xn = (const float*)(p + xnorm_off);
-        static const int es_dbg = getenv("SCD_ESTEP_DBG") ? atoi(getenv("SCD_ESTEP_DBG")) : 0;
-        static const int split = getenv("SCD_ESTEP_REFINE_SPLIT") ? atoi(getenv("SCD_ESTEP_REFINE_SPLIT")) : 0;   // 0: refine in the stream kernel's tail
+        static const int es_dbg = SCD_ABLATE_ENV("SCD_ESTEP_DBG", 0);
+        static const int split = SCD_ABLATE_ENV("SCD_ESTEP_REFINE_SPLIT", 0);   // 0: refine in the stream kernel's tail
         // refine in the stream kernel's tail only when the caller expects few flagged rows (scd_kmeans_estep_hint: Lloyd iterations
         // after the first two): with ~10 % of the rows flagged the one-block-per-CU tail takes 190 us where the refine kernel at
         // full occupancy takes 60-100; with none flagged the tail saves the launch (37 -> 31 us per call)
-        const bool tail = split == 0 && d <= 1024 && h->estep_few;
-        h->estep_few = 0;
+        const bool tail = split == 0 && d <= 1024 && few_hint;
 #define ES_LAUNCH(NCH)                                                                                                       \
     case NCH: {                                                                                                              \
         { const int rc_ = scd_set_max_lds((const void*)estep_stream_kernel<NCH>, ES_LDS); if (rc_) return rc_; }                                                                                                                    \
@@ -1005,6 +1011,7 @@ __global__ void __launch_bounds__(256) rowdist_kernel(const float* __restrict__ 
 
 extern "C" int scd_kmeans_rowdist(scd_handle h, const float* X, const float* C, const int32_t* labels, int64_t n, int d,
                                   int k, float* d2_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_rowdist");
     SCD_REQUIRE(h && X && C && labels && d2_out && n > 0 && d > 0 && k > 0, "scd_kmeans_rowdist: bad arguments");
     rowdist_kernel<false><<<(unsigned)scd_cdiv(n, 4), 256, 0, (hipStream_t)stream_>>>(X, C, labels, n, d, k, d2_out);
     SCD_LAUNCH_CHECK();
@@ -1015,6 +1022,7 @@ extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const f
                                            float* d2_inout, int64_t ld, void* stream_);
 extern "C" int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int64_t n, int d, float* d2_inout,
                                      void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_min_update");
     SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0, "scd_kmeans_min_update: bad arguments");
     return scd_kmeans_min_update_multi(h, X, c_new, n, d, 1, d2_inout, n, stream_);
 }
@@ -1052,6 +1060,7 @@ __global__ void __launch_bounds__(256) dist_kernel(const float* __restrict__ X, 
 
 extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int64_t n, int d, int k, int mode, float* out,
                                int32_t* cost_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_dist");
     SCD_REQUIRE(h && X && C && out && n > 0 && d > 0 && k > 0, "scd_kmeans_dist: bad arguments");
     dist_kernel<<<(unsigned)scd_cdiv(n, 16), 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
     SCD_LAUNCH_CHECK();
@@ -1122,6 +1131,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
 extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d,
                                    const float* C_old, float* C_out, double* shift_out, int shift_mode, const void* prep,
                                    void* estep_ws, size_t estep_ws_bytes, int64_t n, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_finalize");
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
     SCD_REQUIRE(k <= 32768, "scd_kmeans_finalize: k=%d > 32768", k);
@@ -1156,9 +1166,10 @@ extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64
     return SCD_OK;
 }
 
-extern "C" int scd_kmeans_estep_hint(scd_handle h, int expect_few_refined_rows) {
+extern "C" int scd_kmeans_estep_hint(scd_handle h, int flags) {
     SCD_REQUIRE(h, "scd_kmeans_estep_hint: null handle");
-    h->estep_few = expect_few_refined_rows != 0;
+    h->estep_few = (flags & SCD_ESTEP_FEW) != 0;
+    h->prep_ok = (flags & SCD_ESTEP_CENTRES_FROM_FINALIZE) != 0;
     return SCD_OK;
 }
 
@@ -1176,6 +1187,7 @@ __global__ void __launch_bounds__(256) labels_changed_kernel(const int* __restri
 }
 
 extern "C" int scd_labels_changed(scd_handle h, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_labels_changed");
     SCD_REQUIRE(h && a && b && out && n > 0, "scd_labels_changed: bad arguments");
     SCD_HIP(hipMemsetAsync(out, 0, 8, (hipStream_t)stream_));
     labels_changed_kernel<<<(unsigned)scd_cdiv(n, 1024), 256, 0, (hipStream_t)stream_>>>(a, b, n, (unsigned long long*)out);
@@ -1225,6 +1237,7 @@ __global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ x, 
 }
 
 extern "C" int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_sum_f32");
     SCD_REQUIRE(h && x && out && n > 0, "scd_sum_f32: bad arguments");
     sum_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(x, n, out);
     SCD_LAUNCH_CHECK();
@@ -1338,6 +1351,7 @@ __global__ void __launch_bounds__(1024) kpp_pick_kernel(const float* __restrict_
 
 extern "C" int scd_kpp_draw(scd_handle h, const float* d2, int64_t n, float r, const double* total, const double* prefix,
                             int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_draw");
     SCD_REQUIRE(h && d2 && (idx_out || probsum_out) && n > 0 && ws, "scd_kpp_draw: bad arguments");
     SCD_REQUIRE(ws_bytes >= scd_kpp_draw_ws_bytes(n), "scd_kpp_draw: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
@@ -1415,6 +1429,7 @@ __global__ void __launch_bounds__(1024) kpp_search_kernel(const float* __restric
 
 extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, const double* u, int n_draws, int64_t* idx_out,
                                     double* pot_out, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_searchsorted");
     SCD_REQUIRE(h && d2 && u && idx_out && n > 0 && n_draws > 0 && ws, "scd_kpp_searchsorted: bad arguments");
     SCD_REQUIRE(ws_bytes >= scd_kpp_draw_ws_bytes(n), "scd_kpp_searchsorted: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
@@ -1555,6 +1570,7 @@ static int minupd_launch(const float* X, const float* Cn, long long n, int d, in
 
 extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new, int64_t n, int d, int R,
                                            float* d2_inout, int64_t ld, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_min_update_multi");
     SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0 && R > 0 && ld >= n, "scd_kmeans_min_update_multi: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
     int r0 = 0;
@@ -1653,6 +1669,7 @@ __global__ void __launch_bounds__(1024) kpp_pick_multi_kernel(const float* __res
 extern "C" int scd_kpp_draw_multi(scd_handle h, const float* d2, int64_t n, int64_t ld, int R, const float* r_dev, const double* total,
                                   const double* prefix, int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes,
                                   void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_draw_multi");
     SCD_REQUIRE(h && d2 && r_dev && (idx_out || probsum_out) && n > 0 && ld >= n && R > 0 && ws, "scd_kpp_draw_multi: bad arguments");
     SCD_REQUIRE(ws_bytes >= (size_t)R * scd_kpp_draw_ws_bytes(n), "scd_kpp_draw_multi: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
@@ -1679,6 +1696,7 @@ __global__ void __launch_bounds__(1024) sum_multi_kernel(const float* __restrict
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_t ld, int R, double* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_sum_f32_multi");
     SCD_REQUIRE(h && x && out && n > 0 && ld >= n && R > 0, "scd_sum_f32_multi: bad arguments");
     sum_multi_kernel<<<R, 1024, 0, (hipStream_t)stream_>>>(x, n, ld, out);
     SCD_LAUNCH_CHECK();
@@ -1696,13 +1714,14 @@ extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void*
                                      const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
                                      float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,
                                      size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step");
     SCD_REQUIRE(h && X_u && prep_u && (X_cat || X16_cat) && labels_cat && C_in && C_out && sums && counts && stats && ws_e && ws_m,
                 "scd_kmeans_lloyd_step: null argument");
     SCD_REQUIRE(n_u > 0 && n_cat >= n_u && C_in != C_out, "scd_kmeans_lloyd_step: bad arguments (n_u=%lld n_cat=%lld)", (long long)n_u,
                 (long long)n_cat);
     const int64_t l_num = n_cat - n_u;
     int rc = SCD_OK;
-    if (expect_few) rc = scd_kmeans_estep_hint(h, 1);
+    rc = scd_kmeans_estep_hint(h, expect_few);
     if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
     if (!rc)
         rc = X16_cat ? scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream)

@@ -124,10 +124,10 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
                                                             unsigned long long* __restrict__ counts, double* __restrict__ inertia) {
     const int lane = threadIdx.x & 63;
     const long long s0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MSTEP_ROWS;
-    if (s0 >= n) return;
+    // (a wave past the end of the keys stays alive - empty row range, no run - so that every wave reaches the block barrier below)
     const long long s1 = s0 + MSTEP_ROWS < n ? s0 + MSTEP_ROWS : n;
-    double acc[MAXG];
-    float co[MAXG];
+    double acc[MAXG] = {};
+    float co[MAXG] = {};
     double in0 = 0.0, in1 = 0.0;
     int cur = -1;
     long long run = 0;
@@ -240,10 +240,10 @@ __global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __re
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const long long s0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * MSTEP_ROWS;
-    if (s0 >= n) return;
+    // (a wave past the end of the keys stays alive - empty row range, no run - so that every wave reaches the block barrier below)
     const long long s1 = s0 + MSTEP_ROWS < n ? s0 + MSTEP_ROWS : n;
-    double acc[MAXG2][2];
-    float co[MAXG2][2];
+    double acc[MAXG2][2] = {};
+    float co[MAXG2][2] = {};
     double in0 = 0.0, in1 = 0.0;
     int cur = -1;
     long long run = 0;
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __re
             flab[wv] = (cur >= 0 && cur < k) ? cur : -1;
             frun[wv] = run;
         }
-        __syncthreads();                 // (waves past the end of the keys have exited: they do not take part)
+        __syncthreads();
         const int nw = (int)(((n - (long long)blockIdx.x * 4 * MSTEP_ROWS) + MSTEP_ROWS - 1) / MSTEP_ROWS);
         const int lw = nw < 4 ? nw : 4;
         bool leader = flab[wv] >= 0;
@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(256) f16_exact_kernel(const float* __restrict_
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(inexact, 1);
 }
 extern "C" int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_f16_exact");
     SCD_REQUIRE(h && X && out16 && inexact_out && n_elems > 0 && n_elems % 4 == 0, "scd_f16_exact: bad arguments (n_elems % 4 != 0?)");
     SCD_HIP(hipMemsetAsync(inexact_out, 0, 4, (hipStream_t)stream_));
     f16_exact_kernel<<<(unsigned)scd_cdiv(n_elems / 4, 256), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out);
@@ -384,12 +385,14 @@ static int mstep_impl(scd_handle h, const float* X, const half_t* X16, const int
 extern "C" int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const float* C_old, int64_t n, int d,
                                 int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
                                 size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_mstep");
     SCD_REQUIRE(X, "scd_kmeans_mstep: null X");
     return mstep_impl(h, X, nullptr, labels, C_old, n, d, k, split, sums, counts, inertia, ws, ws_bytes, stream_);
 }
 extern "C" int scd_kmeans_mstep_f16(scd_handle h, const void* X16, const int32_t* labels, const float* C_old, int64_t n, int d,
                                     int k, int64_t split, double* sums, int64_t* counts, double* inertia, void* ws,
                                     size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_mstep_f16");
     SCD_REQUIRE(X16 && d % 2 == 0, "scd_kmeans_mstep_f16: null X16 or odd d");
     return mstep_impl(h, nullptr, (const half_t*)X16, labels, C_old, n, d, k, split, sums, counts, inertia, ws, ws_bytes, stream_);
 }

@@ -331,6 +331,7 @@ __device__ __forceinline__ double rb_max64(double a, double b) { double d; asm("
 __device__ __forceinline__ double rb_min64(double a, double b) { double d; asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 #define RB_NEG -3.0e38f                    /* masks padded names: finite, so that widening + index bits stays a number */
 
+#ifdef SCD_ABLATE   // the four-wave predecessor (SCD_SIM_RB=1): kept for A/B runs, not in the default build
 template <bool SOFTMAX, int TM, int XM = 0>          // XM: timing ablations (1 no epilogue pieces, 2 no ring fills, 4 no MFMAs; results are wrong)
 __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
                                                           long long v, float scale, float* __restrict__ cand_val,
@@ -621,6 +622,8 @@ __global__ void __launch_bounds__(256) sim_topk_rb_kernel(const half_t* __restri
 #undef RB_MFMA
 #undef RB_MFMA0
 }
+
+#endif  // SCD_ABLATE
 
 // ------------------------------------------------------------------------------------------------
 // Eight-wave row-block kernel (round 3; default at d == 512).  Same unit structure, ring, keys and lists as sim_topk_rb_kernel,
@@ -1894,7 +1897,14 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
-    static const int use_rb = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 16;     // 16: 16x16x32 tiles for k <= 3, 8: eight-wave 32x32x16 kernel, 1: four-wave, 0: tile kernel
+    // SCD_SIM_RB: 16 (default) = 16x16x32 tiles for k <= 3 and the eight-wave 32x32x16 kernel above that, 8 = the latter for every k;
+    // with -DSCD_ABLATE also 1 = four-wave predecessor, 0 = tile kernel, and SCD_SIM_X = timing ablations (results are wrong)
+    static const int use_rb_env = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 16;
+#ifdef SCD_ABLATE
+    const int use_rb = use_rb_env;
+#else
+    const int use_rb = use_rb_env == 8 ? 8 : 16;
+#endif
     const bool sm = mode == SCD_SIM_SOFTMAX;
     if (use_rb && d == 512 && v < (1ll << 28)) {
         // row-block kernels (the CLIP width): units of 32 names x K = 512, epilogue hidden behind the next unit's MFMAs
@@ -1903,12 +1913,6 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         if (refine4) sim_refine4_kernel<SM, TMV><<<(unsigned)scd_cdiv(n, 16), 256, 0, st>>>(f, wt, n, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV, nullptr, 2); \
         else sim_refine_kernel<SM, TMV><<<g2, 256, 0, st>>>(f, wt, n, d, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, KSV); \
         { const int rc_ = sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; }
-#define RB_GO(SM, TMV)                                                                                                          \
-    {                                                                                                                           \
-        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
-        sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                             \
-        RB_TAIL(SM, TMV, -1)                                                                                                    \
-    }
 #define RC_GO(SM, TMV, KSV)                                                                                                     \
     {                                                                                                                           \
         { const int rc_ = scd_set_max_lds((const void*)sim_topk_rc_kernel<SM, TMV, KSV, 0>, 131072); if (rc_) return rc_; }         \
@@ -1922,45 +1926,54 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         sim_topk_rb8_kernel<SM, TMV, KSV><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits);     \
         RB_TAIL(SM, TMV, KSV)                                                                                                   \
     }
-        static const int sim_x_rb = getenv("SCD_SIM_X") ? atoi(getenv("SCD_SIM_X")) : 0;
-        if (sim_x_rb) {                                          // timing ablations of the raw TM = 8 kernels (tools/sim_bench.py)
+#ifdef SCD_ABLATE
+#define RB_GO(SM, TMV)                                                                                                          \
+    {                                                                                                                           \
+        { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<SM, TMV, 0>, 131072); if (rc_) return rc_; }              \
+        sim_topk_rb_kernel<SM, TMV><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats);                             \
+        RB_TAIL(SM, TMV, -1)                                                                                                    \
+    }
+        static const int sim_x_rb = SCD_ABLATE_ENV("SCD_SIM_X", 0);
+        if (sim_x_rb) {                                          // timing ablations of the raw kernels (tools/sim_bench.py): kernel only, no refine
             switch (sim_x_rb + (use_rb == 8 ? 1000 : use_rb == 16 ? 2000 : 0)) {
 #define RC_X(X) case 2000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rc_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rc_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, bnd, &hdr->wmax2_bits); break;
-                RC_X(1) RC_X(3) RC_X(64) RC_X(1024)
-#undef RC_X
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
 #define RB8_X(X) case 1000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb8_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); break;
+                RC_X(1) RC_X(3) RC_X(64) RC_X(1024)
                 RB_X(1) RB_X(3) RB_X(4)
-                RB8_X(1) RB8_X(3) RB8_X(64)
+                RB8_X(1) RB8_X(3) RB8_X(64) RB8_X(1024)
+#undef RC_X
 #undef RB_X
 #undef RB8_X
             }
             SCD_LAUNCH_CHECK();
             return SCD_OK;
         }
+        if (use_rb == 1) {
+            // k == 1: two half lists of 4; k >= 2: 8 (certification needs margin, see DESIGN.md)
+            if (k == 1) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
+            else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
+        } else
+#undef RB_GO
+#endif
         if (use_rb == 16 && k <= 3) {
             // 16x16x32 tiles, four quarter lists per image: TM = k + 2 entries each, the best four leave the kernel
             if (k == 1) { if (sm) RC_GO(true, 3, 0) else RC_GO(false, 3, 0) }
             else { if (sm) RC_GO(true, 5, 2) else RC_GO(false, 5, 2) }
-        } else if (use_rb >= 8) {
+        } else {
             // entries per half list TM >= k + 2 (a row fails its certificate only when one half holds the image's TM + 1 best and two
             // gaps among them are inside the error bound); KS + 1 >= k: the entry of the other half's list the shared threshold uses
             if (k == 1) { if (sm) RB8_GO(true, 4, 0) else RB8_GO(false, 4, 0) }
             else if (k <= 3) { if (sm) RB8_GO(true, 5, 2) else RB8_GO(false, 5, 2) }
             else if (k <= 5) { if (sm) RB8_GO(true, 8, 4) else RB8_GO(false, 8, 4) }
             else { if (sm) RB8_GO(true, 8, 7) else RB8_GO(false, 8, 7) }
-        } else {
-            // k == 1: two half lists of 4; k >= 2: 8 (certification needs margin, see DESIGN.md)
-            if (k == 1) { if (sm) RB_GO(true, 4) else RB_GO(false, 4) }
-            else { if (sm) RB_GO(true, 8) else RB_GO(false, 8) }
         }
 #undef RB8_GO
 #undef RC_GO
 #undef RB_TAIL
-#undef RB_GO
         if (fallback_rows_out) SCD_HIP(hipMemcpyAsync(fallback_rows_out, &hdr->fb_cnt, 4, hipMemcpyDeviceToDevice, st));
         SCD_LAUNCH_CHECK();
         return SCD_OK;
@@ -1996,6 +2009,7 @@ __global__ void __launch_bounds__(256) transpose_f16_kernel(const half_t* __rest
     }
 }
 extern "C" int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_t c, void* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_transpose_f16");
     SCD_REQUIRE(h && in && out && r > 0 && c > 0, "scd_transpose_f16: bad arguments");
     transpose_f16_kernel<<<dim3((unsigned)scd_cdiv(c, 64), (unsigned)scd_cdiv(r, 64)), 256, 0, (hipStream_t)stream_>>>(
         (const half_t*)in, r, c, (half_t*)out);
@@ -2017,6 +2031,7 @@ __global__ void __launch_bounds__(256) mean2_f16_kernel(const half_t* __restrict
     *(half8*)(out + i * 8) = o;
 }
 extern "C" int scd_mean2_f16(scd_handle h, const void* a, const void* b, int64_t n_elems, void* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_mean2_f16");
     SCD_REQUIRE(h && a && b && out && n_elems > 0 && n_elems % 8 == 0, "scd_mean2_f16: bad arguments (n_elems must be a multiple of 8)");
     mean2_f16_kernel<<<(unsigned)scd_cdiv(n_elems / 8, 256), 256, 0, (hipStream_t)stream_>>>((const half_t*)a, (const half_t*)b,
                                                                                            n_elems / 8, (half_t*)out);
@@ -2033,6 +2048,7 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const half_t* __restri
 }
 extern "C" int scd_gather_rows_f16(scd_handle h, const void* Wt, const int64_t* idx, int64_t m, int d, void* out,
                                    void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_gather_rows_f16");
     SCD_REQUIRE(h && Wt && idx && out && m > 0 && d > 0, "scd_gather_rows_f16: bad arguments");
     gather_rows_kernel<<<(unsigned)scd_cdiv(m, 4), 256, 0, (hipStream_t)stream_>>>((const half_t*)Wt, (const long long*)idx, m,
                                                                                  d, (half_t*)out);
@@ -2056,6 +2072,7 @@ __global__ void __launch_bounds__(256) l2norm_kernel(const T* __restrict__ x, lo
     for (int j = lane; j < d; j += 64) out[row * d + j] = (T)((float)x[row * d + j] * inv);
 }
 extern "C" int scd_l2norm_rows(scd_handle h, const void* x, int dtype, int64_t n, int d, void* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_l2norm_rows");
     SCD_REQUIRE(h && x && out && n > 0 && d > 0, "scd_l2norm_rows: bad arguments");
     const unsigned g = (unsigned)scd_cdiv(n, 4);
     if (dtype == SCD_F32) l2norm_kernel<float><<<g, 256, 0, (hipStream_t)stream_>>>((const float*)x, n, d, (float*)out);
@@ -2115,6 +2132,7 @@ __global__ void __launch_bounds__(256) prompt_pool_kernel(const half_t* __restri
 }
 extern "C" int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t_per, int d, int64_t col0, int64_t ld_out,
                                void* out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_prompt_pool");
     SCD_REQUIRE(h && emb && out && n_names > 0 && t_per > 0 && d > 0 && d <= 1024, "scd_prompt_pool: bad arguments");
     prompt_pool_kernel<<<n_names, 256, 0, (hipStream_t)stream_>>>((const half_t*)emb, n_names, t_per, d, col0, ld_out, (half_t*)out);
     SCD_LAUNCH_CHECK();

@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64) vote_out_kernel(const unsigned long long* 
 extern "C" int scd_vote_hist(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int top_k, const int64_t* preds,
                              const int64_t* clusters, int n_clusters, const int64_t* known, int n_known, int m,
                              int64_t* keys_out, int32_t* counts_out, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_vote_hist");
     SCD_REQUIRE(h && name_idx && preds && clusters && keys_out && counts_out && ws, "scd_vote_hist: null argument");
     SCD_REQUIRE(n > 0 && top_k > 0 && top_k <= ld && m > 0, "scd_vote_hist: bad shape");
     SCD_REQUIRE(n_clusters > 0 && n_clusters <= VOTE_MAX_CLUSTER_ID, "scd_vote_hist: bad n_clusters");

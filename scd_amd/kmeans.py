@@ -302,17 +302,24 @@ class KMeansEngine:
         self.stats["estep_calls"] += 1
         return self._be().estep(data, centers, expect_few=it >= 2), None
 
-    def _lloyd(self, data_u, cat, labels, l_num, centers):
+    def _per_fit(self, data_u, cat):
+        """What one fit()/fit_mix() call derives from its data and hands to every restart: the exact fp16 copy of the rows the
+        M-step streams (None when a value does not survive the round trip) and the fused Lloyd-step buffers.  Built per CALL and
+        passed down - never cached on the engine under a data pointer: X may be rewritten in place between two fits, and a freed
+        `cat` is usually re-allocated at the same address."""
+        be = self._be()
+        cat16 = be.exact_f16(cat) if hasattr(be, "exact_f16") else None
+        bufs = None
+        if (not self.constrained and cat.is_cuda and self._dist() is None and hasattr(be, "lloyd_buffers")):
+            bufs = be.lloyd_buffers(data_u, cat, cat16, self.k)
+        return dict(cat16=cat16, bufs=bufs)
+
+    def _lloyd(self, data_u, cat, labels, l_num, centers, cat16=None, bufs=None):
         """Iterations shared by fit_once / fit_mix_once (sskm_constrained.py:110-138)."""
         be = self._be()
         dd = self._dist()
-        key = (cat.data_ptr(), tuple(cat.shape))
-        if getattr(self, "_cat16_key", None) != key:            # once per data set: the M-step streams an fp16 copy when it is exact
-            self._cat16 = be.exact_f16(cat) if hasattr(be, "exact_f16") else None
-            self._cat16_key = key
-        cat16 = self._cat16
         if not self.constrained and cat.is_cuda:
-            return self._lloyd_pipelined(data_u, cat, cat16, labels, l_num, centers)
+            return self._lloyd_pipelined(data_u, cat, cat16, labels, l_num, centers, bufs)
         best = (None, None, None)
         it = 0
         for it in range(self.max_iterations):
@@ -338,7 +345,7 @@ class KMeansEngine:
                 break
         return best[0], best[1], best[2], it + 1
 
-    def _lloyd_pipelined(self, data_u, cat, cat16, labels, l_num, centers):
+    def _lloyd_pipelined(self, data_u, cat, cat16, labels, l_num, centers, bufs=None):
         """The same iterations with the host one iteration behind the device: iteration i + 1 is launched (from iteration i's
         centres, which is what the sequential loop would use if i has not converged) before iteration i's {inertia, shift} are
         read back through a pinned buffer; if i turns out to have converged, i + 1 is dropped unseen.  The device never idles
@@ -357,11 +364,7 @@ class KMeansEngine:
         # of an iteration (185 us) otherwise exceeds its device time (105 us)
         fused = None
         if dd is None and hasattr(be, "lloyd_buffers"):
-            key = (data_u, cat.data_ptr(), self.k)
-            if getattr(self, "_lloyd_key", None) != key:
-                self._lloyd_buf = be.lloyd_buffers(data_u, cat, cat16, self.k)
-                self._lloyd_key = key
-            fused = self._lloyd_buf
+            fused = bufs if bufs is not None else be.lloyd_buffers(data_u, cat, cat16, self.k)
             fused.lab32[:l_num] = labels[:l_num]
             fused.c0.copy_(centers)
             centers = fused.c0              # iteration 0 reads the run's own start buffer and writes set 0
@@ -414,7 +417,7 @@ class KMeansEngine:
         return best[0].to(labels.dtype), best[1], best[2], n_done
 
     # ------------------------------------------------------------------ reference API
-    def fit_once(self, X, random_state, data=None, init_centers=None):
+    def fit_once(self, X, random_state, data=None, init_centers=None, cat16=None, bufs=None):
         be = self._be()
         if data is None:
             data = be.prepare(X)
@@ -433,9 +436,10 @@ class KMeansEngine:
         else:
             centers = x[: self.k].clone()
         labels = torch.empty(len(x), dtype=torch.int64, device=x.device)
-        return self._lloyd(data, x, labels, 0, centers)
+        return self._lloyd(data, x, labels, 0, centers, cat16, bufs)
 
-    def fit_mix_once(self, u_feats, l_feats, l_targets, random_state, data=None, cat=None, init_centers=None, l_rank=None):
+    def fit_mix_once(self, u_feats, l_feats, l_targets, random_state, data=None, cat=None, init_centers=None, l_rank=None, cat16=None,
+                     bufs=None):
         be = self._be()
         if data is None:
             data = be.prepare(u_feats)
@@ -450,7 +454,7 @@ class KMeansEngine:
         labels = torch.empty(len(cat), dtype=torch.int64, device=u.device)
         labels[:l_num] = l_rank
         centers = init_centers if init_centers is not None else self.kpp(u, l_centers, k=self.k, random_state=random_state, data=data)
-        lab, inertia, cent, _ = self._lloyd(data, cat, labels, l_num, centers)
+        lab, inertia, cent, _ = self._lloyd(data, cat, labels, l_num, centers, cat16, bufs)
         # reference quirk: returns `i + 1` with i the stale labelled-row index (sskm_constrained.py:104,139)
         return lab, inertia, cent, l_num
 
@@ -476,7 +480,7 @@ class KMeansEngine:
             def inits(rs):
                 c = self.kpp_lockstep(data, None, self.k, rs, self.n_init)
                 return [dict(init_centers=c[j]) for j in range(self.n_init)]
-        self._run(self.fit_once, X, data=data, inits=inits)
+        self._run(self.fit_once, X, data=data, inits=inits, **self._per_fit(data, data.x))
 
     def fit_mix(self, u_feats, l_feats, l_targets):
         data = self._be().prepare(u_feats)
@@ -488,7 +492,7 @@ class KMeansEngine:
                 _, l_rank, l_centers = self._class_means(l, l_targets.to(data.x.device))
                 c = self.kpp_lockstep(data, l_centers, self.k, rs, self.n_init)
                 return [dict(init_centers=c[j], l_rank=l_rank) for j in range(self.n_init)]
-        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat, inits=inits)
+        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat, inits=inits, **self._per_fit(data, cat))
         self.cluster_centers_ = self.cluster_centers_.type_as(u_feats) if torch.is_floating_point(u_feats) else self.cluster_centers_
 
 

@@ -7,6 +7,8 @@ back to torch math - a missing library or device raises.
 import ctypes as C
 
 import numpy as np
+import weakref
+
 import torch
 
 from . import _lib
@@ -114,6 +116,10 @@ def prompt_pool(emb, n_names, t_per, out, col0):
 
 
 # ----------------------------------------------------------------------------- k-means
+ESTEP_FEW, ESTEP_CENTRES_FROM_FINALIZE = 1, 2       # include/scd_hip.h
+_LAST_FINALIZE = {}                                  # "c": (weakref to the centres kmeans_finalize returned, their _version, the KMeansData)
+
+
 class KMeansData:
     """X (float32 [n,d], device) plus the prepared fp16 E-step operand."""
 
@@ -135,9 +141,14 @@ class KMeansData:
         """expect_few: few rows are expected inside the filter's error bound (late Lloyd iterations): they are re-evaluated in
         the filter kernel's tail, no refine launch.  Same labels either way."""
         _need_cuda(self.x)
-        if expect_few:
-            check(_L().scd_kmeans_estep_hint(handle(), 1))
         k = centers.shape[0]
+        # the hand-over of kmeans_finalize(data=self) is used only for the very tensor it returned, unmodified since (torch counts
+        # in-place writes in `_version`): a matching address alone proves nothing, the allocator recycles addresses
+        last = _LAST_FINALIZE.get("c")
+        vouch = last is not None and last[0]() is centers and last[1] == centers._version and last[2] is self
+        _LAST_FINALIZE.pop("c", None)
+        flags = (ESTEP_FEW if expect_few else 0) | (ESTEP_CENTRES_FROM_FINALIZE if vouch else 0)
+        check(_L().scd_kmeans_estep_hint(handle(), flags))
         centers = centers.to(torch.float32).contiguous()
         labels = torch.empty(self.n, dtype=torch.int32, device=self.x.device)
         ref = torch.zeros(1, dtype=torch.int32, device=self.x.device) if return_refined else None     # (a fill launch otherwise)
@@ -226,9 +237,12 @@ class LloydBuffers:
 
     def step(self, c_in, c_out, stats, expect_few):
         d = self.data
+        # c_in is c0 (a fresh copy: no hand-over registered for it) or the buffer the previous step wrote - these buffers are private
+        # to this object, nothing else writes them
+        flags = (ESTEP_FEW if expect_few else 0) | ESTEP_CENTRES_FROM_FINALIZE
         check(_L().scd_kmeans_lloyd_step(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat), ptr(self.cat16), self.cat.shape[0],
                                          d.d, self.k, ptr(self.lab32), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
-                                         ptr(stats), 1 if expect_few else 0, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m,
+                                         ptr(stats), flags, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m,
                                          stream_ptr()))
 
 
@@ -245,6 +259,10 @@ def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):
         prep, ws, n = data.prep, data.ws(("e", k), nb), data.n
     check(_L().scd_kmeans_finalize(handle(), ptr(sums), ptr(counts), k, d, ptr(c_old), ptr(c), ptr(shift), int(shift_mode),
                                    ptr(prep), ptr(ws), nb, n, stream_ptr()))
+    if data is not None and data.d == d:
+        _LAST_FINALIZE["c"] = (weakref.ref(c), c._version, data)
+    else:
+        _LAST_FINALIZE.pop("c", None)
     return c, shift
 
 

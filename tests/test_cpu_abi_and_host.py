@@ -44,6 +44,17 @@ def test_no_torch_types_in_abi():
                                             capture_output=True, text=True).stdout
 
 
+def test_default_library_has_no_ablation_switches():
+    """Timing ablations (kernels with pieces removed: wrong results) and the A/B kernels of earlier rounds exist only in the
+    -DSCD_ABLATE build (`python -m scd_amd.build --ablate`): the shipped library neither reads those variables nor contains the
+    code behind them."""
+    blob = open(os.path.join(ROOT, "scd_amd", "lib", "libscd_hip.so"), "rb").read()
+    for name in (b"SCD_GEMM_X", b"SCD_SIM_X", b"SCD_ATTN_X", b"SCD_ESTEP_DBG", b"SCD_ESTEP_REFINE_SPLIT", b"SCD_GEMM_MFMA", b"SCD_GEMM_TILE"):
+        assert name not in blob, name
+    for kern in (b"gemm_w8_kernel", b"gemm_dma16_kernel", b"sim_topk_w4_kernel", b"sim_topk_rb_kernel"):
+        assert kern not in blob, kern
+
+
 def test_product_does_not_import_oracle():
     bad = []
     for dp, _, fs in os.walk(os.path.join(ROOT, "scd_amd")):

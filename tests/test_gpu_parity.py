@@ -13,6 +13,7 @@ from oracle import clip_oracle as co
 from oracle import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -554,6 +555,33 @@ def test_sim_topk_shapes(ops, n, v, d, k):
     assert int(fb.item()) <= n // 20
     a, av = ops.sim_argmax(dev(f), wt)
     assert np.array_equal(a.cpu().numpy(), oi[:, 0])
+
+
+def test_ablation_variables_change_nothing_in_the_default_library():
+    """SCD_GEMM_X / SCD_SIM_X / SCD_ATTN_X / SCD_ESTEP_DBG removed kernel pieces (wrong results) in rounds 1-2; the default build
+    ignores them: a child process with all of them set returns the oracle's top-k and labels."""
+    import subprocess
+    import sys
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from scd_amd import ops
+from oracle import naming_oracle as no, kmeans_oracle as ko, synth
+rs = np.random.RandomState(5)
+f = (rs.randn(300, 512) / 22.6).astype(np.float16); w = (rs.randn(512, 2100) / 22.6).astype(np.float16)
+wt = ops.transpose_f16(torch.from_numpy(w).cuda())
+idx, val = ops.sim_topk(torch.from_numpy(f).cuda(), wt, 3, "raw")
+oi, ov = no.sim_topk(f, w, 3, "raw")
+assert np.array_equal(idx.cpu().numpy(), oi)
+x, y, c = synth.clustered_features(3000, 768, 20, seed=3, center_seed=4, noise=0.8)
+lab = ops.KMeansData(torch.from_numpy(x).cuda()).estep(torch.from_numpy(c).cuda())
+assert np.array_equal(lab.cpu().numpy(), ko.estep(x, c)[0])
+print("same")
+""" % (ROOT,)
+    env = dict(os.environ, SCD_GEMM_X="16", SCD_SIM_X="1", SCD_ATTN_X="4", SCD_ESTEP_DBG="16", SCD_ESTEP_REFINE_SPLIT="2", SCD_SIM_RB="1")
+    env.pop("SCD_HIP_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("n", [3, 100, 300])

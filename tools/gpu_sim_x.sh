@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing ablations of the similarity kernels, both row-block kernels on the same box: tools/gpu_sim_x.sh "X values" [k]
 set -u
+[ -f scd_amd/lib/libscd_hip_ablate.so ] && export SCD_HIP_LIB=$PWD/scd_amd/lib/libscd_hip_ablate.so   # SCD_SIM_X needs the -DSCD_ABLATE build (python -m scd_amd.build --ablate)
 out=gpurun_out/sim_x; mkdir -p $out
 for x in $1; do
   for rb in ${RBS:-8 16}; do
