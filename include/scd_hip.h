@@ -85,6 +85,11 @@ int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, const float
  *                                     scd_kmeans_finalize on this handle (same buffer, NOT modified since, same E-step workspace):
  *                                     that call has already written the E-step's centre operands and the prep launch is skipped.
  *                                     Without the flag a matching pointer is not trusted (the address may have been recycled). */
+/* Measurement aid (bench.py): while enabled, the streaming filter launches of every scd_kmeans_estep on this handle - stand-alone
+ * or inside scd_kmeans_lloyd_step - are bracketed by HIP events on the launch stream (one pair per call; K > 128: the call's
+ * kp / 128 launches together).  Each call returns and clears what was collected: the calls' durations in milliseconds, in call
+ * order (the first `cap` of them), and their number; it synchronises on the recorded events. */
+int scd_kmeans_timing(scd_handle h, int enable, double* samples_ms_out, int cap, int* launches_out);
 #define SCD_ESTEP_FEW 1
 #define SCD_ESTEP_CENTRES_FROM_FINALIZE 2
 int scd_kmeans_estep_hint(scd_handle h, int flags);

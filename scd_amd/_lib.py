@@ -47,6 +47,7 @@ SIGNATURES = {
     "scd_kmeans_estep_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kmeans_estep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "scd_kmeans_estep_hint": (_i, [_vp, _i]),
+    "scd_kmeans_timing": (_i, [_vp, _i, _vp, _i, _vp]),
     "scd_kmeans_rowdist": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "scd_kmeans_dist": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "scd_kmeans_mstep_ws_bytes": (_sz, [_i64, _i, _i]),

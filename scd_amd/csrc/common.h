@@ -7,6 +7,11 @@
 #include <math.h>
 #include "../../include/scd_hip.h"
 
+#ifdef __cplusplus
+#include <utility>
+#include <vector>
+#endif
+
 struct scd_ctx {
     int device;
     int n_cu;
@@ -17,6 +22,10 @@ struct scd_ctx {
     const void* prep_ws;
     int prep_k, prep_d;
     int prep_ok;            // scd_kmeans_estep_hint(SCD_ESTEP_CENTRES_FROM_FINALIZE): the caller vouches that the next E-step's centres are prep_C's, unmodified
+    // scd_kmeans_timing: while enabled, the streaming E-step kernel launches of scd_kmeans_estep (hence of scd_kmeans_lloyd_step)
+    // are bracketed by HIP events on their launch stream
+    bool km_timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> km_ev;
     int estep_few;          // scd_kmeans_estep_hint: the next E-step re-evaluates its (few) flagged rows in the filter kernel's tail
 };
 #define SCD_SCRATCH_BYTES (262144 + 64)

@@ -938,10 +938,20 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
                                                                           (cb == 0 ? 1 : 0) | (cb == kp / 128 - 1 ? 2 : 0), tkey, tidx, cn, kp,  \
                                                                           tail ? X : nullptr, C, d, k);                       \
     } break;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->km_timing) {
+            SCD_HIP(hipEventCreate(&ev0));
+            SCD_HIP(hipEventCreate(&ev1));
+            SCD_HIP(hipEventRecord(ev0, st));
+        }
         switch (dp / 128) {
             ES_LAUNCH(1) ES_LAUNCH(2) ES_LAUNCH(3) ES_LAUNCH(4) ES_LAUNCH(5) ES_LAUNCH(6)
         }
 #undef ES_LAUNCH
+        if (h->km_timing) {
+            SCD_HIP(hipEventRecord(ev1, st));
+            h->km_ev.emplace_back(ev0, ev1);
+        }
         if (tail) {
             if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
         } else if (split == 2) {
@@ -1163,6 +1173,24 @@ extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64
                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr);
     }
     SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+extern "C" int scd_kmeans_timing(scd_handle h, int enable, double* samples_ms_out, int cap, int* launches_out) {
+    SCD_REQUIRE(h, "scd_kmeans_timing: null handle");
+    int i = 0;
+    for (auto& pr : h->km_ev) {
+        SCD_HIP(hipEventSynchronize(pr.second));
+        float t = 0.f;
+        SCD_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+        if (samples_ms_out && i < cap) samples_ms_out[i] = t;
+        ++i;
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    if (launches_out) *launches_out = i;
+    h->km_ev.clear();
+    h->km_timing = enable != 0;
     return SCD_OK;
 }
 

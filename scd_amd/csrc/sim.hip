@@ -1897,13 +1897,16 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
-    // SCD_SIM_RB: 16 (default) = 16x16x32 tiles for k <= 3 and the eight-wave 32x32x16 kernel above that, 8 = the latter for every k;
-    // with -DSCD_ABLATE also 1 = four-wave predecessor, 0 = tile kernel, and SCD_SIM_X = timing ablations (results are wrong)
-    static const int use_rb_env = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 16;
+    // SCD_SIM_RB: 8 (default) = the eight-wave 32x32x16 kernel with eight entries per half list for k >= 2; 16 = 16x16x32 tiles for
+    // k <= 3 (2-3 % faster on unstructured features, but its 16 candidates per image are the best four of four QUARTER lists: on
+    // features whose top logits crowd inside the error bound - the bench's synthetic images: 100 planted names within ~0.5 - a hundred
+    // rows per call fail their certificate and the exact pass costs more than the tiles save); with -DSCD_ABLATE also 1 = four-wave
+    // predecessor, 0 = tile kernel, and SCD_SIM_X = timing ablations (results are wrong)
+    static const int use_rb_env = getenv("SCD_SIM_RB") ? atoi(getenv("SCD_SIM_RB")) : 8;
 #ifdef SCD_ABLATE
     const int use_rb = use_rb_env;
 #else
-    const int use_rb = use_rb_env == 8 ? 8 : 16;
+    const int use_rb = use_rb_env == 16 ? 16 : 8;
 #endif
     const bool sm = mode == SCD_SIM_SOFTMAX;
     if (use_rb && d == 512 && v < (1ll << 28)) {
@@ -1940,8 +1943,8 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
                         sim_topk_rc_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, bnd, &hdr->wmax2_bits); break;
 #define RB_X(X) case X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb_kernel<false, 8, X>, 131072); if (rc_) return rc_; } \
                         sim_topk_rb_kernel<false, 8, X><<<g1, 256, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats); break;
-#define RB8_X(X) case 1000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<false, 5, 2, X>, 131072); if (rc_) return rc_; } \
-                        sim_topk_rb8_kernel<false, 5, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); break;
+#define RB8_X(X) case 1000 + X: { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<false, 8, 2, X>, 131072); if (rc_) return rc_; } \
+                        sim_topk_rb8_kernel<false, 8, 2, X><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); break;
                 RC_X(1) RC_X(3) RC_X(64) RC_X(1024)
                 RB_X(1) RB_X(3) RB_X(4)
                 RB8_X(1) RB8_X(3) RB8_X(64) RB8_X(1024)
@@ -1967,7 +1970,7 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
             // entries per half list TM >= k + 2 (a row fails its certificate only when one half holds the image's TM + 1 best and two
             // gaps among them are inside the error bound); KS + 1 >= k: the entry of the other half's list the shared threshold uses
             if (k == 1) { if (sm) RB8_GO(true, 4, 0) else RB8_GO(false, 4, 0) }
-            else if (k <= 3) { if (sm) RB8_GO(true, 5, 2) else RB8_GO(false, 5, 2) }
+            else if (k <= 3) { if (sm) RB8_GO(true, 8, 2) else RB8_GO(false, 8, 2) }
             else if (k <= 5) { if (sm) RB8_GO(true, 8, 4) else RB8_GO(false, 8, 4) }
             else { if (sm) RB8_GO(true, 8, 7) else RB8_GO(false, 8, 7) }
         }

@@ -116,6 +116,15 @@ def prompt_pool(emb, n_names, t_per, out, col0):
 
 
 # ----------------------------------------------------------------------------- k-means
+def kmeans_timing(enable, cap=4096):
+    """HIP-event timing of the streaming E-step kernel inside scd_kmeans_estep / scd_kmeans_lloyd_step (measurement aid).
+    Returns the durations (ms, numpy, call order) collected since the last call and switches the collection on / off."""
+    buf = np.zeros(cap, dtype=np.float64)
+    cnt = C.c_int(0)
+    check(_L().scd_kmeans_timing(handle(), 1 if enable else 0, ptr(buf), cap, C.byref(cnt)))
+    return buf[: min(cnt.value, cap)].copy()
+
+
 ESTEP_FEW, ESTEP_CENTRES_FROM_FINALIZE = 1, 2       # include/scd_hip.h
 _LAST_FINALIZE = {}                                  # "c": (weakref to the centres kmeans_finalize returned, their _version, the KMeansData)
 

@@ -1,0 +1,97 @@
+"""One rank of the multi-GPU check (tests/test_gpu_parity.py::test_multi_rank_rccl): started N times by torch.distributed.run,
+one process per GPU, "nccl" (= RCCL) backend, every kernel through libscd_hip.so.  Each rank holds a contiguous, uneven row shard;
+the sharded results must equal what the same rank computes alone from the full data:
+  * sharded SSKM fit_mix (lock-step seeding over three all-gathers per round, one packed all-reduce per Lloyd iteration),
+  * the sharded vote loop,
+  * the C entry points scd_comm_init / scd_allreduce_centroids / scd_allgather_text over RCCL.
+Prints "rank R ok" and exits 0."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def shard(n, rank, world):
+    """contiguous, deliberately uneven: rank r owns [cut[r], cut[r+1])"""
+    w = np.arange(1, world + 1, dtype=np.float64) + 2.0
+    cut = np.concatenate([[0], np.round(np.cumsum(w) / w.sum() * n).astype(int)])
+    return slice(int(cut[rank]), int(cut[rank + 1]))
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from oracle import synth, naming_oracle as no
+    from scd_amd import ops, naming, pipeline
+    from scd_amd.kmeans import KMeansEngine
+    grp = dist.group.WORLD
+    # ---- (1) sharded SSKM == the same fit on one rank
+    n, d, k = 6000, 64, 12
+    x, y, mask_lab = synth.blob_case(n, d, k, 21)
+    u, l, lt = x[~mask_lab], x[mask_lab], y[mask_lab]
+    su, sl = shard(len(u), rank, world), shard(len(l), rank, world)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    one = KMeansEngine(k=k, max_iterations=6, n_init=3, random_state=3)
+    one.fit_mix(T(u), T(l), T(lt))
+    shd = KMeansEngine(k=k, max_iterations=6, n_init=3, random_state=3, group=grp)
+    shd.fit_mix(T(u[su]), T(l[sl]), T(lt[sl]))
+    n_l, n_ls = len(lt), sl.stop - sl.start
+    full = one.labels_.cpu().numpy()
+    mine = shd.labels_.cpu().numpy()
+    assert np.array_equal(mine[:n_ls], full[:n_l][sl]), "labelled rows"
+    assert np.array_equal(mine[n_ls:], full[n_l:][su]), "unlabelled rows: sharded labels differ from the single-rank fit"
+    # 1-GPU and N-GPU centres: the same float64 sums in a different order
+    assert np.allclose(shd.cluster_centers_.cpu().numpy(), one.cluster_centers_.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    cen = shd.cluster_centers_.contiguous()
+    ref = cen.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(cen, ref), "centres must be bit-identical on every rank"
+    # ---- (2) sharded vote loop == single-rank vote loop
+    nv, dv, kv, vv = 4800, 512, 12, 2100
+    xv, yv, cv = synth.clustered_features(nv, dv, kv, seed=31, center_seed=32, noise=0.9)
+    w = synth.vocabulary(vv, dv, cv, seed=33, jitter=0.5)
+    nouns = synth.nouns_list(vv)
+    f = T(xv.astype(np.float16))
+    wt = T(np.ascontiguousarray(w.T).astype(np.float16))
+    idx, _ = ops.sim_topk(f, wt, 5, "softmax")
+    rs = np.random.RandomState(35)
+    preds0 = T(np.where(rs.rand(nv) < 0.8, (yv * 7 + 2) % kv, rs.randint(0, kv, size=nv)).astype(np.int64))
+    cand1, up1, tr1 = naming.vote_loop_unsup(idx, preds0, f, wt, nouns, kv, 10, 2, max_iter=50)
+    sv = shard(nv, rank, world)
+    cand2, up2, tr2 = pipeline.vote_loop_unsup_sharded(idx[sv], preds0[sv], f[sv], wt, nouns, kv, 10, 2, grp, max_iter=50)
+    assert cand1 == cand2 and len(tr1) == len(tr2), "sharded vote loop: candidate names differ"
+    assert np.array_equal(np.asarray(up1)[sv], np.asarray(up2)), "sharded vote loop: re-classified rows differ"
+    # ---- (3) the C entry points over RCCL
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(ops.Comm.unique_id()), dtype=torch.uint8).to(dev)
+    dist.broadcast(uid, 0)
+    comm = ops.Comm(rank, world, bytes(uid.cpu().numpy().tobytes()))
+    try:
+        xk, yk, ck = synth.clustered_features(5000, 64, 7, seed=5)
+        sk = shard(5000, rank, world)
+        sums, counts, inertia = ops.kmeans_mstep(T(xk[sk]), T(yk[sk].astype(np.int32)), T(ck), 7, 0)
+        s2, c2, i2 = comm.allreduce_centroids(sums, counts, inertia)
+        fs, fc, fi = ops.kmeans_mstep(T(xk), T(yk.astype(np.int32)), T(ck), 7, 0)
+        assert torch.equal(c2, fc) and torch.allclose(s2, fs, rtol=1e-12, atol=1e-12) and torch.allclose(i2, fi, rtol=1e-12)
+        rows = 8 * world
+        wfull = np.random.RandomState(0).randn(rows, 512).astype(np.float16)
+        got = comm.allgather_text(T(wfull[8 * rank: 8 * rank + 8]))
+        assert torch.equal(got, T(wfull)), "scd_allgather_text: rank order"
+    finally:
+        comm.close()
+    torch.cuda.synchronize()
+    dist.barrier()
+    print("rank %d ok" % rank, flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -745,6 +745,36 @@ def test_dino_tower_matches_oracle(ops):
     assert out.shape == (3, 768) and _cos(out, ref).min().item() > 1 - 1e-3
 
 
+def test_dino_features_give_the_oracle_features_labels(ops):
+    """The DINO tower runs with fp16 activations where the reference runs fp32 (vision_transformer.py:135-219); what the features
+    are USED for is clustering (main_unsup.py:339-350).  On a class-structured synthetic image set the semi-supervised K-Means
+    labels computed from the HIP features equal the labels computed from the fp32 oracle's features, row for row, and the two
+    feature sets agree to cos > 1 - 1e-3 on every image."""
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import DinoViT
+    from scd_amd.kmeans import KMeansEngine
+    n_cls, per = 6, 12
+    sd = W.synthetic_dino_state_dict(seed=1, layers=12)
+    sd16 = {k: (v.half().float() if v.dim() >= 2 and "pos_embed" not in k and "cls_token" not in k else v) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(123)
+    base = torch.randn(n_cls, 3, 224, 224, generator=g)
+    y = np.repeat(np.arange(n_cls), per)
+    img = (base[torch.from_numpy(y)] + 0.6 * torch.randn(n_cls * per, 3, 224, 224, generator=g)).half().float()
+    hip = torch.nn.functional.normalize(DinoViT(sd).cuda()(img.cuda()).float(), dim=-1).cpu()
+    ref = torch.nn.functional.normalize(torch.cat([co.dino_forward(sd16, img[i:i + 12]) for i in range(0, len(img), 12)]).float(), dim=-1)
+    assert _cos(hip, ref).min().item() > 1 - 1e-3
+    rs = np.random.RandomState(3)
+    mask_lab = (y < n_cls // 2) & (rs.rand(len(y)) < 0.5)
+    labels = []
+    for feats in (hip, ref):
+        km = KMeansEngine(k=n_cls, tolerance=1e-4, max_iterations=10, n_init=10, random_state=0)
+        km.fit_mix(feats[~mask_lab].cuda(), feats[mask_lab].cuda(), torch.from_numpy(y[mask_lab]).cuda())
+        labels.append(km.labels_.cpu().numpy())
+    assert np.array_equal(labels[0], labels[1])
+    acc = (labels[0][int(mask_lab.sum()):] == y[~mask_lab]).mean()      # and the clustering is the planted one (cluster ids of the
+    assert acc > 0.45                                                  # labelled half are class ids; the novel half is permuted)
+
+
 def test_zeroshot_classifier_pooling(ops):
     from scd_amd.local_utils import clip_lang_util as clu
     from scd_amd.clip import weights as W
@@ -1207,3 +1237,24 @@ def test_rccl_entry_points_single_rank(ops):
         assert torch.equal(comm.allgather_text(w), w)
     finally:
         comm.close()
+
+
+def test_multi_rank_rccl(ops):
+    """One process per visible GPU (at most 8), RCCL: sharded SSKM, sharded vote loop and the C collectives equal the
+    single-rank results (tests/dist_rccl_worker.py).  The ranks are fresh CHILD processes started through
+    torch.distributed.run (never an exec of this process).  On a one-GPU box the same worker runs as a world of one: the
+    script and the nccl backend are exercised, the exchange pattern itself is then covered by tests/test_dist_gloo.py."""
+    import socket
+    import subprocess
+    import sys
+    n = max(1, min(torch.cuda.device_count(), 8))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_rccl_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    for rank in range(n):
+        assert "rank %d ok" % rank in r.stdout
