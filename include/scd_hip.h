@@ -123,8 +123,9 @@ int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts,
 /* One whole Lloyd iteration of the unconstrained K-Means (faster_mix_k_means_pytorch.py:187-214) = scd_kmeans_estep on the n_u
  * unlabelled rows (labels_cat[n_cat - n_u ...] written; the first n_cat - n_u entries are the labelled rows' fixed cluster ids) +
  * scd_kmeans_mstep[_f16] over the n_cat rows [labelled ; unlabelled] (X16_cat: their exact fp16 copy, or NULL) + scd_kmeans_finalize
- * with the hand-over of the next E-step's centre operands, behind one call.  stats: device double [3] = {inertia labelled,
- * inertia unlabelled, centre shift}.  C_out must differ from C_in; ws_e / ws_m as for the single calls. */
+ * with the hand-over of the next E-step's centre operands, behind one call.  stats: device double [4] = {inertia labelled,
+ * inertia unlabelled, centre shift, rows the E-step re-evaluated exactly}.  `expect_few`: SCD_ESTEP_* flags for this step's
+ * E-step.  C_out must differ from C_in; ws_e / ws_m as for the single calls. */
 int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,
                           const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
                           float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,

@@ -83,6 +83,15 @@ static inline size_t scd_align(size_t x, size_t a = 256) { return (x + a - 1) / 
 static inline int64_t scd_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 #ifdef __HIPCC__
+#include <type_traits>
+// compile-time loop: f(std::integral_constant<int, S>) for S = B .. E-1 (asm immediates need constant expressions)
+template <int B, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 __host__ __device__ __forceinline__ long long scd_cdiv_dev(long long a, long long b) { return (a + b - 1) / b; }
 // ---- wavefront (64 lanes) reductions ----
 __device__ __forceinline__ double wave_sum_f64(double v) {

@@ -764,6 +764,224 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
     for (int i = tid; i < cnts[1]; i += 256) full_list[cnts[3] + i] = l_full[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-pass filter for 128 < K <= 2048 at Dp = 512 (BASELINE C4: K = 1000, CLIP features; round 3).  The streaming kernel above
+// keeps 128 centres in registers and re-reads X once per 128 centres (8 passes over X at K = 1000: 350 us for 164 MB of
+// algorithmic bytes, 0.19 of the MFMA peak - and at K = 1000 the E-step is matrix-bound).  Here the roles are swapped,
+// in the structure of sim_topk_rb8_kernel: a block keeps 256 ROWS of x' in registers (eight waves, two per SIMD, 32 rows each as B
+// fragments in 128 AGPRs) and the centres stream past them ONCE, in units of 32 centres x 512 columns through the 4-slot LDS-DMA ring
+// (one 1-KB row per instruction, 16-B chunk c of row r at chunk c ^ (r & 15)); the whole centre matrix is 1 MB and stays in L2.
+//   * score: the 33rd MFMA of a unit multiplies the centres' extension column (||c'||^2 / 2 as an fp16 pair hi + lo, 16 bytes per
+//     centre in LDS behind the ring) with a constant -1 fragment, so an accumulator ends as x'.c' - ||c'||^2 / 2 (maximal where the
+//     distance is minimal) and no per-unit norm vector has to reach the lanes;
+//   * selection: every value becomes a key (low 11 mantissa bits = centre index) and goes through a max / med3 / min network that
+//     keeps the lane's three LARGEST keys over all units - 6 instructions per value, dealt over the 32 MFMA steps of the next
+//     unit, no branches, no lists; lanes r / r + 32 merge at the end;
+//   * decisions as in estep_stream_kernel: label = best key's centre; a row whose first two scores are within 2 E goes to the pair
+//     list (third outside 2 E) or to the all-centres list; estep_refine_both_kernel re-evaluates them in float64.
+// Error bound: that of the streaming kernel with the key term for 11 index bits (2^-12 of |x'.c' - ||c'||^2 / 2|) and 2^-22 ||c'||^2
+// for the hi + lo split.
+#define ERB_LDS (131072 + 32768)
+__device__ __forceinline__ void erb_insert(float& b0, float& b1, float& b2, float k) {       // descending triple (b0 >= b1 >= b2)
+    const float t = es_min(b1, k);
+    b2 = es_max(b2, t);
+    b1 = es_med3(b0, b1, k);
+    b0 = es_max(b0, k);
+}
+__global__ void __launch_bounds__(256) estep_ext_kernel(const float* __restrict__ cn, int kp, half_t* __restrict__ ext) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= kp) return;
+    const float v = cn[c];
+    // ||c'||^2 / 8, multiplied by -4 in the MFMA: |x'| < 16 gives ||c'||^2 / 2 <= 65,536, just past the fp16 range
+    float hv = 0.125f * v;
+    if (!(v < 3.0e38f)) hv = 60000.f;                            // dead centre (padding, NaN): never the best of a row
+    const half_t hi = (half_t)hv;
+    const half_t lo = (half_t)(hv - (float)hi);
+    half8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (half_t)0.f;
+    o[0] = hi;
+    o[1] = lo;
+    *(half8*)(ext + (size_t)c * 8) = o;
+}
+__global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
+                                                       const half_t* __restrict__ ch, const half_t* __restrict__ ext,
+                                                       const float* __restrict__ cn, EHdr* eh, int* flag_list, int* flag_cand,
+                                                       int* full_list, long long n, int kp, int32_t* __restrict__ labels) {
+    constexpr int D = 512, UB = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int nunits = kp >> 5;
+
+    // the extension column of every centre: 16 B per centre behind the ring
+    for (int c = tid; c < kp; c += 512) *(half8*)(smem + 4 * UB + c * 16) = *(const half8*)(ext + (size_t)c * 8);
+
+    half8 bf[32];
+    const long long row = (long long)blockIdx.x * 256 + wave * 32 + r;
+    {
+        const half_t* xr = xh + (row < n ? row : n - 1) * D + 8 * hh;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                              // eight fragments at a time (see sim_topk_rb8_kernel)
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) bf[s] = *(const half8*)(xr + 16 * s);
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) asm volatile("" : "+a"(bf[s]) : : "memory");
+        }
+    }
+    half8 bx;                                                    // B fragment of the extension step: -4 against (hi, lo) = ||c'||^2 / 8, lanes r only
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bx[q] = (half_t)((hh == 0 && q < 2) ? -4.f : 0.f);
+
+    const unsigned bsw = (unsigned)((lane ^ ((4 * wave) & 12)) << 4);
+    const half_t* fbase = ch;
+    unsigned fm0 = 0;
+    auto fill_unit = [&](int unit) {
+        fbase = ch + (size_t)unit * 32 * D;
+        fm0 = sbase + (unit & 3) * UB + 4 * wave * 1024;
+    };
+    auto fill = [&](int p) {
+        const unsigned off = (bsw ^ (unsigned)(p << 4)) + (unsigned)(4 * wave + p) * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(fm0 + p * 1024), "v"(off), "s"(fbase) : "memory");
+    };
+    unsigned fa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = sbase + (unsigned)(r * 1024 + ((32 * j) ^ (16 * (hh ^ (r & 15)))));
+    unsigned fxa = sbase + 4 * UB + (unsigned)(r * 16);          // extension fragment of unit 0, row r (both half-waves read it)
+
+#define ERB_RD(DST, J, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[J]), "n"(IMM))
+#define ERB_RDX(DST) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(fxa))
+#define ERB_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
+#define ERB_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define ERB_MFMAV(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define ERB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
+
+    float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;        // the lane's three largest keys
+    f32x16 acc[2];
+    half8 fr[4], fx;
+    using yes = std::true_type;
+    using no = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto body = [&](auto has_prev, auto parity, int u) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool EPI = decltype(has_prev)::value;
+        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = u + 1 < nunits;
+        const bool fills = u + 3 < nunits;
+        if (fills) fill_unit(u + 3);
+        const unsigned ub = (unsigned)((u - 1) * 32 + 4 * hh);    // centre index of value i of unit u - 1: ub + (i & 3) + 8 (i >> 2)
+        static_for<0, 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s == 29) {
+                const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[j] += delta;
+            }
+            if constexpr (s < 29) ERB_RD(fr[(s + 3) & 3], (s + 3) & 7, ((s + 3) >> 3) * 256);
+            else if (more) ERB_RD(fr[(s + 3) & 3], (s + 3 - 32) & 7, 0);
+            // the extension fragment of THIS unit is fetched at step 8 (one more read in flight for three waits) and used at step 20
+            if constexpr (s == 8) ERB_RDX(fx);
+            if constexpr (s >= 8 && s <= 10) ERB_WAIT(3, fr[(s + 1) & 3]);
+            else if (s < 29 || more) ERB_WAIT(2, fr[(s + 1) & 3]);
+            else if (s == 29) ERB_WAIT(1, fr[(s + 1) & 3]);
+            else if (s == 30) ERB_WAIT(0, fr[(s + 1) & 3]);
+            if (s == 0) ERB_MFMA0(acc[P], fr[s & 3], bf[s]);
+            else ERB_MFMA(acc[P], fr[s & 3], bf[s]);
+            if constexpr (s == 20) {
+                asm volatile("" : "+v"(fx));
+                ERB_MFMAV(acc[P], fx, bx);
+                fxa += 512;                                      // next unit's 32 extension entries
+            }
+            if ((s & 7) == 7 && fills) fill(s >> 3);
+            if constexpr (EPI && s >= 2 && s < 18) {
+                constexpr int i = s - 2;
+                const unsigned idx = ub + (unsigned)((i & 3) + 8 * (i >> 2));
+                const float k = __uint_as_float((__float_as_uint(acc[1 - P][i]) & 0xfffff800u) | idx);
+                erb_insert(b0, b1, b2, k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < 3; ++pre)
+        if (pre < nunits) {
+            fill_unit(pre);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fill(p);
+        }
+    if (nunits > 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (nunits > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // unit 0 and the extension table are in LDS
+    asm volatile("" ::: "memory");
+    ERB_RD(fr[0], 0, 0);
+    ERB_RD(fr[1], 1, 0);
+    ERB_RD(fr[2], 2, 0);
+    ERB_WAIT(2, fr[0]);
+
+    body(no{}, P0{}, 0);
+    int u = 1;
+    for (; u + 1 < nunits; u += 2) {
+        body(yes{}, P1{}, u);
+        body(yes{}, P0{}, u + 1);
+    }
+    const bool odd_tail = u < nunits;
+    if (odd_tail) body(yes{}, P1{}, u);
+    {   // keys of the last unit
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+        const unsigned ub = (unsigned)((nunits - 1) * 32 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float a = odd_tail ? acc[1][i] : acc[0][i];
+            erb_insert(b0, b1, b2, __uint_as_float((__float_as_uint(a) & 0xfffff800u) | (ub + (unsigned)((i & 3) + 8 * (i >> 2)))));
+        }
+    }
+    {   // the other half-wave's three
+        const float o0 = es_swap32(b0), o1 = es_swap32(b1), o2 = es_swap32(b2);
+        erb_insert(b0, b1, b2, o0);
+        erb_insert(b0, b1, b2, o1);
+        erb_insert(b0, b1, b2, o2);
+    }
+    float cm2 = 0.f;
+    for (int c = lane; c < kp; c += 64) {
+        const float v = cn[c];
+        if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
+    }
+    cm2 = wave_max_f32(cm2);
+    if (hh != 0 || row >= n) return;
+    // decisions (scores s = -2 * key value, ascending: m0 <= m1 <= m2)
+    const float m0 = -2.f * b0, m1 = -2.f * b1, m2 = -2.f * b2;
+    const int j0 = (int)(__float_as_uint(b0) & 2047u), j1 = (int)(__float_as_uint(b1) & 2047u);
+    const float cmax = sqrtf(cm2) * 1.0000002f;
+    const float sq = 22.627417f;                                 // sqrt(512)
+    const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 4.9e-4f * cmax);
+    const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 2.45e-4f * cmax * cmax);
+    labels[row] = j0;
+    const float E = A * xnorm[row] + B;
+    if (!(m1 - m0 > 2.0f * E)) {                                 // also catches NaN
+        if (m2 - m0 > 2.0f * E) {
+            const int pos = atomicAdd(&eh->flag_cnt, 1);
+            flag_list[pos] = (int)row;
+            flag_cand[pos] = j0 | (j1 << 16);
+        } else {
+            full_list[atomicAdd(&eh->full_cnt, 1)] = (int)row;
+        }
+    }
+#undef ERB_RD
+#undef ERB_RDX
+#undef ERB_WAIT
+#undef ERB_MFMA
+#undef ERB_MFMAV
+#undef ERB_MFMA0
+}
+
 // exact re-evaluation of flagged rows: one wave per row, float64 difference form over all K centres
 __global__ void __launch_bounds__(64) estep_refine_kernel(const float* __restrict__ X, const float* __restrict__ C,
                                                           const EHdr* eh, const int* flag_list, const int* flag_cand, int d,
@@ -913,6 +1131,30 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
     const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
     static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
+    static const int use_rb = getenv("SCD_ESTEP_RB") ? atoi(getenv("SCD_ESTEP_RB")) : 1;
+    if (use_stream && use_rb && dp == 512 && kp > 128 && kp <= 2048) {
+        // single-pass filter (128 < K <= 2048 at Dp = 512): the rows of a block stay in registers, the centres stream past them once
+        if (!handover) prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
+        half_t* ext = chf;                                       // the fragment-order copy is not used on this path: 16 B per centre
+        estep_ext_kernel<<<(unsigned)scd_cdiv(kp, 256), 256, 0, st>>>(cn, kp, ext);
+        { const int rc_ = scd_set_max_lds((const void*)estep_rb_kernel, ERB_LDS); if (rc_) return rc_; }
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (h->km_timing) {
+            SCD_HIP(hipEventCreate(&ev0));
+            SCD_HIP(hipEventCreate(&ev1));
+            SCD_HIP(hipEventRecord(ev0, st));
+        }
+        estep_rb_kernel<<<(unsigned)scd_cdiv(n, 256), 512, ERB_LDS, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off), ch, ext, cn,
+                                                                            eh, flags, fcand, fulls, n, kp, labels_out);
+        if (h->km_timing) {
+            SCD_HIP(hipEventRecord(ev1, st));
+            h->km_ev.emplace_back(ev0, ev1);
+        }
+        estep_refine_both_kernel<<<1024, 256, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+                                                                         refine_rows_out);
+        SCD_LAUNCH_CHECK();
+        return SCD_OK;
+    }
     if (use_stream && kp <= 2048 && dp <= 768) {
         // streaming filter (D <= 768): centre prep (unless scd_kmeans_finalize has just produced these very centres and their
         // operands into this workspace), one filter launch per 128 centres, refine; no memset
@@ -1086,10 +1328,13 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
 __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const long long* counts, int k, int d,
                                                        const float* Cold, float* Cout, double* shift, double* part,
                                                        unsigned* ticket, int shift_mode, const PrepHdr* ph, const double* mu,
-                                                       EHdr* eh, float* cn, half_t* ch, float* ct, int kp, half_t* chf) {
+                                                       EHdr* eh, float* cn, half_t* ch, float* ct, int kp, half_t* chf,
+                                                       double* refined_out) {
     __shared__ double wred[4];
     __shared__ bool last;
     const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // rows the E-step of this iteration re-evaluated exactly (read before this block's prep_center_row zeroes the counters)
+    if (refined_out && eh && c == 0 && threadIdx.x == 0) *refined_out = (double)(eh->flag_cnt + eh->full_cnt);
     if (c >= k) {                                   // padded centres of the fused E-step prep (grid = kp blocks)
         prep_center_row(Cout, c, k, d, ph->dp, ph, mu, eh, cn, ch, ct, kp, 1, chf);
         return;
@@ -1138,9 +1383,9 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
     }
 }
 
-extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d,
-                                   const float* C_old, float* C_out, double* shift_out, int shift_mode, const void* prep,
-                                   void* estep_ws, size_t estep_ws_bytes, int64_t n, void* stream_) {
+static int finalize_impl(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old, float* C_out,
+                         double* shift_out, int shift_mode, const void* prep, void* estep_ws, size_t estep_ws_bytes, int64_t n,
+                         void* stream_, double* refined_out) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_finalize");
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
@@ -1162,7 +1407,7 @@ extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64
         const char* p = (const char*)prep;
         finalize_kernel<<<kp, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
                                                               (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
-                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf);
+                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf, refined_out);
         h->prep_C = C_out;
         h->prep_ws = estep_ws;
         h->prep_k = k;
@@ -1170,10 +1415,16 @@ extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64
     } else {
         finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
                                                              (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
-                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr);
+                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr, nullptr);
     }
     SCD_LAUNCH_CHECK();
     return SCD_OK;
+}
+
+extern "C" int scd_kmeans_finalize(scd_handle h, const double* sums, const int64_t* counts, int k, int d,
+                                   const float* C_old, float* C_out, double* shift_out, int shift_mode, const void* prep,
+                                   void* estep_ws, size_t estep_ws_bytes, int64_t n, void* stream_) {
+    return finalize_impl(h, sums, counts, k, d, C_old, C_out, shift_out, shift_mode, prep, estep_ws, estep_ws_bytes, n, stream_, nullptr);
 }
 
 extern "C" int scd_kmeans_timing(scd_handle h, int enable, double* samples_ms_out, int cap, int* launches_out) {
@@ -1754,6 +2005,7 @@ extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void*
     if (!rc)
         rc = X16_cat ? scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream)
                      : scd_kmeans_mstep(h, X_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
-    if (!rc) rc = scd_kmeans_finalize(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream);
+    // stats[3]: rows this iteration's E-step re-evaluated exactly (the caller's cue for SCD_ESTEP_FEW two iterations later)
+    if (!rc) rc = finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3);
     return rc;
 }

@@ -29,14 +29,6 @@ __device__ __forceinline__ void topm_insert(float (&lv)[TOPM], int (&li)[TOPM], 
     }
 }
 
-// compile-time loop: f(std::integral_constant<int, S>) for S = B .. E-1 (asm immediates need constant expressions)
-template <int B, int E, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 template <int TM>
 __device__ __forceinline__ void topm_insert_n(float (&lv)[TM], int (&li)[TM], float v, int idx) {

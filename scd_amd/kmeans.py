@@ -356,7 +356,7 @@ class KMeansEngine:
         dev = cat.device
         ring = getattr(self, "_host_ring", None)
         if ring is None:
-            ring = self._host_ring = [torch.empty(3, dtype=torch.float64).pin_memory() for _ in range(2)]
+            ring = self._host_ring = [torch.zeros(4, dtype=torch.float64).pin_memory() for _ in range(2)]
         best = (None, None, None)
         pending = None                      # (it, labels snapshot, new centres, host buffer, event)
         n_done = 0
@@ -369,10 +369,16 @@ class KMeansEngine:
             fused.c0.copy_(centers)
             centers = fused.c0              # iteration 0 reads the run's own start buffer and writes set 0
 
+        # SCD_ESTEP_FEW (flagged rows re-evaluated in the filter kernel's tail) pays only when a handful of rows are flagged: the
+        # one-block-per-CU tail takes ~100 us for a few thousand rows where the refine launch takes 20.  The cue is the count the
+        # host has seen last (iteration i - 2 when launching iteration i: the host runs one iteration behind the device)
+        refined_seen = [None]
+
         def settle(p):
             nonlocal best
             p[4].synchronize()
             host = p[3].numpy()
+            refined_seen[0] = float(host[3])
             inertia = np.float32(np.float32(host[1]) + np.float32(host[0]))
             if best[1] is None or inertia < best[1]:
                 best = (p[1], inertia, p[2].clone() if fused is not None else p[2])
@@ -384,7 +390,7 @@ class KMeansEngine:
             if fused is not None:
                 centers, stats = fused.c[it & 1], fused.stats[it & 1]
                 self.stats["estep_calls"] += 1
-                fused.step(old, centers, stats, it >= 2)
+                fused.step(old, centers, stats, it >= 2 and refined_seen[0] is not None and refined_seen[0] <= 64)
                 buf.copy_(stats, non_blocking=True)
                 snap = fused.lab32.clone()
             else:
@@ -400,7 +406,7 @@ class KMeansEngine:
                     counts = packed[kd:kd + self.k].round().to(torch.int64)
                     inertia2 = packed[kd + self.k:]
                 centers, shift = be.finalize(sums, counts, old, data_u)
-                buf.copy_(torch.cat([inertia2, shift.reshape(1)]), non_blocking=True)
+                buf[:3].copy_(torch.cat([inertia2, shift.reshape(1)]), non_blocking=True)
                 snap, centers = labels.clone(), centers.clone()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))

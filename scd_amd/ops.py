@@ -238,7 +238,7 @@ class LloydBuffers:
         self.c0 = torch.empty((k, d), dtype=torch.float32, device=dev)
         self.sums = torch.empty((k, d), dtype=torch.float64, device=dev)
         self.counts = torch.empty(k, dtype=torch.int64, device=dev)
-        self.stats = [torch.empty(3, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.stats = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]   # {inertia l, inertia u, shift, refined rows}
         self.nb_e = _L().scd_kmeans_estep_ws_bytes(data_u.n, data_u.d, k)
         self.ws_e = data_u.ws(("e", k), self.nb_e)
         self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)

@@ -131,11 +131,13 @@ def test_estep_nan_centre_never_wins(ops):
 
 @pytest.mark.parametrize("n,d,k,seed", [(31, 16, 3, 11), (33, 200, 128, 12), (1000, 300, 1, 13), (2049, 512, 64, 14), (777, 640, 128, 15),
                                         (5000, 768, 128, 16), (1025, 100, 129, 17), (600, 896, 50, 18), (1500, 256, 1000, 19), (700, 128, 2048, 20),
-                                        (900, 64, 2049, 21)])
+                                        (900, 64, 2049, 21), (1300, 512, 129, 22), (2049, 512, 1000, 23), (515, 448, 2048, 24),
+                                        (4000, 512, 300, 25)])
 def test_estep_stream_kernel_shapes(ops, n, d, k, seed):
     """Every column-chunk count of estep_stream_kernel (D <= 768: 1..6 x 128), K = 1 / 128, ragged last 32-row unit, the
-    multi-pass form (K = 129 / 1000 / 2048: 2 / 8 / 16 passes) and the shapes outside it (K = 2049, D = 896: estep_mfma_kernel); centres are data points, so rows with distance 0 and
-    many small margins (both refine lists) occur."""
+    multi-pass form (K = 129 / 1000 / 2048: 2 / 8 / 16 passes), the single-pass form of Dp = 512 with 128 < K <= 2048 (estep_rb_kernel:
+    K = 129 / 300 / 1000 / 2048, ragged last 256-row block, D = 448 padded to 512) and the shapes outside both (K = 2049, D = 896:
+    estep_mfma_kernel); centres are data points, so rows with distance 0 and many small margins (both refine lists) occur."""
     x, y, cent = synth.clustered_features(n, d, max(2, min(k, 20)), seed=seed, center_seed=seed + 7, noise=0.9)
     rs = np.random.RandomState(seed)
     c = x[rs.choice(n, k, replace=k > n)].copy()
@@ -1258,3 +1260,50 @@ def test_multi_rank_rccl(ops):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     for rank in range(n):
         assert "rank %d ok" % rank in r.stdout
+
+
+def test_c4_shape_sskm_k1000(ops):
+    """BASELINE configs[3] per-GPU shard (main_unsup.py:350 with --n_cluster 1000): N = 160,146 CLIP-width rows, K = 1000.
+    Full-size properties of the single-pass E-step and of one fused Lloyd step - labels = the stand-alone E-step's, exact
+    column-total checksum of the M-step sums, 2,048 sampled rows equal the float64 oracle - and, on a sub-sample, the lock-step
+    k-means++ seeding of all restarts equal to the sequential one."""
+    from scd_amd.kmeans import KMeansEngine
+    n, d, k = 160146, 512, 1000
+    g = torch.Generator(device="cuda").manual_seed(41)
+    cen = torch.nn.functional.normalize(torch.randn(k, d, device="cuda", generator=g), dim=-1)
+    y = torch.randint(0, k, (n,), device="cuda", generator=g)
+    x = torch.nn.functional.normalize(cen[y] + (0.8 / d ** 0.5) * torch.randn(n, d, device="cuda", generator=g), dim=-1).half().float().contiguous()
+    c0 = x[torch.randperm(n, device="cuda", generator=g)[:k]].contiguous()          # data points as centres: zero distances, small margins
+    data = ops.KMeansData(x)
+    lab, ref = data.estep(c0, return_refined=True)
+    assert int(ref.item()) < n // 4
+    xs = x.cpu().numpy()
+    cs = c0.cpu().numpy()
+    rows = np.random.RandomState(2).choice(n, 2048, replace=False)
+    rows[:4] = [0, 255, n - 1, n - 146]
+    olab, omind, _ = ko.estep(xs[rows], cs)
+    assert np.array_equal(lab.cpu().numpy()[rows].astype(np.int64), olab)
+    assert np.array_equal(data.rowdist(c0, lab).cpu().numpy()[rows], omind)
+    # one fused Lloyd step (E + M + finalize) from the same centres
+    x16 = ops.f16_exact(x)
+    assert x16 is not None
+    bufs = ops.LloydBuffers(data, x, x16, k)
+    bufs.c0.copy_(c0)
+    bufs.step(bufs.c0, bufs.c[0], bufs.stats[0], False)
+    assert torch.equal(bufs.lab32, lab)
+    col = x.double().sum(0)
+    assert torch.equal(bufs.sums.sum(0), col) or torch.allclose(bufs.sums.sum(0), col, rtol=1e-13, atol=1e-9)
+    assert int(bufs.counts.sum().item()) == n
+    sums, counts, inertia = ops.kmeans_mstep(x, lab, c0, k, 0, x16=x16)
+    assert torch.equal(sums, bufs.sums) and torch.equal(counts, bufs.counts)
+    newc, _ = ops.kmeans_finalize(sums, counts, c0)
+    assert torch.equal(newc.nan_to_num(7.0), bufs.c[0].nan_to_num(7.0))
+    # lock-step seeding == sequential seeding (sub-sample, k = 1000: 999 rounds)
+    sub = x[:20000].contiguous()
+    a = KMeansEngine(k=k, max_iterations=1, n_init=2, random_state=5)
+    dsub = ops.KMeansData(sub)
+    lock = a.kpp_lockstep(dsub, None, k, ko.check_random_state(5), 2)
+    rs = ko.check_random_state(5)
+    for j in range(2):
+        seq = a.kpp(sub, k=k, random_state=rs, data=dsub)
+        assert torch.equal(seq, lock[j])
