@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) mstep_segment_kernel(const float* __restr
 #pragma unroll
             for (int g = 0; g < MAXG; ++g) {
                 const int c = g * 64 + lane;
-                xv[u][g] = xr[c < d ? c : d - 1];
+                xv[u][g] = __builtin_nontemporal_load(xr + (c < d ? c : d - 1));      // non-temporal: see mstep_segment16_kernel
             }
         }
 #pragma unroll
@@ -273,7 +273,9 @@ __global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __re
 #pragma unroll
             for (int g = 0; g < MAXG2; ++g) {
                 const int c = g * 128 + 2 * lane;
-                xv[u][g] = *(const h2*)(xr + (c < d ? c : d - 2));          // clamped (always valid) address, masked at use
+                // non-temporal: this pass must not push the E-step's operand (the prepared fp16 copy, read next) out of the
+                // Infinity Cache - the two copies together exceed its 256 MB at C2
+                xv[u][g] = __builtin_nontemporal_load((const h2*)(xr + (c < d ? c : d - 2)));   // clamped (always valid) address, masked at use
             }
         }
 #pragma unroll
