@@ -130,6 +130,21 @@ int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, in
                           const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
                           float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,
                           size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream);
+/* The same iteration with an INCREMENTAL M-step, for row sets whose exact fp16 copy exists (scd_f16_exact: then the float64
+ * cluster sums are exact, hence independent of the order of additions): sums / counts of the previous iteration are updated with
+ * the rows whose label changed (labels_prev: the labels sums / counts belong to, updated in place) and the inertia is evaluated
+ * from the sums, the centres and the rows' sum of squares (scd_kmeans_sumsq, double-double) - bit-identical centres, labels and
+ * float32 inertia at a cost proportional to the changes.  flags: SCD_ESTEP_* | SCD_LLOYD_FULL (a fresh M-step over the rows, as
+ * scd_kmeans_lloyd_step; the first iterations of a restart, or whenever many labels move).  sums_lab / counts_lab: sums / counts of
+ * the labelled rows alone (NULL when there are none).  stats: device double [5] = {inertia labelled, inertia unlabelled, centre
+ * shift, rows re-evaluated exactly, rows whose label changed}.  Reference: faster_mix_k_means_pytorch.py:187-214. */
+#define SCD_LLOYD_FULL 8
+int scd_kmeans_sumsq(scd_handle h, const void* X16, const float* X, int64_t n, int d, int64_t split, double* out4, void* stream);
+int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
+                                float* C_out, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,
+                                const double* sumsq4, double* stats, int flags, void* ws_e, size_t ws_e_bytes, void* ws_m,
+                                size_t ws_m_bytes, void* stream);
 /* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
  * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
  * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips

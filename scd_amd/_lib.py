@@ -60,6 +60,9 @@ SIGNATURES = {
     "scd_kmeans_min_update": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "scd_kpp_draw_ws_bytes": (_sz, [_i64]),
     "scd_kpp_draw": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kmeans_sumsq": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
+    "scd_kmeans_lloyd_step_delta": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz,
+                                         _vp, _sz, _vp]),
     "scd_kmeans_lloyd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "scd_kmeans_min_update_multi": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp]),
     "scd_kpp_draw_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1989,6 +1989,223 @@ extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_
 // scd_kmeans_estep + scd_kmeans_mstep[_f16] + scd_kmeans_finalize with the buffers wired together - but a Lloyd iteration is
 // ~105 us of device work and the caller's per-call overhead (a Python caller: 15 tensor / FFI calls, ~185 us) otherwise bounds it.
 // stats[3] = {inertia of the labelled rows, inertia of the unlabelled rows, centre shift}, float64 on the device.
+// ------------------------------------------------------------------------------------------------
+// Incremental Lloyd step (round 3).  When every value of X is exactly representable in fp16 (features that left an fp16 encoder:
+// scd_f16_exact), the float64 per-cluster sums are EXACT - every value is a multiple of 2^-24 below 2^16 and a cluster of N <= 2^13
+// ... 2^29 such rows sums below 2^53 units for unit-scale features - so they do not depend on the order of additions, and the sums of
+// iteration i are the sums of iteration i - 1 plus the rows whose label changed (added to the new cluster, subtracted from the old):
+// bit-identical to a fresh M-step at a cost proportional to the changes (a few hundred rows of 95,000 after the third iteration
+// on clustered features) instead of a pass over X.  The inertia of the reference's bookkeeping (sum over rows of ||x - c_label||^2
+// with the centres the labels were computed from, sskm.py:118-132) follows without X as well:
+//     sum_i ||x_i - c_l(i)||^2 = sum_i ||x_i||^2 + sum_k ( n_k ||c_k||^2 - 2 <c_k, S_k> )
+// evaluated in double-double arithmetic (error-free products by fma, two-sum accumulation) from the exact S_k, n_k, the float32
+// centres and sum ||x||^2 (once per fit, also double-double), separately for the labelled and the unlabelled rows - the value agrees
+// with the float64 row-by-row sum to ~1e-15 relative, like two summation orders of that sum.
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ dd_t dd_add_d(dd_t a, double b) {      // a + b, b a plain double
+    const double s = a.hi + b;
+    const double bb = s - a.hi;
+    const double e = (a.hi - (s - bb)) + (b - bb);
+    const double lo = a.lo + e;
+    const double hi = s + lo;
+    return {hi, lo - (hi - s)};
+}
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) { return dd_add_d(dd_add_d(a, b.hi), b.lo); }
+__device__ __forceinline__ dd_t dd_add_prod(dd_t a, double x, double y) {    // a + x * y, the product error-free
+    const double p = x * y;
+    const double e = fma(x, y, -p);
+    return dd_add_d(dd_add_d(a, p), e);
+}
+__device__ __forceinline__ dd_t dd_wave_sum(dd_t v) {            // fixed butterfly order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dd_t ov;
+        ov.hi = __shfl_xor(v.hi, o, 64);
+        ov.lo = __shfl_xor(v.lo, o, 64);
+        v = dd_add(v, ov);
+    }
+    return v;
+}
+// sum of squares of the rows [0, split) and [split, n), double-double, two launches: per-block partials, then one block
+__global__ void __launch_bounds__(256) sumsq_dd_kernel(const half_t* __restrict__ X16, const float* __restrict__ X, long long n, int d,
+                                                       long long split, double* part) {
+    __shared__ double red[4][4];
+    dd_t a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < n; row += (long long)gridDim.x * 4) {
+        dd_t r = {0.0, 0.0};
+        for (int j = lane; j < d; j += 64) {
+            const double x = X16 ? (double)(float)X16[row * d + j] : (double)X[row * d + j];
+            r = dd_add_prod(r, x, x);
+        }
+        if (row < split) a0 = dd_add(a0, r); else a1 = dd_add(a1, r);
+    }
+    a0 = dd_wave_sum(a0);
+    a1 = dd_wave_sum(a1);
+    if (lane == 0) { red[wave][0] = a0.hi; red[wave][1] = a0.lo; red[wave][2] = a1.hi; red[wave][3] = a1.lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dd_t b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+        for (int w = 0; w < 4; ++w) { b0 = dd_add(b0, {red[w][0], red[w][1]}); b1 = dd_add(b1, {red[w][2], red[w][3]}); }
+        part[blockIdx.x * 4 + 0] = b0.hi; part[blockIdx.x * 4 + 1] = b0.lo;
+        part[blockIdx.x * 4 + 2] = b1.hi; part[blockIdx.x * 4 + 3] = b1.lo;
+    }
+}
+__global__ void sumsq_dd_final_kernel(const double* part, int nblk, double* out) {
+    dd_t b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+    for (int b = 0; b < nblk; ++b) { b0 = dd_add(b0, {part[b * 4], part[b * 4 + 1]}); b1 = dd_add(b1, {part[b * 4 + 2], part[b * 4 + 3]}); }
+    out[0] = b0.hi; out[1] = b0.lo; out[2] = b1.hi; out[3] = b1.lo;
+}
+extern "C" int scd_kmeans_sumsq(scd_handle h, const void* X16, const float* X, int64_t n, int d, int64_t split, double* out4,
+                                void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_sumsq");
+    SCD_REQUIRE((X16 || X) && out4 && n > 0 && d > 0 && split >= 0 && split <= n, "scd_kmeans_sumsq: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    double* part = (double*)h->scratch;                          // 256 blocks x 4 doubles of the handle's 256-KB scratch
+    sumsq_dd_kernel<<<256, 256, 0, st>>>((const half_t*)X16, X, n, d, split, part);
+    sumsq_dd_final_kernel<<<1, 1, 0, st>>>(part, 256, out4);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// rows [row0, n) whose label differs from labels_prev: +x to the new cluster's sums, -x from the old one's (float64 atomics of exact
+// values: order-free), counts, labels_prev updated, the number of changes added to *changed (double).  One wave per 64 rows.
+__global__ void __launch_bounds__(256) mstep_delta_kernel(const half_t* __restrict__ X16, const int32_t* __restrict__ labels,
+                                                          int32_t* __restrict__ labels_prev, long long row0, long long n, int d, int k,
+                                                          double* __restrict__ sums, unsigned long long* __restrict__ counts,
+                                                          double* __restrict__ changed) {
+    const int lane = threadIdx.x & 63;
+    const long long base = row0 + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (base >= n) return;
+    const long long row = base + lane;
+    int ln = -1, lo = -1;
+    if (row < n) { ln = labels[row]; lo = labels_prev[row]; }
+    const bool ch = row < n && ln != lo;
+    unsigned long long m = __ballot(ch);
+    if (!m) return;
+    if (ch) labels_prev[row] = ln;
+    if (lane == 0) atomicAdd(changed, (double)__popcll(m));
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int a = __shfl(ln, src, 64), b = __shfl(lo, src, 64);
+        const half_t* xr = X16 + (base + src) * d;
+        for (int c = 2 * lane; c < d; c += 128) {
+            const double x0 = (double)(float)xr[c], x1 = (double)(float)xr[c + 1];
+            if ((unsigned)a < (unsigned)k) { atomicAdd(&sums[(size_t)a * d + c], x0); atomicAdd(&sums[(size_t)a * d + c + 1], x1); }
+            if ((unsigned)b < (unsigned)k) { atomicAdd(&sums[(size_t)b * d + c], -x0); atomicAdd(&sums[(size_t)b * d + c + 1], -x1); }
+        }
+        if (lane == 0) {
+            if ((unsigned)a < (unsigned)k) atomicAdd(&counts[a], 1ull);
+            if ((unsigned)b < (unsigned)k) atomicAdd(&counts[b], ~0ull);      // - 1
+        }
+    }
+}
+// labels_prev = labels for rows [row0, n) and the number of differences (the full step's bookkeeping for the next incremental one)
+__global__ void __launch_bounds__(256) labels_sync_kernel(const int32_t* __restrict__ labels, int32_t* __restrict__ labels_prev, long long row0,
+                                                          long long n, double* __restrict__ changed) {
+    const long long i = row0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    bool ch = false;
+    if (i < n) {
+        const int a = labels[i];
+        ch = a != labels_prev[i];
+        if (ch) labels_prev[i] = a;
+    }
+    const unsigned long long m = __ballot(ch);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (double)__popcll(m));
+}
+// inertia of both row groups from the exact sums: block k -> n_k ||c_k||^2 - 2 <c_k, S_k> for the labelled rows (S_lab, n_lab) and for
+// the others (S - S_lab, n - n_lab); the last block adds the K partials in index order and the sums of squares
+__global__ void __launch_bounds__(256) inertia_dd_kernel(const float* __restrict__ C, const double* __restrict__ sums,
+                                                         const long long* __restrict__ counts, const double* __restrict__ sums_lab,
+                                                         const long long* __restrict__ counts_lab, const double* __restrict__ sumsq4, int k,
+                                                         int d, double* part, unsigned* ticket, double* out2) {
+    __shared__ double red[4][6];
+    __shared__ bool last;
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long nl = counts_lab ? counts_lab[c] : 0, nu = counts[c] - nl;
+    dd_t cc = {0.0, 0.0}, dl = {0.0, 0.0}, du = {0.0, 0.0};
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const double cv = (double)C[(size_t)c * d + j];
+        const double sl = sums_lab ? sums_lab[(size_t)c * d + j] : 0.0;
+        const double su = sums[(size_t)c * d + j] - sl;          // exact: both are exact sums of multiples of 2^-24
+        cc = dd_add_prod(cc, cv, cv);
+        if (nl) dl = dd_add_prod(dl, cv, sl);
+        if (nu) du = dd_add_prod(du, cv, su);
+    }
+    cc = dd_wave_sum(cc); dl = dd_wave_sum(dl); du = dd_wave_sum(du);
+    if (lane == 0) { red[wave][0] = cc.hi; red[wave][1] = cc.lo; red[wave][2] = dl.hi; red[wave][3] = dl.lo; red[wave][4] = du.hi; red[wave][5] = du.lo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dd_t n2 = {0.0, 0.0}, pl = {0.0, 0.0}, pu = {0.0, 0.0};
+        for (int w = 0; w < 4; ++w) { n2 = dd_add(n2, {red[w][0], red[w][1]}); pl = dd_add(pl, {red[w][2], red[w][3]}); pu = dd_add(pu, {red[w][4], red[w][5]}); }
+        // t = n ||c||^2 - 2 <c, S>   (n < 2^31: the products with hi / lo are formed error-free)
+        dd_t tl = {0.0, 0.0}, tu = {0.0, 0.0};
+        if (nl) { tl = dd_add_prod(dd_add_prod(tl, (double)nl, n2.hi), (double)nl, n2.lo); tl = dd_add_d(dd_add_d(tl, -2.0 * pl.hi), -2.0 * pl.lo); }
+        if (nu) { tu = dd_add_prod(dd_add_prod(tu, (double)nu, n2.hi), (double)nu, n2.lo); tu = dd_add_d(dd_add_d(tu, -2.0 * pu.hi), -2.0 * pu.lo); }
+        part[c * 4 + 0] = tl.hi; part[c * 4 + 1] = tl.lo; part[c * 4 + 2] = tu.hi; part[c * 4 + 3] = tu.lo;
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)k - 1;
+    }
+    __syncthreads();
+    if (last) {                                     // the K partials in a fixed tree order (a serial loop on one thread took 50 us)
+        __shared__ double tr[256][4];
+        __threadfence();
+        dd_t il = {0.0, 0.0}, iu = {0.0, 0.0};
+        for (int q = threadIdx.x; q < k; q += 256) {
+            il = dd_add(il, {((volatile double*)part)[q * 4], ((volatile double*)part)[q * 4 + 1]});
+            iu = dd_add(iu, {((volatile double*)part)[q * 4 + 2], ((volatile double*)part)[q * 4 + 3]});
+        }
+        tr[threadIdx.x][0] = il.hi; tr[threadIdx.x][1] = il.lo; tr[threadIdx.x][2] = iu.hi; tr[threadIdx.x][3] = iu.lo;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                const dd_t a = dd_add({tr[threadIdx.x][0], tr[threadIdx.x][1]}, {tr[threadIdx.x + o][0], tr[threadIdx.x + o][1]});
+                const dd_t b = dd_add({tr[threadIdx.x][2], tr[threadIdx.x][3]}, {tr[threadIdx.x + o][2], tr[threadIdx.x + o][3]});
+                tr[threadIdx.x][0] = a.hi; tr[threadIdx.x][1] = a.lo; tr[threadIdx.x][2] = b.hi; tr[threadIdx.x][3] = b.lo;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const dd_t fl = dd_add({sumsq4[0], sumsq4[1]}, {tr[0][0], tr[0][1]}), fu = dd_add({sumsq4[2], sumsq4[3]}, {tr[0][2], tr[0][3]});
+            out2[0] = fl.hi + fl.lo;
+            out2[1] = fu.hi + fu.lo;
+            *ticket = 0;
+        }
+    }
+}
+
+extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                           int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
+                                           float* C_out, double* sums, int64_t* counts, const double* sums_lab,
+                                           const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
+                                           size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
+    SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
+                "scd_kmeans_lloyd_step_delta: null argument");
+    SCD_REQUIRE(n_u > 0 && n_cat >= n_u && C_in != C_out && k <= 8192, "scd_kmeans_lloyd_step_delta: bad arguments");
+    const int64_t l_num = n_cat - n_u;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = scd_kmeans_estep_hint(h, flags & (SCD_ESTEP_FEW | SCD_ESTEP_CENTRES_FROM_FINALIZE));
+    if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
+    if (rc) return rc;
+    SCD_HIP(hipMemsetAsync(stats + 4, 0, 8, st));
+    if (flags & SCD_LLOYD_FULL) {
+        // a fresh M-step (sums, counts, inertia from the rows), then labels_prev = labels for the incremental steps that follow
+        rc = scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
+        if (rc) return rc;
+        labels_sync_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>(labels_cat, labels_prev, l_num, n_cat, stats + 4);
+    } else {
+        mstep_delta_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>((const half_t*)X16_cat, labels_cat, labels_prev, l_num, n_cat, d, k, sums,
+                                                                          (unsigned long long*)counts, stats + 4);
+        // partials at the start of the handle's scratch (free between two finalize launches of this stream), own ticket word
+        inertia_dd_kernel<<<k, 256, 0, st>>>(C_in, sums, (const long long*)counts, sums_lab, (const long long*)counts_lab, sumsq4, k, d,
+                                             (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144 + 32), stats);
+    }
+    SCD_LAUNCH_CHECK();
+    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3);
+}
+
 extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,
                                      const void* X16_cat, int64_t n_cat, int d, int k, int32_t* labels_cat, const float* C_in,
                                      float* C_out, double* sums, int64_t* counts, double* stats, int expect_few, void* ws_e,

@@ -356,7 +356,7 @@ class KMeansEngine:
         dev = cat.device
         ring = getattr(self, "_host_ring", None)
         if ring is None:
-            ring = self._host_ring = [torch.zeros(4, dtype=torch.float64).pin_memory() for _ in range(2)]
+            ring = self._host_ring = [torch.zeros(5, dtype=torch.float64).pin_memory() for _ in range(2)]
         best = (None, None, None)
         pending = None                      # (it, labels snapshot, new centres, host buffer, event)
         n_done = 0
@@ -373,12 +373,16 @@ class KMeansEngine:
         # one-block-per-CU tail takes ~100 us for a few thousand rows where the refine launch takes 20.  The cue is the count the
         # host has seen last (iteration i - 2 when launching iteration i: the host runs one iteration behind the device)
         refined_seen = [None]
+        # the incremental M-step (LloydBuffers.step_delta) pays while few labels move; same cue, the count of iteration i - 2
+        changed_seen = [None]
+        n_u = data_u.n if hasattr(data_u, "n") else len(cat) - l_num
 
         def settle(p):
             nonlocal best
             p[4].synchronize()
             host = p[3].numpy()
             refined_seen[0] = float(host[3])
+            changed_seen[0] = float(host[4])
             inertia = np.float32(np.float32(host[1]) + np.float32(host[0]))
             if best[1] is None or inertia < best[1]:
                 best = (p[1], inertia, p[2].clone() if fused is not None else p[2])
@@ -390,7 +394,13 @@ class KMeansEngine:
             if fused is not None:
                 centers, stats = fused.c[it & 1], fused.stats[it & 1]
                 self.stats["estep_calls"] += 1
-                fused.step(old, centers, stats, it >= 2 and refined_seen[0] is not None and refined_seen[0] <= 64)
+                few = it >= 2 and refined_seen[0] is not None and refined_seen[0] <= 64
+                if getattr(fused, "inc", False):
+                    full = it < 2 or changed_seen[0] is None or changed_seen[0] > max(256, n_u // 64)
+                    fused.step_delta(old, centers, stats, few, full)
+                    self.stats["delta_steps"] = self.stats.get("delta_steps", 0) + (0 if full else 1)
+                else:
+                    fused.step(old, centers, stats, few)
                 buf.copy_(stats, non_blocking=True)
                 snap = fused.lab32.clone()
             else:

@@ -5,6 +5,7 @@ computation below is a call into libscd_hip.so.  Nothing in this module falls
 back to torch math - a missing library or device raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import weakref
@@ -125,7 +126,7 @@ def kmeans_timing(enable, cap=4096):
     return buf[: min(cnt.value, cap)].copy()
 
 
-ESTEP_FEW, ESTEP_CENTRES_FROM_FINALIZE = 1, 2       # include/scd_hip.h
+ESTEP_FEW, ESTEP_CENTRES_FROM_FINALIZE, LLOYD_FULL = 1, 2, 8      # include/scd_hip.h
 _LAST_FINALIZE = {}                                  # "c": (weakref to the centres kmeans_finalize returned, their _version, the KMeansData)
 
 
@@ -224,8 +225,9 @@ def kmeans_mstep(x, labels32, c_old, k, split=0, x16=None):
 
 
 class LloydBuffers:
-    """Device buffers of KMeansEngine's Lloyd loop through scd_kmeans_lloyd_step: two sets (the host reads set i while the
-    device fills set i + 1), allocated once per fit."""
+    """Device buffers of KMeansEngine's Lloyd loop through scd_kmeans_lloyd_step[_delta]: two sets (the host reads set i while the
+    device fills set i + 1), allocated once per fit.  With an exact fp16 copy of the rows (`cat16`) the M-step can run
+    incrementally (`step_delta`: sums / counts updated with the rows whose label changed, inertia from the sums)."""
 
     def __init__(self, data_u, cat, cat16, k):
         dev = cat.device
@@ -238,11 +240,18 @@ class LloydBuffers:
         self.c0 = torch.empty((k, d), dtype=torch.float32, device=dev)
         self.sums = torch.empty((k, d), dtype=torch.float64, device=dev)
         self.counts = torch.empty(k, dtype=torch.int64, device=dev)
-        self.stats = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]   # {inertia l, inertia u, shift, refined rows}
+        # {inertia labelled, inertia unlabelled, centre shift, rows re-evaluated exactly, rows whose label changed}
+        self.stats = [torch.zeros(5, dtype=torch.float64, device=dev) for _ in range(2)]
         self.nb_e = _L().scd_kmeans_estep_ws_bytes(data_u.n, data_u.d, k)
         self.ws_e = data_u.ws(("e", k), self.nb_e)
         self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)
         self.ws_m = _ws(self.nb_m, dev)
+        self.inc = cat16 is not None and k <= 8192 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0"
+        if self.inc:
+            self.lab_prev = torch.full((n_cat,), -1, dtype=torch.int32, device=dev)
+            self.sumsq = torch.empty(4, dtype=torch.float64, device=dev)
+            self.sums_lab = self.counts_lab = None
+            self._fit_ready = False
 
     def step(self, c_in, c_out, stats, expect_few):
         d = self.data
@@ -253,6 +262,29 @@ class LloydBuffers:
                                          d.d, self.k, ptr(self.lab32), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
                                          ptr(stats), flags, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m,
                                          stream_ptr()))
+
+    def _prepare_fit(self):
+        """Once per fit: the rows' sums of squares (labelled | unlabelled, double-double) and the sums / counts of the labelled rows,
+        whose labels (self.lab32[:l_num], set by the caller) never change."""
+        n_cat, d = self.cat.shape
+        l_num = n_cat - self.data.n
+        check(_L().scd_kmeans_sumsq(handle(), ptr(self.cat16), None, n_cat, d, l_num, ptr(self.sumsq), stream_ptr()))
+        if l_num > 0:
+            s, c, _ = kmeans_mstep(self.cat[:l_num], self.lab32[:l_num].contiguous(), None, self.k, 0, x16=self.cat16[:l_num])
+            self.sums_lab, self.counts_lab = s.contiguous(), c.contiguous()
+        self._fit_ready = True
+
+    def step_delta(self, c_in, c_out, stats, expect_few, full):
+        """One Lloyd iteration with the incremental M-step (full=False) or with a fresh one that also re-bases the incremental
+        state (full=True: the first iterations of a restart, or when many labels are moving)."""
+        if not self._fit_ready:
+            self._prepare_fit()
+        d = self.data
+        flags = (ESTEP_FEW if expect_few else 0) | ESTEP_CENTRES_FROM_FINALIZE | (LLOYD_FULL if full else 0)
+        check(_L().scd_kmeans_lloyd_step_delta(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), self.cat.shape[0], d.d, self.k,
+                                               ptr(self.lab32), ptr(self.lab_prev), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
+                                               ptr(self.sums_lab), ptr(self.counts_lab), ptr(self.sumsq), ptr(stats), flags,
+                                               ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
 
 
 def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):

@@ -1307,3 +1307,34 @@ def test_c4_shape_sskm_k1000(ops):
     for j in range(2):
         seq = a.kpp(sub, k=k, random_state=rs, data=dsub)
         assert torch.equal(seq, lock[j])
+
+
+@pytest.mark.parametrize("n,d,k,labelled", [(20000, 512, 40, True), (30000, 768, 100, False), (6000, 64, 7, True)])
+def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch):
+    """On fp16-exact rows the float64 cluster sums are exact, so updating them with the rows whose label changed
+    (scd_kmeans_lloyd_step_delta) must give the SAME centres, labels, float32 inertia and iteration count as a fresh M-step per
+    iteration - and both equal the float64 oracle's run (faster_mix_k_means_pytorch.py:187-214)."""
+    from scd_amd.kmeans import KMeansEngine
+    x, y, _ = synth.clustered_features(n, d, k, seed=61, center_seed=62, noise=0.8)
+    x = x.astype(np.float16).astype(np.float32)
+    mask = (y < k // 2) & (np.random.RandomState(7).rand(n) < 0.5) if labelled else np.zeros(n, dtype=bool)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCD_MSTEP_DELTA", mode)
+        km = KMeansEngine(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
+        if labelled:
+            km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
+        else:
+            km.fit(dev(x))
+        res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, dict(km.stats))
+    assert res["1"][4].get("delta_steps", 0) > 0 and res["0"][4].get("delta_steps", 0) == 0
+    # (an empty cluster's centre is NaN in the reference and here: equal_nan)
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
+    assert res["1"][2] == res["0"][2] and res["1"][3] == res["0"][3]
+    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
+    if labelled:
+        okm.fit_mix(x[~mask], x[mask], y[mask])
+    else:
+        okm.fit(x)
+    assert np.array_equal(res["1"][0], okm.labels_) and np.array_equal(res["1"][1], okm.cluster_centers_, equal_nan=True)
+    assert res["1"][2] == float(okm.inertia_)
