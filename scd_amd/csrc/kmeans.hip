@@ -804,23 +804,57 @@ __global__ void __launch_bounds__(256) estep_ext_kernel(const float* __restrict_
     o[1] = lo;
     *(half8*)(ext + (size_t)c * 8) = o;
 }
+// decision for one row from its three largest keys (shared by the kernel and by the merge of split row blocks)
+__device__ __forceinline__ void erb_decide(long long row, float b0, float b1, float b2, float cm2, const float* __restrict__ xnorm, EHdr* eh,
+                                           int* flag_list, int* flag_cand, int* full_list, int32_t* __restrict__ labels) {
+    constexpr int D = 512;
+    // scores s = -2 * key value, ascending: m0 <= m1 <= m2
+    const float m0 = -2.f * b0, m1 = -2.f * b1, m2 = -2.f * b2;
+    const int j0 = (int)(__float_as_uint(b0) & 2047u), j1 = (int)(__float_as_uint(b1) & 2047u);
+    const float cmax = sqrtf(cm2) * 1.0000002f;
+    const float sq = 22.627417f;                                 // sqrt(512)
+    const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 4.9e-4f * cmax);
+    const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 2.45e-4f * cmax * cmax);
+    labels[row] = j0;
+    const float E = A * xnorm[row] + B;
+    if (!(m1 - m0 > 2.0f * E)) {                                 // also catches NaN
+        if (m2 - m0 > 2.0f * E) {
+            const int pos = atomicAdd(&eh->flag_cnt, 1);
+            flag_list[pos] = (int)row;
+            flag_cand[pos] = j0 | (j1 << 16);
+        } else {
+            full_list[atomicAdd(&eh->full_cnt, 1)] = (int)row;
+        }
+    }
+}
+// Grid: the first `nfull` blocks take one 256-row block each against all centres.  The row blocks of the last, partial round of
+// the chip (626 row blocks on 256 CUs at C4: 114 left for a third round) are SPLIT: `nsplit` blocks each sweep 1 / nsplit of the
+// centres, leave their rows' three best keys in `tkeys` [nsplit][3][tail rows], and estep_rb_merge_kernel merges and decides - the
+// last round then takes 1 / nsplit of a full one.
 __global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
-                                                       const half_t* __restrict__ ch, const half_t* __restrict__ ext,
+                                                       const half_t* __restrict__ ch_all, const half_t* __restrict__ ext_all,
                                                        const float* __restrict__ cn, EHdr* eh, int* flag_list, int* flag_cand,
-                                                       int* full_list, long long n, int kp, int32_t* __restrict__ labels) {
+                                                       int* full_list, long long n, int kp_all, int32_t* __restrict__ labels,
+                                                       int nfull, int nsplit, float* __restrict__ tkeys) {
     constexpr int D = 512, UB = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const int nunits = kp >> 5;
+    // this block's rows and its share of the centres
+    const bool split = (int)blockIdx.x >= nfull;
+    const int part = split ? ((int)blockIdx.x - nfull) % nsplit : 0;
+    const long long rblock = split ? nfull + ((int)blockIdx.x - nfull) / nsplit : blockIdx.x;
+    const int nunits = split ? (kp_all >> 5) / nsplit : kp_all >> 5, u0 = part * nunits, kp = nunits * 32;
+    const half_t* ch = ch_all + (size_t)u0 * 32 * D;
+    const half_t* ext = ext_all + (size_t)u0 * 32 * 8;
 
     // the extension column of every centre: 16 B per centre behind the ring
     for (int c = tid; c < kp; c += 512) *(half8*)(smem + 4 * UB + c * 16) = *(const half8*)(ext + (size_t)c * 8);
 
     half8 bf[32];
-    const long long row = (long long)blockIdx.x * 256 + wave * 32 + r;
+    const long long row = rblock * 256 + wave * 32 + r;
     {
         const half_t* xr = xh + (row < n ? row : n - 1) * D + 8 * hh;
 #pragma unroll
@@ -876,7 +910,7 @@ __global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict_
         const bool more = u + 1 < nunits;
         const bool fills = u + 3 < nunits;
         if (fills) fill_unit(u + 3);
-        const unsigned ub = (unsigned)((u - 1) * 32 + 4 * hh);    // centre index of value i of unit u - 1: ub + (i & 3) + 8 (i >> 2)
+        const unsigned ub = (unsigned)((u0 + u - 1) * 32 + 4 * hh);   // centre index of value i of unit u - 1: ub + (i & 3) + 8 (i >> 2)
         static_for<0, 32>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             if (s == 29) {
@@ -936,7 +970,7 @@ __global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict_
     if (odd_tail) body(yes{}, P1{}, u);
     {   // keys of the last unit
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
-        const unsigned ub = (unsigned)((nunits - 1) * 32 + 4 * hh);
+        const unsigned ub = (unsigned)((u0 + nunits - 1) * 32 + 4 * hh);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float a = odd_tail ? acc[1][i] : acc[0][i];
@@ -950,36 +984,45 @@ __global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict_
         erb_insert(b0, b1, b2, o2);
     }
     float cm2 = 0.f;
-    for (int c = lane; c < kp; c += 64) {
+    for (int c = lane; c < kp_all; c += 64) {
         const float v = cn[c];
         if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
     }
     cm2 = wave_max_f32(cm2);
     if (hh != 0 || row >= n) return;
-    // decisions (scores s = -2 * key value, ascending: m0 <= m1 <= m2)
-    const float m0 = -2.f * b0, m1 = -2.f * b1, m2 = -2.f * b2;
-    const int j0 = (int)(__float_as_uint(b0) & 2047u), j1 = (int)(__float_as_uint(b1) & 2047u);
-    const float cmax = sqrtf(cm2) * 1.0000002f;
-    const float sq = 22.627417f;                                 // sqrt(512)
-    const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 4.9e-4f * cmax);
-    const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 2.45e-4f * cmax * cmax);
-    labels[row] = j0;
-    const float E = A * xnorm[row] + B;
-    if (!(m1 - m0 > 2.0f * E)) {                                 // also catches NaN
-        if (m2 - m0 > 2.0f * E) {
-            const int pos = atomicAdd(&eh->flag_cnt, 1);
-            flag_list[pos] = (int)row;
-            flag_cand[pos] = j0 | (j1 << 16);
-        } else {
-            full_list[atomicAdd(&eh->full_cnt, 1)] = (int)row;
-        }
+    if (split) {                                                 // this part's three best of the row, for estep_rb_merge_kernel
+        const long long trows = n - (long long)nfull * 256, tr = row - (long long)nfull * 256;
+        tkeys[((size_t)part * 3 + 0) * trows + tr] = b0;
+        tkeys[((size_t)part * 3 + 1) * trows + tr] = b1;
+        tkeys[((size_t)part * 3 + 2) * trows + tr] = b2;
+        return;
     }
+    erb_decide(row, b0, b1, b2, cm2, xnorm, eh, flag_list, flag_cand, full_list, labels);
 #undef ERB_RD
 #undef ERB_RDX
 #undef ERB_WAIT
 #undef ERB_MFMA
 #undef ERB_MFMAV
 #undef ERB_MFMA0
+}
+
+__global__ void __launch_bounds__(256) estep_rb_merge_kernel(const float* __restrict__ tkeys, int nsplit, long long row0, long long n,
+                                                             const float* __restrict__ xnorm, const float* __restrict__ cn, int kp,
+                                                             EHdr* eh, int* flag_list, int* flag_cand, int* full_list,
+                                                             int32_t* __restrict__ labels) {
+    float cm2 = 0.f;
+    for (int c = threadIdx.x & 63; c < kp; c += 64) {
+        const float v = cn[c];
+        if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
+    }
+    cm2 = wave_max_f32(cm2);
+    const long long trows = n - row0, tr = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tr >= trows) return;
+    float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;
+    for (int p = 0; p < nsplit; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) erb_insert(b0, b1, b2, tkeys[((size_t)p * 3 + q) * trows + tr]);
+    erb_decide(row0 + tr, b0, b1, b2, cm2, xnorm, eh, flag_list, flag_cand, full_list, labels);
 }
 
 // exact re-evaluation of flagged rows: one wave per row, float64 difference form over all K centres
@@ -1144,8 +1187,23 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             SCD_HIP(hipEventCreate(&ev1));
             SCD_HIP(hipEventRecord(ev0, st));
         }
-        estep_rb_kernel<<<(unsigned)scd_cdiv(n, 256), 512, ERB_LDS, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off), ch, ext, cn,
-                                                                            eh, flags, fcand, fulls, n, kp, labels_out);
+        // the partial last round of the chip is split over the centres (see estep_rb_kernel): 2 or 4 parts while a part keeps >= 8 units
+        const long long nblk = scd_cdiv(n, 256);
+        const int ncu = h->n_cu > 0 ? h->n_cu : 256;
+        const int rem = (int)(nblk % ncu);
+        int nsplit = 1;
+        if (nblk > ncu && rem > 0) {
+            while (nsplit < 4 && rem * (nsplit * 2) <= ncu && (kp / 32) % (nsplit * 2) == 0 && (kp / 32) / (nsplit * 2) >= 8) nsplit *= 2;
+        }
+        const int nfull = nsplit > 1 ? (int)(nblk - rem) : (int)nblk;
+        float* tk = tkey;                                        // [nsplit][3][tail rows] <= 12 n floats
+        estep_rb_kernel<<<(unsigned)(nfull + (nblk - nfull) * nsplit), 512, ERB_LDS, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off), ch,
+                                                                                             ext, cn, eh, flags, fcand, fulls, n, kp, labels_out,
+                                                                                             nfull, nsplit, tk);
+        if (nsplit > 1)
+            estep_rb_merge_kernel<<<(unsigned)scd_cdiv(n - (long long)nfull * 256, 256), 256, 0, st>>>(tk, nsplit, (long long)nfull * 256, n,
+                                                                                                        (const float*)(p + xnorm_off), cn, kp, eh,
+                                                                                                        flags, fcand, fulls, labels_out);
         if (h->km_timing) {
             SCD_HIP(hipEventRecord(ev1, st));
             h->km_ev.emplace_back(ev0, ev1);

@@ -1338,3 +1338,23 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
         okm.fit(x)
     assert np.array_equal(res["1"][0], okm.labels_) and np.array_equal(res["1"][1], okm.cluster_centers_, equal_nan=True)
     assert res["1"][2] == float(okm.inertia_)
+
+
+@pytest.mark.parametrize("n,k", [(75700, 1000), (100000, 520)])
+def test_estep_rb_split_last_round(ops, n, k):
+    """estep_rb_kernel splits the row blocks of the chip's partial last round over the centres (n = 75,700: 40 of 296 row blocks,
+    four parts of 8 units; n = 100,000, K = 520 -> 640 padded: 135 blocks left, no split at 20 units / 2 parts of 10) and merges
+    their keys in estep_rb_merge_kernel: sampled rows, the first and the last rows of the split range equal the float64 oracle."""
+    g = torch.Generator(device="cuda").manual_seed(n)
+    d = 512
+    cen = torch.nn.functional.normalize(torch.randn(k, d, device="cuda", generator=g), dim=-1)
+    y = torch.randint(0, k, (n,), device="cuda", generator=g)
+    x = torch.nn.functional.normalize(cen[y] + (0.9 / d ** 0.5) * torch.randn(n, d, device="cuda", generator=g), dim=-1).contiguous()
+    c0 = x[torch.randperm(n, device="cuda", generator=g)[:k]].contiguous()
+    data = ops.KMeansData(x)
+    lab = data.estep(c0).cpu().numpy()
+    nfull = (n + 255) // 256 // 256 * 256
+    rows = np.unique(np.concatenate([np.random.RandomState(1).choice(n, 1500, replace=False), np.arange(nfull * 256 - 3, nfull * 256 + 300),
+                                     np.arange(n - 300, n)]))
+    olab, _, _ = ko.estep(x.cpu().numpy()[rows], c0.cpu().numpy())
+    assert np.array_equal(lab[rows].astype(np.int64), olab)
