@@ -185,6 +185,16 @@ size_t scd_vote_hist_ws_bytes(int64_t n, int top_k);
 int scd_vote_hist(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int top_k, const int64_t* preds,
                   const int64_t* clusters, int n_clusters, const int64_t* known, int n_known, int m,
                   int64_t* keys_out, int32_t* counts_out, void* ws, size_t ws_bytes, void* stream);
+/* The histogram over row SHARDS (one process per GPU).  scd_vote_table: this rank's dense tables counts int32 [C, V]
+ * (occurrences of a name among the first top_k columns of the rows predicted as cluster c) and first int64 [C, V] (smallest
+ * (row_offset + row) * top_k + column at which it occurs; 0x7f7f7f7f7f7f7f7f = never) - slot_of int32 [n_slots] maps a prediction to its
+ * table row (-1: not voted on).  The caller all-reduces counts with SUM and first with MIN over the ranks;
+ * scd_vote_table_topm then reads most_common(m) of every cluster off the reduced tables, (count desc, first asc) - the order of
+ * Counter.most_common on the concatenated rows (main_unsup.py:573-586).  It zeroes the counts it takes. */
+int scd_vote_table(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int top_k, const int64_t* preds, const int32_t* slot_of,
+                   int n_slots, int64_t row_offset, int64_t v, int n_clusters, int32_t* counts, int64_t* first, void* stream);
+int scd_vote_table_topm(scd_handle h, int32_t* counts, const int64_t* first, int n_clusters, int64_t v, int m, int64_t* keys_out,
+                        int32_t* counts_out, void* stream);
 
 /* ---- host solvers (CPU, synchronous) ---- */
 /* linear_assignment (gcd/project_utils/cluster_utils.py:234-493), same tie-breaking; pairs_out [min(n,m),2] sorted */

@@ -70,6 +70,8 @@ SIGNATURES = {
     "scd_sum_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),
     "scd_vote_hist": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "scd_vote_table": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp]),
+    "scd_vote_table_topm": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp]),
     "scd_munkres": (_i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
     "scd_munkres_sparse": (_i, [_i, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "scd_transport_solve": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(_i64)]),

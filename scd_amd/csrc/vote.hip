@@ -135,3 +135,90 @@ extern "C" int scd_vote_hist(scd_handle h, const int64_t* name_idx, int64_t n, i
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// The same histogram for row SHARDS: each rank builds the dense table of ITS rows - counts[c][name] and the first
+// position (global row * top_k + column) at which cluster c saw the name - the ranks all-reduce the two tables (sum / min), and
+// most_common(m) of every cluster is read off the reduced table: (count desc, first-seen asc), first-seen in (rank, row) = global
+// row order, exactly what Counter.most_common gives on the concatenated rows (main_unsup.py:573-586).
+__global__ void __launch_bounds__(256) vote_table_kernel(const long long* __restrict__ name_idx, long long n, int ld, int top_k,
+                                                         const long long* __restrict__ preds, const int* __restrict__ slot_of, int n_slots,
+                                                         long long row_offset, long long v, int* __restrict__ counts,
+                                                         unsigned long long* __restrict__ first) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * top_k) return;
+    const long long i = e / top_k;
+    const int j = (int)(e % top_k);
+    const long long p = preds[i];
+    const long long name = name_idx[i * ld + j];
+    if (p < 0 || p >= n_slots || name < 0 || name >= v) return;
+    const int slot = slot_of[p];
+    if (slot < 0) return;
+    atomicAdd(&counts[(size_t)slot * v + name], 1);
+    atomicMin(&first[(size_t)slot * v + name], (unsigned long long)((row_offset + i) * top_k + j));
+}
+
+// one block per cluster: m rounds of a block-wide arg-max over key = count << 40 | (2^40 - 1 - first); a taken name's count is zeroed
+__global__ void __launch_bounds__(256) vote_table_topm_kernel(int* __restrict__ counts, const unsigned long long* __restrict__ first, long long v,
+                                                              int m, long long* __restrict__ keys_out, int* __restrict__ counts_out) {
+    __shared__ unsigned long long rk[4];
+    __shared__ long long rn[4];
+    const int slot = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* cnt = counts + (size_t)slot * v;
+    const unsigned long long* fs = first + (size_t)slot * v;
+    for (int out = 0; out < m; ++out) {
+        unsigned long long bk = 0;
+        long long bn = -1;
+        for (long long nm = threadIdx.x; nm < v; nm += 256) {
+            const int c = cnt[nm];
+            if (c > 0) {
+                const unsigned long long key = ((unsigned long long)c << 40) | ((1ull << 40) - 1 - (fs[nm] & ((1ull << 40) - 1)));
+                if (key > bk) { bk = key; bn = nm; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ok = __shfl_xor(bk, o, 64);
+            const long long on = __shfl_xor(bn, o, 64);
+            if (ok > bk) { bk = ok; bn = on; }
+        }
+        if (lane == 0) { rk[wave] = bk; rn[wave] = bn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int w = 0;
+            for (int q = 1; q < 4; ++q)
+                if (rk[q] > rk[w]) w = q;
+            keys_out[(long long)slot * m + out] = rn[w];
+            counts_out[(long long)slot * m + out] = rn[w] >= 0 ? (int)(rk[w] >> 40) : 0;
+            if (rn[w] >= 0) cnt[rn[w]] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int scd_vote_table(scd_handle h, const int64_t* name_idx, int64_t n, int ld, int top_k, const int64_t* preds,
+                              const int32_t* slot_of, int n_slots, int64_t row_offset, int64_t v, int n_clusters, int32_t* counts,
+                              int64_t* first, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_vote_table");
+    SCD_REQUIRE(name_idx && preds && slot_of && counts && first, "scd_vote_table: null argument");
+    SCD_REQUIRE(n > 0 && top_k > 0 && top_k <= ld && v > 0 && n_clusters > 0 && n_slots > 0, "scd_vote_table: bad shape");
+    SCD_REQUIRE((row_offset + n) * top_k < (1ll << 40), "scd_vote_table: global rows x top_k must be < 2^40");
+    hipStream_t st = (hipStream_t)stream_;
+    SCD_HIP(hipMemsetAsync(counts, 0, (size_t)n_clusters * v * 4, st));
+    SCD_HIP(hipMemsetAsync(first, 0x7F, (size_t)n_clusters * v * 8, st));          // "never seen" = 0x7f7f...: above every position, also as a SIGNED int64 (MIN all-reduce)
+    vote_table_kernel<<<(unsigned)scd_cdiv(n * top_k, 256), 256, 0, st>>>((const long long*)name_idx, n, ld, top_k, (const long long*)preds, slot_of,
+                                                                           n_slots, row_offset, v, counts, (unsigned long long*)first);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+extern "C" int scd_vote_table_topm(scd_handle h, int32_t* counts, const int64_t* first, int n_clusters, int64_t v, int m,
+                                   int64_t* keys_out, int32_t* counts_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_vote_table_topm");
+    SCD_REQUIRE(counts && first && keys_out && counts_out && n_clusters > 0 && v > 0 && m > 0, "scd_vote_table_topm: bad arguments");
+    vote_table_topm_kernel<<<n_clusters, 256, 0, (hipStream_t)stream_>>>(counts, (const unsigned long long*)first, v, m, (long long*)keys_out,
+                                                                         counts_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}

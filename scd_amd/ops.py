@@ -412,6 +412,35 @@ def vote_hist(name_idx, top_k, preds, clusters, m, known=None):
     return keys, counts
 
 
+def vote_table(name_idx, top_k, preds, clusters, n_slots, row_offset, v):
+    """This rank's dense vote tables for its row shard (scd_vote_table): counts int32 [C, V], first int64 [C, V]
+    (global first-seen position, all ones = never).  clusters: the cluster ids voted on, in table-row order."""
+    _need_cuda(name_idx, preds)
+    name_idx = name_idx.to(torch.int64).contiguous()
+    preds = preds.to(torch.int64).contiguous()
+    dev = name_idx.device
+    nc = len(clusters)
+    slot = torch.full((n_slots,), -1, dtype=torch.int32)
+    slot[torch.as_tensor(clusters, dtype=torch.int64)] = torch.arange(nc, dtype=torch.int32)
+    slot = slot.to(dev)
+    counts = torch.empty((nc, v), dtype=torch.int32, device=dev)
+    first = torch.empty((nc, v), dtype=torch.int64, device=dev)
+    n, ld = name_idx.shape
+    check(_L().scd_vote_table(handle(), ptr(name_idx), n, ld, top_k, ptr(preds), ptr(slot), n_slots, int(row_offset), int(v), nc,
+                              ptr(counts), ptr(first), stream_ptr()))
+    return counts, first
+
+
+def vote_table_topm(counts, first, m):
+    """most_common(m) per cluster from the (all-reduced) tables: (keys int64 [C, m], counts int32 [C, m]); -1 / 0 padded."""
+    _need_cuda(counts, first)
+    nc, v = counts.shape
+    keys = torch.empty((nc, m), dtype=torch.int64, device=counts.device)
+    cnt = torch.empty((nc, m), dtype=torch.int32, device=counts.device)
+    check(_L().scd_vote_table_topm(handle(), ptr(counts), ptr(first), nc, v, m, ptr(keys), ptr(cnt), stream_ptr()))
+    return keys, cnt
+
+
 # ----------------------------------------------------------------------------- host solvers
 def munkres(cost):
     """linear_assignment (cluster_utils.py:234): int array [n,m] -> sorted pairs [min(n,m),2]."""

@@ -3,8 +3,9 @@ stage order of /root/reference/main_unsup.py:298-641 with the I/O and eval print
 __graft_entry__.smoke() and main_unsup.py --synthetic.  Everything numeric is a libscd_hip.so call.
 
 Multi-GPU: images (and their features) are sharded over ranks; W is replicated; K-Means exchanges one packed
-all-reduce per Lloyd iteration; the vote gathers the (tiny) top-k index table so that every rank computes the same
-global histogram and Munkres assignment, then re-classifies its own shard.
+all-reduce per Lloyd iteration; the vote histograms each rank's own rows into a dense [clusters, V] table, all-reduces it
+(counts: sum, first-seen positions: min), rank 0 solves the assignment and broadcasts the K candidate names, and every rank
+re-classifies its own shard.
 """
 import numpy as np
 import torch
@@ -22,20 +23,6 @@ def encode_images(model, images, batch, out=None):
     for s in range(0, n, batch):
         out[s:s + batch] = enc.encode_image(images[s:s + batch], normalize=True)
     return out
-
-
-def _allgather_rows(t, group):
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    lens = [torch.empty(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(lens, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
-    lens = [int(x) for x in lens]
-    mx = max(lens)
-    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:l] for o, l in zip(outs, lens)]), lens
 
 
 def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2,
@@ -73,14 +60,23 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
 
 
 def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50, be=None):
-    """main_unsup.py:568-614 over row shards.  The histogram is global, with rows in (rank, row) = global order, so the int64
-    top-k table is all-gathered once and the int predictions once per iteration (N_u * 8 B); every rank then computes the same
-    histograms and the same Munkres assignment (identical inputs -> identical names, no broadcast needed) and re-classifies
-    only its own rows.  `be` = the op set (default scd_amd.ops; tests/test_dist_gloo.py passes an oracle-backed stand-in)."""
+    """main_unsup.py:568-614 over row shards, with the exchange of SURVEY.md 8e.  Per iteration every rank histograms ITS rows into
+    a dense [clusters, V] table (counts, first-seen position in global row order), the tables are all-reduced (sum / min), and
+    most_common(m) of every cluster is read off the reduced table - what Counter.most_common gives on the concatenated rows.  Rank 0
+    solves the assignment (Munkres, host) and broadcasts the voted names, the assignment and the K candidate columns; every rank
+    re-classifies only its own rows.  O(N / world) device work per rank and iteration; the collectives carry 12 bytes per
+    (cluster, name) pair, whatever N is.  `be` = the op set (default scd_amd.ops; tests/test_dist_gloo.py passes an oracle-backed
+    stand-in)."""
     import copy
+    import torch.distributed as dist
     from .local_utils.clip_lang_util import assign_name
     be = be or ops
-    g_idx, lens = _allgather_rows(name_idx, group)
+    dev = name_idx.device
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lens = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(lens, torch.tensor([name_idx.shape[0]], dtype=torch.int64, device=dev), group=group)
+    row_offset = int(sum(int(x) for x in lens[:rank]))
+    v = wt.shape[0]
     first = {}
     for j, n in enumerate(nouns):
         first.setdefault(n, j)
@@ -88,22 +84,46 @@ def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, n
     m = max(ncv, ncl)
     cur, prev, cand, trace = [0], [1], list(nouns), []
     u_preds = u_preds.to(torch.int64)
+    n_slots = max(n_cluster, int(u_preds.max().item()) + 1 if u_preds.numel() else 1)
+    ns = torch.tensor([n_slots], dtype=torch.int64, device=dev)
+    dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)
+    n_slots = int(ns.item())
     while set(cur) != set(prev) and len(trace) < max_iter:
-        g_preds, _ = _allgather_rows(u_preds, group)
-        clusters = list(set(g_preds.cpu().numpy().tolist()))
-        keys, counts = be.vote_hist(g_idx, top_k, g_preds, clusters, m)
-        keys, counts = keys.cpu().numpy(), counts.cpu().numpy()
-        c2c = {c: naming.TopCounter(keys[i], counts[i]) for i, c in enumerate(clusters)}
-        voted = []
-        for i in clusters:
-            voted += [c[0] for c in c2c[i].most_common(ncv)]
-        voted = list(set(voted))
-        ind, w = assign_name(voted, c2c, num_common=ncl)
+        # the clusters present anywhere (python-set order of the ids, main_unsup.py:573)
+        present = torch.bincount(u_preds, minlength=n_slots).to(torch.int64)
+        dist.all_reduce(present, group=group)
+        clusters = list(set(torch.nonzero(present).reshape(-1).cpu().numpy().tolist()))
+        counts, firsts = be.vote_table(name_idx, top_k, u_preds, clusters, n_slots, row_offset, v)
+        dist.all_reduce(counts, group=group)
+        dist.all_reduce(firsts, op=dist.ReduceOp.MIN, group=group)
+        keys, cnts = be.vote_table_topm(counts, firsts, m)
+        # rank 0: names voted on, assignment (Munkres); broadcast [n_voted | voted | ind (pairs)]
+        nc = len(clusters)
+        if rank == 0:
+            keys_h, cnts_h = keys.cpu().numpy(), cnts.cpu().numpy()
+            c2c = {c: naming.TopCounter(keys_h[i], cnts_h[i]) for i, c in enumerate(clusters)}
+            voted = []
+            for i in clusters:
+                voted += [c[0] for c in c2c[i].most_common(ncv)]
+            voted = list(set(voted))
+            ind, w = assign_name(voted, c2c, num_common=ncl)
+            pack = np.concatenate([[len(voted), len(ind)], np.asarray(voted, dtype=np.int64), np.asarray(ind, dtype=np.int64).reshape(-1)])
+        else:
+            pack = None
+        hdr = torch.tensor([0 if pack is None else len(pack)], dtype=torch.int64, device=dev)
+        dist.broadcast(hdr, 0, group=group)
+        buf = torch.empty(int(hdr.item()), dtype=torch.int64, device=dev) if pack is None else torch.from_numpy(pack.astype(np.int64)).to(dev)
+        dist.broadcast(buf, 0, group=group)
+        arr = buf.cpu().numpy()
+        nv, ni = int(arr[0]), int(arr[1])
+        voted = arr[2:2 + nv].tolist()
+        ind = arr[2 + nv:2 + nv + 2 * ni].reshape(ni, 2)
         prev = copy.deepcopy(cur)
         cur = [nouns[voted[x[1]]] for x in ind[:n_cluster]]
         cand = copy.deepcopy(cur)
-        cols = torch.tensor([first[n] for n in cand], dtype=torch.int64, device=name_idx.device)
+        cols = torch.tensor([first[n] for n in cand], dtype=torch.int64, device=dev)
         u_preds, _ = be.sim_argmax(f_u, be.gather_rows_f16(wt, cols))
+        u_preds = u_preds.to(torch.int64)
         trace.append(dict(voted=np.array(voted, dtype=np.int64), ind=ind, cand=cols.cpu().numpy(), u_preds=u_preds.cpu().numpy()))
     return cand, u_preds.cpu().numpy(), trace
 

@@ -93,8 +93,9 @@ class OracleBackend:
 
 
 class OracleNamingOps:
-    """TEST-ONLY stand-in for the three naming ops pipeline.vote_loop_unsup_sharded calls (scd_amd.ops.vote_hist,
-    gather_rows_f16, sim_argmax), on the numpy oracle - so that the row-sharded vote can run under gloo on CPU."""
+    """TEST-ONLY stand-in for the naming ops pipeline.vote_loop_unsup_sharded calls (scd_amd.ops.vote_table,
+    vote_table_topm, gather_rows_f16, sim_argmax; vote_hist for the single-rank form), on the numpy oracle - so that the row-sharded
+    vote can run under gloo on CPU."""
 
     def vote_hist(self, name_idx, top_k, preds, clusters, m, known=None):
         from oracle import naming_oracle as no
@@ -105,6 +106,33 @@ class OracleNamingOps:
             for j, (a, b) in enumerate(ref[c].most_common(m)):
                 keys[i, j], counts[i, j] = a, b
         return torch.from_numpy(keys), torch.from_numpy(counts)
+
+    def vote_table(self, name_idx, top_k, preds, clusters, n_slots, row_offset, v):
+        """numpy restatement of scd_vote_table: dense counts / first-seen tables of this rank's rows."""
+        idx, pr = name_idx.numpy(), preds.numpy()
+        slot = {c: i for i, c in enumerate(clusters)}
+        counts = np.zeros((len(clusters), v), dtype=np.int32)
+        first = np.full((len(clusters), v), 0x7F7F7F7F7F7F7F7F, dtype=np.int64)
+        for i in range(idx.shape[0]):
+            s = slot.get(int(pr[i]))
+            if s is None:
+                continue
+            for j in range(top_k):
+                nm = int(idx[i, j])
+                counts[s, nm] += 1
+                first[s, nm] = min(first[s, nm], (row_offset + i) * top_k + j)
+        return torch.from_numpy(counts), torch.from_numpy(first)
+
+    def vote_table_topm(self, counts, first, m):
+        c, f = counts.numpy(), first.numpy()
+        keys = np.full((c.shape[0], m), -1, dtype=np.int64)
+        cnt = np.zeros((c.shape[0], m), dtype=np.int32)
+        for s in range(c.shape[0]):
+            nz = np.nonzero(c[s])[0]
+            order = sorted(nz.tolist(), key=lambda nm: (-int(c[s, nm]), int(f[s, nm])))[:m]
+            for j, nm in enumerate(order):
+                keys[s, j], cnt[s, j] = nm, c[s, nm]
+        return torch.from_numpy(keys), torch.from_numpy(cnt)
 
     def gather_rows_f16(self, wt, idx):
         return wt[idx]

@@ -1358,3 +1358,24 @@ def test_estep_rb_split_last_round(ops, n, k):
                                      np.arange(n - 300, n)]))
     olab, _, _ = ko.estep(x.cpu().numpy()[rows], c0.cpu().numpy())
     assert np.array_equal(lab[rows].astype(np.int64), olab)
+
+
+@pytest.mark.parametrize("n,k,v,topk,m", [(5000, 12, 2100, 3, 10), (20000, 100, 21000, 5, 20), (300, 7, 50, 2, 4)])
+def test_vote_table_equals_vote_hist(ops, n, k, v, topk, m):
+    """The sharded form of the vote histogram (dense per-rank table -> all-reduce -> most_common) on one rank, and
+    split over two row shards with the tables added / min-ed by hand, gives scd_vote_hist's keys and counts - Counter.most_common
+    order: count descending, ties in first-seen (global row-major) order."""
+    rs = np.random.RandomState(n)
+    idx = rs.randint(0, max(2, v // 40), size=(n, 5)).astype(np.int64)            # few distinct names: many ties in the counts
+    preds = rs.randint(0, k, size=n).astype(np.int64)
+    preds[preds == 3] = 4                                                         # a cluster id nobody predicts
+    clusters = sorted(set(preds.tolist()))
+    keys, cnt = ops.vote_hist(dev(idx), topk, dev(preds), clusters, m)
+    c1, f1 = ops.vote_table(dev(idx), topk, dev(preds), clusters, k, 0, v)
+    k1, n1 = ops.vote_table_topm(c1, f1, m)
+    assert torch.equal(k1, keys) and torch.equal(n1, cnt)
+    cut = n // 3
+    ca, fa = ops.vote_table(dev(idx[:cut]), topk, dev(preds[:cut]), clusters, k, 0, v)
+    cb, fb = ops.vote_table(dev(idx[cut:]), topk, dev(preds[cut:]), clusters, k, cut, v)
+    k2, n2 = ops.vote_table_topm(ca + cb, torch.minimum(fa, fb), m)
+    assert torch.equal(k2, keys) and torch.equal(n2, cnt)
