@@ -273,7 +273,7 @@ def secondary_rooflines(out, wt, dev):
     t = timeit(lambda: ops.sim_topk(feats, wt, 3, "softmax"), 5)
     fb_rows = int(ops.sim_topk(feats, wt, 3, "softmax", return_fallback=True)[2].item())
     fl = 2.0 * n * v * d
-    res.append({"kernel": "scd_sim_topk call (wmax + sim_topk_rc_kernel + sim_refine4_kernel + exact-pass launches), softmax k = 3, %d x %d x %d" % (n, v, d), "bound": "mfma",
+    res.append({"kernel": "scd_sim_topk call (wmax + sim_topk_rb8_kernel + sim_refine4_kernel + exact-pass launches), softmax k = 3, %d x %d x %d" % (n, v, d), "bound": "mfma",
                 "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4),
                 "call_us": round(t * 1e6, 1), "rows_through_exact_pass": fb_rows})
     x = feats.float()
@@ -286,7 +286,8 @@ def secondary_rooflines(out, wt, dev):
     def estep_line(tag, dat, cen, few):
         _, ref = dat.estep(cen, return_refined=True)
         t = timeit(lambda: dat.estep(cen, expect_few=few))
-        name = "scd_kmeans_estep call (centre prep + estep_stream_kernel + refine), N=%d D=%d K=%d, %s" % (n, d, k, tag)
+        kern = "estep_rb_kernel" if (d == 512 and 128 < k <= 2048) else ("estep_stream_kernel" if k <= 128 else "estep_mfma_kernel")
+        name = "scd_kmeans_estep call (centre prep + %s + refine), N=%d D=%d K=%d, %s" % (kern, n, d, k, tag)
         if k > 300:            # with 16-bit MFMA operands the E-step is matrix-bound beyond K ~ 300
             fl_e = 2.0 * n * k * d
             return {"kernel": name, "bound": "mfma", "achieved": round(fl_e / t / 1e12, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
@@ -326,8 +327,10 @@ def secondary_rooflines(out, wt, dev):
                               % (len(late), n, d, k),
                     "bound": "hbm", "achieved": round(by / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / t / 8e12, 4),
                     "kernel_us": round(t * 1e6, 1), "kernel_us_median": round(float(np.median(late)) * 1e6, 1),
-                    "kernel_us_all_launches": round(float(smp.mean()) * 1e6, 1), "fit_wall_ms": round(wall * 1e3, 2),
-                    "wall_us_per_iteration": round(wall * 1e6 / 30, 1)})
+                    "kernel_us_all_launches": round(float(smp.mean()) * 1e6, 1),
+                    "fit_wall_ms_incl_seeding": round(wall * 1e3, 2),
+                    "note": "HIP-event brackets include the dispatch latency of the bracketed launch (~5-8 us on a 30 us kernel); the "
+                            "rocprofv3 kernel trace of tools/sskm_phases.py (profiles/r03_sskm_phases_kernel_stats.csv) has the kernel alone"})
     return res
 
 

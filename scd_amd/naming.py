@@ -257,6 +257,43 @@ def evaluate_semantic_acc_ub_lb(clip_feats, targets, cidx_to_cname, nouns, zeros
 
 
 # ----------------------------------------------------------------------------- soft sACC
+def get_topk_name_indices(loader, cidx_to_cname, nouns, zeroshot_weights, model, with_target=True, verbose=True):
+    """main_unsup.py:43-75 (and, with_target=False, get_topk_name_indices_wotarget :77-111): the loader form of the naming pass -
+    per batch encode_image -> L2-normalise -> 100 f @ W -> top-5 names and raw logits, plus the zero-shot top-1 / top-5 accuracy
+    against the vocabulary index of each image's class name.  The reference reads a global `model`; here it is an argument.  The
+    N x V logits are never materialised (scd_sim_topk); ties among equal logits go to the lower name index.
+    Returns (name_idx_top5 int64 [N, 5], name_logits_top5 float32 [N, 5]) on the device, like the reference's torch.cat."""
+    first = _first_index(nouns)
+    wt = _as_wt(zeroshot_weights)
+    k = min(5, wt.shape[0])
+    idxs, vals = [], []
+    top1 = top5 = n = 0.0
+    with torch.no_grad():
+        for batch in loader:
+            images, target = batch[0], batch[1]
+            f = model.encode_image(images.cuda())
+            f = ops.l2norm_rows(f)
+            idx, val = ops.sim_topk(f, wt, k, "raw", 100.0)
+            idxs.append(idx)
+            vals.append(val)
+            if with_target:
+                tgt = torch.tensor([first[cidx_to_cname[int(t)]] if cidx_to_cname[int(t)] in first else nouns.index(cidx_to_cname[int(t)])
+                                    for t in np.asarray(target)], dtype=torch.int64, device=idx.device)
+                hit = idx == tgt.view(-1, 1)
+                top1 += float(hit[:, 0].sum().item())
+                top5 += float(hit.any(1).sum().item())
+            n += images.shape[0]
+    if with_target and verbose:
+        print(f"Top-1 accuracy: {top1 / n * 100:.2f}")
+        print(f"Top-5 accuracy: {top5 / n * 100:.2f}")
+    return torch.cat(idxs, dim=0), torch.cat(vals, dim=0)
+
+
+def get_topk_name_indices_wotarget(loader, cidx_to_cname, nouns, zeroshot_weights, model):
+    """main_unsup.py:77-111."""
+    return get_topk_name_indices(loader, cidx_to_cname, nouns, zeroshot_weights, model, with_target=False)
+
+
 def calucate_dis_between_names(pred_name, target_name, wnid_to_synset, name_to_wnids):
     """main_unsup.py:170-188 (the reference's spelling): max Leacock-Chodorow similarity over the synsets of two names."""
     pred_wnids = name_to_wnids[pred_name]

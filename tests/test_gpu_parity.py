@@ -1379,3 +1379,31 @@ def test_vote_table_equals_vote_hist(ops, n, k, v, topk, m):
     cb, fb = ops.vote_table(dev(idx[cut:]), topk, dev(preds[cut:]), clusters, k, cut, v)
     k2, n2 = ops.vote_table_topm(ca + cb, torch.minimum(fa, fb), m)
     assert torch.equal(k2, keys) and torch.equal(n2, cnt)
+
+
+def test_get_topk_name_indices_loader_form(ops, capsys):
+    """main_unsup.py:43-111: the loader form (encode -> normalise -> sim -> top-5 per batch) returns what the cached-feature form
+    returns on the same images, and prints the reference's two accuracy lines."""
+    from scd_amd import naming
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=2), text=False)
+    model = CLIP(sd).cuda()
+    g = torch.Generator().manual_seed(9)
+    imgs = torch.randn(24, 3, 224, 224, generator=g).half()
+    tgt = torch.arange(24) % 6
+    loader = [(imgs[i:i + 8], tgt[i:i + 8], None, None) for i in range(0, 24, 8)]
+    feats = ops.l2norm_rows(model.encode_image(imgs.cuda()))
+    rs = np.random.RandomState(4)
+    w = rs.randn(512, 300).astype(np.float32)
+    w[:, :6] = feats.float().cpu().numpy()[:6].T + 0.05 * rs.randn(512, 6)
+    w = (w / np.linalg.norm(w, axis=0, keepdims=True)).astype(np.float16)
+    nouns = ["n%03d" % j for j in range(300)]
+    cidx = {c: nouns[c] for c in range(6)}
+    idx, val = naming.get_topk_name_indices(loader, cidx, nouns, dev(w), model)
+    ri, rv = ops.sim_topk(feats, ops.transpose_f16(dev(w)), 5, "raw")
+    assert torch.equal(idx, ri) and torch.equal(val, rv)
+    out = capsys.readouterr().out
+    assert "Top-1 accuracy:" in out and "Top-5 accuracy:" in out
+    i2, v2 = naming.get_topk_name_indices_wotarget(loader, cidx, nouns, dev(w), model)
+    assert torch.equal(i2, ri) and torch.equal(v2, rv)

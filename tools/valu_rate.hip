@@ -18,6 +18,12 @@ __global__ void __launch_bounds__(256) probe(float* out, float seed) {
             if (OP == 4) { asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
             if (OP == 5) { asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
             if (OP == 6) { asm volatile("v_mul_f64 %0, %0, %0\n v_mul_f64 %1, %1, %1\n v_mul_f64 %2, %2, %2\n v_mul_f64 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
+            if (OP == 8) { asm volatile("v_exp_f16 %0, %0\n v_exp_f16 %1, %1\n v_exp_f16 %2, %2\n v_exp_f16 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
+            if (OP == 9) { asm volatile("v_rcp_f16 %0, %0\n v_rcp_f16 %1, %1\n v_rcp_f16 %2, %2\n v_rcp_f16 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
+            if (OP == 10) { asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
+            if (OP == 11) { asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1" : "+v"(a0), "+v"(a1)); asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1" : "+v"(a2), "+v"(a3)); }
+            if (OP == 12) { asm volatile("v_pk_mul_f16 %0, %0, %0\n v_pk_mul_f16 %1, %1, %1\n v_pk_mul_f16 %2, %2, %2\n v_pk_mul_f16 %3, %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
+            if (OP == 13) { asm volatile("v_max_f64 %0, %0, %0\n v_max_f64 %1, %1, %1\n v_max_f64 %2, %2, %2\n v_max_f64 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
             if (OP == 7) { asm volatile("v_cvt_f32_f64 %4, %0\n v_cvt_f32_f64 %5, %1\n v_cvt_f32_f64 %6, %2\n v_cvt_f32_f64 %7, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
         }
     }
@@ -53,6 +59,12 @@ int main() {
         run<7>("v_cvt_f32_f64", w);
         run<3>("v_cvt_f32_f16", w);
         run<5>("v_exp_f32", w);
+        run<10>("v_rcp_f32", w);
+        run<8>("v_exp_f16", w);
+        run<9>("v_rcp_f16", w);
+        run<11>("v_pk_mul_f32", w);
+        run<12>("v_pk_mul_f16", w);
+        run<13>("v_max_f64", w);
     }
     return 0;
 }
