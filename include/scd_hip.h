@@ -145,6 +145,20 @@ int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep
                                 float* C_out, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,
                                 const double* sumsq4, double* stats, int flags, void* ws_e, size_t ws_e_bytes, void* ws_m,
                                 size_t ws_m_bytes, void* stream);
+/* One restart's whole Lloyd loop behind one call (faster_mix_k_means_pytorch.py:187-214: up to max_iter iterations of
+ * scd_kmeans_lloyd_step_delta from C_start, stop after the iteration whose centre shift is below tol, keep the labels / centres of
+ * the iteration with the least float32 inertia).  The host stays one iteration behind the device (iteration i + 1 is enqueued
+ * before iteration i's statistics are looked at; a speculative iteration behind a converged one is dropped); the statistics reach
+ * the host through pinned memory written by the iteration's last kernel, so nothing but the iterations' kernels enters the stream.
+ * Caller-owned device rings: lab_ring int32 [3][n_cat] (iteration i's labels in slot i % 3; labels_lab = the n_cat - n_u labelled
+ * rows' labels, NULL when there are none), C_ring float [3][k,d], stats_ring double [2][5].  Outputs: best_labels int32 [n_cat] and
+ * best_C [k,d] on the device (valid in stream order), result_host (HOST double [4]) = {least inertia, iterations done, iterations
+ * with the incremental M-step, iterations launched}.  Returns when the last iteration's statistics have arrived. */
+int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat, int d,
+                         int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev, const float* C_start,
+                         float* C_ring, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,
+                         const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* best_labels, float* best_C,
+                         double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream);
 /* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
  * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
  * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips

@@ -63,6 +63,10 @@ SIGNATURES = {
     "scd_kmeans_sumsq": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _vp, _vp]),
     "scd_kmeans_lloyd_step_delta": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz,
                                          _vp, _sz, _vp]),
+    # h, X_u, prep, n_u, X16, n_cat, d, k, labels_lab, lab_ring, labels_prev, C_start, C_ring, sums, counts, sums_lab, counts_lab, sumsq4,
+    # stats_ring, max_iter, tol, best_labels, best_C, result_host, ws_e, nb_e, ws_m, nb_m, stream
+    "scd_kmeans_lloyd_run": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double,
+                                  _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "scd_kmeans_lloyd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "scd_kmeans_min_update_multi": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp]),
     "scd_kpp_draw_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

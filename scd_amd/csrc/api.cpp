@@ -63,6 +63,7 @@ extern "C" int scd_create(int device, scd_handle* out) {
 extern "C" int scd_destroy(scd_handle h) {
     if (h) scd_comm_destroy(h);             // the communicator map is keyed by the handle: a later handle at the same address must not inherit it
     if (h && h->scratch) hipFree(h->scratch);
+    if (h && h->run_host) hipHostFree(h->run_host);
     delete h;
     return SCD_OK;
 }

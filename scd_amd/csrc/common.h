@@ -27,6 +27,11 @@ struct scd_ctx {
     bool km_timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> km_ev;
     int estep_few;          // scd_kmeans_estep_hint: the next E-step re-evaluates its (few) flagged rows in the filter kernel's tail
+    // scd_kmeans_lloyd_run: pinned, device-mapped host ring (2 x 8 doubles) finalize_kernel publishes an iteration's statistics in
+    // ({inertia l, inertia u, shift, refined, changed, -, -, sequence number}), its device address, the last sequence number used
+    double* run_host = nullptr;
+    double* run_dev = nullptr;
+    double run_seq = 0.0;
 };
 #define SCD_SCRATCH_BYTES (262144 + 64)
 

@@ -337,6 +337,39 @@ __device__ __forceinline__ void es_insert(float& b0, float& b1, float& b2, float
     b0 = es_min(b0, k);
 }
 
+// out[u] = wave_sum_f64(a[u]) for eight values at once.  Step o of the butterfly adds lanes l and l ^ o; here, in the first three steps,
+// each lane keeps only half of its values and sends the partner the other half (lane bit 5 / 4 / 3 <-> bit 2 / 1 / 0 of u), so 4 + 2 + 1
+// exchanges replace 3 x 8, and three more finish all eight sums in one register.  The same pairs are added in the same order (IEEE
+// addition is commutative), hence bit-identical totals; v_readlane hands them out.
+__device__ __forceinline__ void wave_sum8_f64(const double (&a)[8], double (&out)[8]) {
+    const int lane = threadIdx.x & 63;
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    double b[4], c[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const double keep = h5 ? a[u + 4] : a[u], send = h5 ? a[u] : a[u + 4];
+        b[u] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double keep = h4 ? b[u + 2] : b[u], send = h4 ? b[u] : b[u + 2];
+        c[u] = keep + __shfl_xor(send, 16, 64);
+    }
+    const double keep = h3 ? c[1] : c[0], send = h3 ? c[0] : c[1];
+    double e = keep + __shfl_xor(send, 8, 64);
+    e += __shfl_xor(e, 4, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);
+    const long long bits = __builtin_bit_cast(long long, e);
+    const int lo = (int)bits, hi = (int)(bits >> 32);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int src = 32 * ((u >> 2) & 1) + 16 * ((u >> 1) & 1) + 8 * (u & 1);
+        const unsigned rl = (unsigned)__builtin_amdgcn_readlane(lo, src), rh = (unsigned)__builtin_amdgcn_readlane(hi, src);
+        out[u] = __builtin_bit_cast(double, ((unsigned long long)rh << 32) | rl);
+    }
+}
+
 // exact re-evaluation of ONE flagged row (float64 difference form), shared by estep_refine_both_kernel and the tail of
 // estep_stream_kernel.  Pair form: one wave, the two candidate centres.  Full form: one 256-thread block, every centre.
 __device__ __forceinline__ void refine_pair_row(const float* __restrict__ X, const float* __restrict__ C, long long row, int cand,
@@ -394,15 +427,19 @@ __device__ __forceinline__ void refine_pair_row(const float* __restrict__ X, con
     if (lane == 0) labels[row] = bi;
 }
 
+// NW = waves of the block: wave w sweeps the centres w, w + NW, ... (eight per pass).  A row is a chain of dependent latencies (the
+// row into LDS, then per pass the centre loads, the float64 sweep and eight wave reductions), so the refine LAUNCH uses eight waves per
+// row (two passes at K <= 128 instead of four); the streaming kernel's tail runs with that kernel's four.
+template <int NW>
 __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, const float* __restrict__ C, long long row, int d, int k,
                                                 double* xs, double* rv, int* ri, int32_t* labels) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
-    for (int j = threadIdx.x; j < d; j += 256) xs[j] = (double)X[row * d + j];
+    for (int j = threadIdx.x; j < d; j += 64 * NW) xs[j] = (double)X[row * d + j];
     __syncthreads();
     double best = INFINITY;
     int bi = 0x7fffffff;
-    for (int c0 = wv; c0 < k; c0 += 32) {
+    for (int c0 = wv; c0 < k; c0 += 8 * NW) {
         double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if ((d & 3) == 0) {
             for (int j0 = 4 * lane; j0 < d; j0 += 768) {
@@ -411,7 +448,7 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
                 for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int v = 0; v < 3; ++v) {
-                        const int c = c0 + 4 * u, j = j0 + 256 * v;
+                        const int c = c0 + NW * u, j = j0 + 256 * v;
                         if (c < k && j < d) cv[u][v] = *(const float4*)(C + (size_t)c * d + j);
                     }
 #pragma unroll
@@ -421,7 +458,7 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
                         const double x0 = xs[j], x1 = xs[j + 1], x2 = xs[j + 2], x3 = xs[j + 3];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            if (c0 + 4 * u < k) {
+                            if (c0 + NW * u < k) {
                                 double t;
                                 t = x0 - (double)cv[u][v].x; a[u] = fma(t, t, a[u]);
                                 t = x1 - (double)cv[u][v].y; a[u] = fma(t, t, a[u]);
@@ -437,7 +474,7 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
                 const double x0 = xs[j];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + 4 * u;
+                    const int c = c0 + NW * u;
                     if (c < k) {
                         const double t = x0 - (double)C[(size_t)c * d + j];
                         a[u] = fma(t, t, a[u]);
@@ -445,11 +482,15 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
                 }
             }
         }
+        // the eight wave sums in ONE butterfly (wave_sum8_f64: bit-identical to eight wave_sum_f64, a fifth of the cross-lane traffic:
+        // eight separate reductions, serialised behind their guards, were most of a pass)
+        double tot[8];
+        wave_sum8_f64(a, tot);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int c = c0 + 4 * u;
+            const int c = c0 + NW * u;
             if (c < k) {
-                const double sum = wave_sum_f64(a[u]);
+                const double sum = tot[u];
                 if (sum < best || (sum == best && c < bi)) { best = sum; bi = c; }      // NaN never wins
             }
         }
@@ -458,7 +499,7 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
     __syncthreads();
     if (threadIdx.x == 0) {
         int w = 0;
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < NW; ++q)
             if (rv[q] < rv[w] || (rv[q] == rv[w] && ri[q] < ri[w])) w = q;
         labels[row] = ri[w] == 0x7fffffff ? 0 : ri[w];
     }
@@ -745,7 +786,7 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         int* ri = (int*)(rv + 4);
         const int n0 = cnts[0], n1 = cnts[1];
         for (int i = tid >> 6; i < n0; i += 4) refine_pair_row(Xf, Cf, l_flag[i], l_cand[i], d_f, tid & 63, labels);
-        for (int i = 0; i < n1; ++i) refine_full_row(Xf, Cf, l_full[i], d_f, k_f, xs, rv, ri, labels);
+        for (int i = 0; i < n1; ++i) refine_full_row<4>(Xf, Cf, l_full[i], d_f, k_f, xs, rv, ri, labels);
         if (tid == 0) {
             if (n0) atomicAdd(&eh->flag_cnt, n0);
             if (n1) atomicAdd(&eh->full_cnt, n1);
@@ -1112,32 +1153,34 @@ __global__ void __launch_bounds__(128) estep_refine_full_kernel(const float* __r
     }
 }
 
-// both refine passes in one launch (streaming path): the lower half of the grid walks the pair list one wave per row, the
-// upper half the full list one block per row.
-__global__ void __launch_bounds__(256) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
+// both refine passes in one launch (streaming path): all-centres rows one 8-wave block per row, pair rows one wave per row.
+#define REFINE_GRID (unsigned)SCD_ABLATE_ENV("SCD_REFINE_GRID", 1024)
+#define REFINE_PAIR SCD_ABLATE_ENV("SCD_REFINE_PAIR", 256)
+__global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
                                                                 const float* __restrict__ ct, const EHdr* eh, const int* flag_list,
                                                                 const int* flag_cand, const int* full_list, int d, int k, int kp,
-                                                                int32_t* labels, int32_t* refine_rows_out) {
+                                                                int32_t* labels, int32_t* refine_rows_out, int pair_blocks) {
     extern __shared__ double xs[];
-    __shared__ double rv[4];
-    __shared__ int ri[4];
-    const int half_grid = gridDim.x >> 1;
+    __shared__ double rv[8];
+    __shared__ int ri[8];
+    // the first gridDim.x - pair_blocks blocks: the all-centres list, one block per row (the long chain of latencies: scheduled first);
+    // the others: the pair list, one wave per row.  A block without work ends at once and makes room.
+    const int full_grid = gridDim.x - pair_blocks;
     if (blockIdx.x == 0 && threadIdx.x == 0 && refine_rows_out) *refine_rows_out = eh->flag_cnt + eh->full_cnt;
-    if ((int)blockIdx.x < half_grid) {
+    if ((int)blockIdx.x >= full_grid) {
         const int lane = threadIdx.x & 63;
         const int cnt = eh->flag_cnt;
-        for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < cnt; f += 4 * half_grid) {
+        for (int f = (blockIdx.x - full_grid) * 8 + (threadIdx.x >> 6); f < cnt; f += 8 * pair_blocks) {
             refine_pair_row(X, C, flag_list[f], flag_cand[f], d, lane, labels);
         }
         return;
     }
-    // full list: the row as doubles in LDS; each of the four waves sweeps every fourth centre, eight centres per pass, whole
+    // all-centres list: the row as doubles in LDS; the eight waves sweep every eighth centre, eight centres per pass, whole
     // centre rows in coalesced float4 loads that are all issued before the first is consumed (a walk down the transposed
     // matrix paid one memory latency per 4 columns)
     const int cnt = eh->full_cnt;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int f = blockIdx.x - half_grid; f < cnt; f += half_grid) {
-        refine_full_row(X, C, full_list[f], d, k, xs, rv, ri, labels);
+    for (int f = blockIdx.x; f < cnt; f += full_grid) {
+        refine_full_row<8>(X, C, full_list[f], d, k, xs, rv, ri, labels);
     }
 }
 
@@ -1208,8 +1251,8 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             SCD_HIP(hipEventRecord(ev1, st));
             h->km_ev.emplace_back(ev0, ev1);
         }
-        estep_refine_both_kernel<<<1024, 256, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
-                                                                         refine_rows_out);
+        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+                                                                                refine_rows_out, REFINE_PAIR);
         SCD_LAUNCH_CHECK();
         return SCD_OK;
     }
@@ -1261,8 +1304,8 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
             if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
         } else
-        estep_refine_both_kernel<<<1024, 256, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
-                                                                         refine_rows_out);
+        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+                                                                                refine_rows_out, REFINE_PAIR);
         SCD_LAUNCH_CHECK();
         return SCD_OK;
     }
@@ -1379,6 +1422,32 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
 
 // (M-step partial sums: see mstep.hip)
 
+// double-double helpers (used by finalize_kernel's fused inertia and the incremental M-step further down)
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ dd_t dd_add_d(dd_t a, double b) {      // a + b, b a plain double
+    const double s = a.hi + b;
+    const double bb = s - a.hi;
+    const double e = (a.hi - (s - bb)) + (b - bb);
+    const double lo = a.lo + e;
+    const double hi = s + lo;
+    return {hi, lo - (hi - s)};
+}
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) { return dd_add_d(dd_add_d(a, b.hi), b.lo); }
+__device__ __forceinline__ dd_t dd_add_prod(dd_t a, double x, double y) {    // a + x * y, the product error-free
+    const double p = x * y;
+    const double e = fma(x, y, -p);
+    return dd_add_d(dd_add_d(a, p), e);
+}
+__device__ __forceinline__ dd_t dd_wave_sum(dd_t v) {            // fixed butterfly order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dd_t ov;
+        ov.hi = __shfl_xor(v.hi, o, 64);
+        ov.lo = __shfl_xor(v.lo, o, 64);
+        v = dd_add(v, ov);
+    }
+    return v;
+}
 // centres = sums / counts; shift = (sum_k ||c_k - c_old_k||)^2.  One block per centre; the per-centre norms go to a scratch
 // array and the LAST block to arrive (ticket) adds them in index order, so the float64 result does not depend on the
 // arrival order.  (A single 1024-thread block took 31 us for K x D = 77k values.)  The scratch belongs to the handle: one
@@ -1387,9 +1456,15 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
                                                        const float* Cold, float* Cout, double* shift, double* part,
                                                        unsigned* ticket, int shift_mode, const PrepHdr* ph, const double* mu,
                                                        EHdr* eh, float* cn, half_t* ch, float* ct, int kp, half_t* chf,
-                                                       double* refined_out) {
+                                                       double* refined_out, double* changed_out, double* changed_acc,
+                                                       const double* stats5, double* mirror, double seq,
+                                                       const double* sums_lab, const long long* counts_lab, const double* sumsq4,
+                                                       double* inertia_out) {
     __shared__ double wred[4];
+    __shared__ double red[4][6];
     __shared__ bool last;
+    // inertia_out != NULL (incremental M-step): this launch also evaluates the iteration's inertia from the sums (the arithmetic of
+    // inertia_dd_kernel, partials behind the k shift partials) - both walk Cold / sums / counts per centre, one launch less
     const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // rows the E-step of this iteration re-evaluated exactly (read before this block's prep_center_row zeroes the counters)
     if (refined_out && eh && c == 0 && threadIdx.x == 0) *refined_out = (double)(eh->flag_cnt + eh->full_cnt);
@@ -1399,13 +1474,28 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
     }
     const double cnt = (double)counts[c];
     double ss = 0.0;
+    const long long nl = (inertia_out && counts_lab) ? counts_lab[c] : 0, nu = counts[c] - nl;
+    dd_t cc = {0.0, 0.0}, dl = {0.0, 0.0}, du = {0.0, 0.0};
     for (int j = threadIdx.x; j < d; j += 256) {
-        const float v = (float)(sums[(size_t)c * d + j] / cnt);     // 0/0 -> NaN for an empty cluster
+        const double sj = sums[(size_t)c * d + j];
+        const float v = (float)(sj / cnt);     // 0/0 -> NaN for an empty cluster
         Cout[(size_t)c * d + j] = v;
         if (Cold) {
-            const double df = (double)v - (double)Cold[(size_t)c * d + j];
+            const double co = (double)Cold[(size_t)c * d + j];
+            const double df = (double)v - co;
             ss = fma(df, df, ss);
+            if (inertia_out) {
+                const double sl = sums_lab ? sums_lab[(size_t)c * d + j] : 0.0;
+                const double su = sj - sl;          // exact: both are exact sums of multiples of 2^-24
+                cc = dd_add_prod(cc, co, co);
+                if (nl) dl = dd_add_prod(dl, co, sl);
+                if (nu) du = dd_add_prod(du, co, su);
+            }
         }
+    }
+    if (inertia_out) {
+        cc = dd_wave_sum(cc); dl = dd_wave_sum(dl); du = dd_wave_sum(du);
+        if (lane == 0) { red[wave][0] = cc.hi; red[wave][1] = cc.lo; red[wave][2] = dl.hi; red[wave][3] = dl.lo; red[wave][4] = du.hi; red[wave][5] = du.lo; }
     }
     if (ph) {                                       // the next E-step's operands of this centre, while its row is still in cache
         __syncthreads();
@@ -1419,6 +1509,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
     if (threadIdx.x == 0) {
         const double sq = (wred[0] + wred[1]) + (wred[2] + wred[3]);
         part[c] = shift_mode ? sq : sqrt(sq);
+        if (inertia_out) {
+            dd_t n2 = {0.0, 0.0}, pl = {0.0, 0.0}, pu = {0.0, 0.0};
+            for (int w = 0; w < 4; ++w) { n2 = dd_add(n2, {red[w][0], red[w][1]}); pl = dd_add(pl, {red[w][2], red[w][3]}); pu = dd_add(pu, {red[w][4], red[w][5]}); }
+            // t = n ||c||^2 - 2 <c, S>   (n < 2^31: the products with hi / lo are formed error-free)
+            dd_t tl = {0.0, 0.0}, tu = {0.0, 0.0};
+            if (nl) { tl = dd_add_prod(dd_add_prod(tl, (double)nl, n2.hi), (double)nl, n2.lo); tl = dd_add_d(dd_add_d(tl, -2.0 * pl.hi), -2.0 * pl.lo); }
+            if (nu) { tu = dd_add_prod(dd_add_prod(tu, (double)nu, n2.hi), (double)nu, n2.lo); tu = dd_add_d(dd_add_d(tu, -2.0 * pu.hi), -2.0 * pu.lo); }
+            double* ip = part + k;
+            ip[c * 4 + 0] = tl.hi; ip[c * 4 + 1] = tl.lo; ip[c * 4 + 2] = tu.hi; ip[c * 4 + 3] = tu.lo;
+        }
         __threadfence();
         last = atomicAdd(ticket, 1u) == (unsigned)k - 1;
     }
@@ -1434,17 +1534,67 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
             if (threadIdx.x < o) tred[threadIdx.x] += tred[threadIdx.x + o];
             __syncthreads();
         }
+        double in_l = 0.0, in_u = 0.0;
+        if (inertia_out) {                        // the K partials in the fixed tree order of inertia_dd_kernel
+            __shared__ double tr[256][4];
+            const double* ip = part + k;
+            dd_t il = {0.0, 0.0}, iu = {0.0, 0.0};
+            for (int q = threadIdx.x; q < k; q += 256) {
+                il = dd_add(il, {((volatile const double*)ip)[q * 4], ((volatile const double*)ip)[q * 4 + 1]});
+                iu = dd_add(iu, {((volatile const double*)ip)[q * 4 + 2], ((volatile const double*)ip)[q * 4 + 3]});
+            }
+            tr[threadIdx.x][0] = il.hi; tr[threadIdx.x][1] = il.lo; tr[threadIdx.x][2] = iu.hi; tr[threadIdx.x][3] = iu.lo;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    const dd_t a = dd_add({tr[threadIdx.x][0], tr[threadIdx.x][1]}, {tr[threadIdx.x + o][0], tr[threadIdx.x + o][1]});
+                    const dd_t b = dd_add({tr[threadIdx.x][2], tr[threadIdx.x][3]}, {tr[threadIdx.x + o][2], tr[threadIdx.x + o][3]});
+                    tr[threadIdx.x][0] = a.hi; tr[threadIdx.x][1] = a.lo; tr[threadIdx.x][2] = b.hi; tr[threadIdx.x][3] = b.lo;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                const dd_t fl = dd_add({sumsq4[0], sumsq4[1]}, {tr[0][0], tr[0][1]}), fu = dd_add({sumsq4[2], sumsq4[3]}, {tr[0][2], tr[0][3]});
+                in_l = fl.hi + fl.lo;
+                in_u = fu.hi + fu.lo;
+                inertia_out[0] = in_l;
+                inertia_out[1] = in_u;
+            }
+        }
         if (threadIdx.x == 0) {
-            *shift = shift_mode ? tred[0] : tred[0] * tred[0];
+            const double sh = shift_mode ? tred[0] : tred[0] * tred[0];
+            *shift = sh;
             *ticket = 0;
+            // rows whose label changed this iteration (accumulated by mstep_delta_kernel / labels_sync_kernel in the handle's scratch;
+            // nothing adds to it until the next iteration's kernels, which run after this one): hand over and reset
+            double chg = 0.0;
+            if (changed_out) {
+                chg = *(volatile double*)changed_acc;
+                *changed_out = chg;
+                *changed_acc = 0.0;
+            }
+            if (mirror) {
+                // scd_kmeans_lloyd_run: the iteration's five statistics straight into pinned host memory, then the sequence number the
+                // host spins on (system-scope fence in between) - no copy operation, no event in the stream
+                mirror[0] = inertia_out ? in_l : ((volatile const double*)stats5)[0];
+                mirror[1] = inertia_out ? in_u : ((volatile const double*)stats5)[1];
+                mirror[2] = sh;
+                mirror[3] = ((volatile const double*)stats5)[3];
+                mirror[4] = chg;
+                __threadfence_system();
+                ((volatile double*)mirror)[7] = seq;
+            }
         }
     }
 }
 
 static int finalize_impl(scd_handle h, const double* sums, const int64_t* counts, int k, int d, const float* C_old, float* C_out,
                          double* shift_out, int shift_mode, const void* prep, void* estep_ws, size_t estep_ws_bytes, int64_t n,
-                         void* stream_, double* refined_out) {
+                         void* stream_, double* refined_out, double* changed_out = nullptr, const double* stats5 = nullptr,
+                         double* mirror = nullptr, double seq = 0.0, const double* sums_lab = nullptr, const int64_t* counts_lab = nullptr,
+                         const double* sumsq4 = nullptr, double* inertia_out = nullptr) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_finalize");
+    double* changed_acc = (double*)((char*)h->scratch + 262144 + 40);
     SCD_REQUIRE(h && sums && counts && C_out && k > 0 && d > 0, "scd_kmeans_finalize: bad arguments");
     SCD_REQUIRE(C_old != C_out, "scd_kmeans_finalize: C_out must not alias C_old");
     SCD_REQUIRE(k <= 32768, "scd_kmeans_finalize: k=%d > 32768", k);
@@ -1465,7 +1615,9 @@ static int finalize_impl(scd_handle h, const double* sums, const int64_t* counts
         const char* p = (const char*)prep;
         finalize_kernel<<<kp, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
                                                               (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
-                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf, refined_out);
+                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf, refined_out,
+                                                              changed_out, changed_acc, stats5, mirror, seq, sums_lab, (const long long*)counts_lab,
+                                                              sumsq4, inertia_out);
         h->prep_C = C_out;
         h->prep_ws = estep_ws;
         h->prep_k = k;
@@ -1473,7 +1625,9 @@ static int finalize_impl(scd_handle h, const double* sums, const int64_t* counts
     } else {
         finalize_kernel<<<k, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
                                                              (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
-                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr, nullptr);
+                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, kp, nullptr, nullptr,
+                                                             changed_out, changed_acc, stats5, mirror, seq, sums_lab, (const long long*)counts_lab,
+                                                             sumsq4, inertia_out);
     }
     SCD_LAUNCH_CHECK();
     return SCD_OK;
@@ -2059,31 +2213,6 @@ extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_
 // evaluated in double-double arithmetic (error-free products by fma, two-sum accumulation) from the exact S_k, n_k, the float32
 // centres and sum ||x||^2 (once per fit, also double-double), separately for the labelled and the unlabelled rows - the value agrees
 // with the float64 row-by-row sum to ~1e-15 relative, like two summation orders of that sum.
-struct dd_t { double hi, lo; };
-__device__ __forceinline__ dd_t dd_add_d(dd_t a, double b) {      // a + b, b a plain double
-    const double s = a.hi + b;
-    const double bb = s - a.hi;
-    const double e = (a.hi - (s - bb)) + (b - bb);
-    const double lo = a.lo + e;
-    const double hi = s + lo;
-    return {hi, lo - (hi - s)};
-}
-__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) { return dd_add_d(dd_add_d(a, b.hi), b.lo); }
-__device__ __forceinline__ dd_t dd_add_prod(dd_t a, double x, double y) {    // a + x * y, the product error-free
-    const double p = x * y;
-    const double e = fma(x, y, -p);
-    return dd_add_d(dd_add_d(a, p), e);
-}
-__device__ __forceinline__ dd_t dd_wave_sum(dd_t v) {            // fixed butterfly order
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        dd_t ov;
-        ov.hi = __shfl_xor(v.hi, o, 64);
-        ov.lo = __shfl_xor(v.lo, o, 64);
-        v = dd_add(v, ov);
-    }
-    return v;
-}
 // sum of squares of the rows [0, split) and [split, n), double-double, two launches: per-block partials, then one block
 __global__ void __launch_bounds__(256) sumsq_dd_kernel(const half_t* __restrict__ X16, const float* __restrict__ X, long long n, int d,
                                                        long long split, double* part) {
@@ -2169,8 +2298,9 @@ __global__ void __launch_bounds__(256) labels_sync_kernel(const int32_t* __restr
         ch = a != labels_prev[i];
         if (ch) labels_prev[i] = a;
     }
-    const unsigned long long m = __ballot(ch);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(changed, (double)__popcll(m));
+    // one atomic per block: with every row changed (iteration 0) 1,500 wave atomics on the one address took 15 us
+    const int cnt = __syncthreads_count(ch);
+    if (threadIdx.x == 0 && cnt) atomicAdd(changed, (double)cnt);
 }
 // inertia of both row groups from the exact sums: block k -> n_k ||c_k||^2 - 2 <c_k, S_k> for the labelled rows (S_lab, n_lab) and for
 // the others (S - S_lab, n - n_lab); the last block adds the K partials in index order and the sums of squares
@@ -2233,11 +2363,11 @@ __global__ void __launch_bounds__(256) inertia_dd_kernel(const float* __restrict
     }
 }
 
-extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
-                                           int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
-                                           float* C_out, double* sums, int64_t* counts, const double* sums_lab,
-                                           const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
-                                           size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream) {
+static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                 int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
+                                 float* C_out, double* sums, int64_t* counts, const double* sums_lab,
+                                 const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
+                                 size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
     SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
                 "scd_kmeans_lloyd_step_delta: null argument");
@@ -2247,21 +2377,154 @@ extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const
     int rc = scd_kmeans_estep_hint(h, flags & (SCD_ESTEP_FEW | SCD_ESTEP_CENTRES_FROM_FINALIZE));
     if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
     if (rc) return rc;
-    SCD_HIP(hipMemsetAsync(stats + 4, 0, 8, st));
+    // rows whose label changed: accumulated in the handle's scratch (zero between iterations), handed to stats[4] by finalize_kernel
+    double* changed_acc = (double*)((char*)h->scratch + 262144 + 40);
+    bool fused_inertia = false;
     if (flags & SCD_LLOYD_FULL) {
         // a fresh M-step (sums, counts, inertia from the rows), then labels_prev = labels for the incremental steps that follow
         rc = scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
         if (rc) return rc;
-        labels_sync_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>(labels_cat, labels_prev, l_num, n_cat, stats + 4);
+        labels_sync_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>(labels_cat, labels_prev, l_num, n_cat, changed_acc);
     } else {
         mstep_delta_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>((const half_t*)X16_cat, labels_cat, labels_prev, l_num, n_cat, d, k, sums,
-                                                                          (unsigned long long*)counts, stats + 4);
-        // partials at the start of the handle's scratch (free between two finalize launches of this stream), own ticket word
-        inertia_dd_kernel<<<k, 256, 0, st>>>(C_in, sums, (const long long*)counts, sums_lab, (const long long*)counts_lab, sumsq4, k, d,
-                                             (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144 + 32), stats);
+                                                                          (unsigned long long*)counts, changed_acc);
+        // the inertia from the sums: inside finalize_kernel when its 4 k partials fit behind the k shift partials in the handle's scratch
+        // (32,768 doubles), else in a launch of its own (partials at the start of the scratch, free between two finalize launches)
+        fused_inertia = 5 * (long long)k <= 32768;
+        if (!fused_inertia)
+            inertia_dd_kernel<<<k, 256, 0, st>>>(C_in, sums, (const long long*)counts, sums_lab, (const long long*)counts_lab, sumsq4, k, d,
+                                                 (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144 + 32), stats);
     }
     SCD_LAUNCH_CHECK();
-    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3);
+    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3, stats + 4, stats,
+                         mirror, seq, sums_lab, counts_lab, sumsq4, fused_inertia ? stats : nullptr);
+}
+
+extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                           int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
+                                           float* C_out, double* sums, int64_t* counts, const double* sums_lab,
+                                           const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
+                                           size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream) {
+    return lloyd_step_delta_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_cat, labels_prev, C_in, C_out, sums, counts, sums_lab,
+                                 counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m, ws_m_bytes, stream, nullptr, 0.0);
+}
+
+// One restart's Lloyd loop behind ONE call (the loop of scd_amd/kmeans.py:_lloyd_pipelined, faster_mix_k_means_pytorch.py:187-214):
+// the host runs one iteration behind the device - iteration i + 1 is enqueued (from iteration i's centres, which is what the
+// sequential loop uses unless i has converged) before iteration i's statistics are looked at; if i turns out to have converged,
+// i + 1 is dropped unseen.  Nothing but the iteration's kernels enters the stream:
+//  * the statistics reach the host through pinned memory written by finalize_kernel's last block (the host spins on a sequence
+//    number), not through a copy + event;
+//  * labels and centres of iteration i live in slot i % 3 of caller-owned rings, so the least-inertia iteration's (the reference's
+//    bookkeeping; nearly always one of the last two) are still there when the loop ends - a slot is copied out only when an OLDER best
+//    iteration's slot is about to be re-used.
+extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
+                                    int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
+                                    const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
+                                    const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                                    int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
+                                    size_t ws_m_bytes, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_run");
+    SCD_REQUIRE(C_start && C_ring && stats_ring && lab_ring && best_labels && best_C && result_host, "scd_kmeans_lloyd_run: null argument");
+    SCD_REQUIRE(max_iter >= 1 && n_u > 0 && n_cat >= n_u && (n_cat == n_u || labels_lab), "scd_kmeans_lloyd_run: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->run_host) {
+        SCD_HIP(hipHostMalloc((void**)&h->run_host, 2 * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        for (int i = 0; i < 16; ++i) h->run_host[i] = 0.0;
+        SCD_HIP(hipHostGetDevicePointer((void**)&h->run_dev, h->run_host, 0));
+    }
+    const size_t kd = (size_t)k * d;
+    const int64_t l_num = n_cat - n_u;
+    for (int sl = 0; sl < 3 && l_num > 0; ++sl)     // the labelled rows' labels never change: every slot carries them
+        SCD_HIP(hipMemcpyAsync(lab_ring + (size_t)sl * n_cat, labels_lab, (size_t)l_num * 4, hipMemcpyDeviceToDevice, st));
+    bool have_best = false, best_in_ring = false;
+    int best_it = -1;
+    float best = 0.f;
+    double refined_seen = -1., changed_seen = -1., changed_prev = -1.;      // counts of the iterations the host has seen last (-1: none yet)
+    // a changed row costs the incremental M-step ~24 ns (two 768-column float64 flushes), a fresh M-step ~70 us: break-even ~ 2,900 rows at C2
+    const double many = (double)(n_u / 32 > 256 ? n_u / 32 : 256);
+    int pending = -1, n_done = 0, delta_steps = 0, launched = 0;
+    double seq_of[2] = {0., 0.};
+    auto save_best = [&]() -> int {                  // ring slot of the best iteration -> the output buffers
+        SCD_HIP(hipMemcpyAsync(best_labels, lab_ring + (size_t)(best_it % 3) * n_cat, (size_t)n_cat * 4, hipMemcpyDeviceToDevice, st));
+        SCD_HIP(hipMemcpyAsync(best_C, C_ring + (size_t)(best_it % 3) * kd, kd * 4, hipMemcpyDeviceToDevice, st));
+        best_in_ring = false;
+        return SCD_OK;
+    };
+    // settle(i): wait for iteration i's statistics; book-keep; *converged when its centre shift is below tol
+    auto settle = [&](int i, bool* converged) -> int {
+        volatile double* host = h->run_host + (i & 1) * 8;
+        const double want = seq_of[i & 1];
+        long long spins = 0;
+        while (host[7] != want) {
+            if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: has the stream failed, or is this taking absurdly long?
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipSuccess && e != hipErrorNotReady) {
+                    scd_set_error("scd_kmeans_lloyd_run: stream error while waiting for iteration %d: %s", i, hipGetErrorString(e));
+                    return SCD_EHIP;
+                }
+                if (e == hipSuccess && host[7] != want) {
+                    scd_set_error("scd_kmeans_lloyd_run: iteration %d finished without publishing its statistics", i);
+                    return SCD_EHIP;
+                }
+            }
+        }
+        refined_seen = host[3];
+        changed_prev = changed_seen;
+        changed_seen = host[4];
+        const float inertia = (float)host[1] + (float)host[0];          // float32 sum of the two float32 parts, as the reference's
+        if (!have_best || inertia < best) {
+            have_best = true;
+            best = inertia;
+            best_it = i;
+            best_in_ring = true;
+        }
+        *converged = host[2] < tol;
+        return SCD_OK;
+    };
+    for (int it = 0; it < max_iter; ++it) {
+        if (best_in_ring && best_it % 3 == it % 3) { const int rc0 = save_best(); if (rc0) return rc0; }   // that slot is about to be re-used
+        const float* c_in = it == 0 ? C_start : C_ring + (size_t)((it - 1) % 3) * kd;
+        float* c_out = C_ring + (size_t)(it % 3) * kd;
+        double* stats = stats_ring + (it & 1) * 5;
+        // SCD_ESTEP_FEW pays only when a handful of rows are flagged, the incremental M-step while few labels move: the cue is the
+        // count the host has seen last (iteration it - 2)
+        const bool few = it >= 2 && refined_seen >= 0. && refined_seen <= 64.;
+        // the changes seen last are two iterations old, and they decay fast (95,000 / 28,600 / 3,700 / 40 / 27 at C2): extrapolate with
+        // the last ratio squared.  A wrong guess costs time only - both M-steps give the same bits
+        double pred = changed_seen;
+        if (it >= 3 && changed_prev > 0. && changed_seen < changed_prev) pred = changed_seen * (changed_seen / changed_prev) * (changed_seen / changed_prev);
+        const bool full = it < 2 || changed_seen < 0. || pred > many;
+        const int flags = (few ? SCD_ESTEP_FEW : 0) | SCD_ESTEP_CENTRES_FROM_FINALIZE | (full ? SCD_LLOYD_FULL : 0);
+        h->run_seq += 1.0;
+        seq_of[it & 1] = h->run_seq;
+        const int rc = lloyd_step_delta_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, lab_ring + (size_t)(it % 3) * n_cat, labels_prev, c_in,
+                                             c_out, sums, counts, sums_lab, counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m,
+                                             ws_m_bytes, stream, h->run_dev + (it & 1) * 8, h->run_seq);
+        if (rc) return rc;
+        ++launched;
+        delta_steps += full ? 0 : 1;
+        if (pending >= 0) {
+            bool conv = false;
+            n_done = pending + 1;
+            { const int rc2 = settle(pending, &conv); if (rc2) return rc2; }
+            pending = -1;
+            if (conv) break;                          // iteration `it` was launched on speculation: dropped unseen (whatever follows on
+                                                      // this stream is ordered behind it)
+        }
+        pending = it;
+    }
+    if (pending >= 0) {
+        bool conv = false;
+        n_done = pending + 1;
+        { const int rc2 = settle(pending, &conv); if (rc2) return rc2; }
+    }
+    if (best_in_ring) { const int rc0 = save_best(); if (rc0) return rc0; }
+    result_host[0] = (double)best;
+    result_host[1] = (double)n_done;
+    result_host[2] = (double)delta_steps;
+    result_host[3] = (double)launched;
+    return SCD_OK;
 }
 
 extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,

@@ -13,6 +13,8 @@ ONE all-reduce of [sums | counts | inertia] (float64) - SURVEY.md 8(e) - and the
 shard totals.  The compute backend is injectable (`backend=`) so that the collective logic is testable with
 gloo on CPU; the default and only product backend is scd_amd.ops (HIP).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -368,13 +370,20 @@ class KMeansEngine:
             fused.lab32[:l_num] = labels[:l_num]
             fused.c0.copy_(centers)
             centers = fused.c0              # iteration 0 reads the run's own start buffer and writes set 0
+            if getattr(fused, "inc", False) and os.environ.get("SCD_LLOYD_RUN", "1") != "0":
+                # the whole loop below behind one C call (same pipelining, same bookkeeping): the Python loop's ~45 us per
+                # iteration were a third of an iteration's wall time
+                lab, inertia, cen, n_done, n_delta, n_launched = fused.run(self.max_iterations, self.tolerance)
+                self.stats["estep_calls"] += n_launched
+                self.stats["delta_steps"] = self.stats.get("delta_steps", 0) + n_delta
+                return lab.to(labels.dtype), inertia, cen, n_done
 
         # SCD_ESTEP_FEW (flagged rows re-evaluated in the filter kernel's tail) pays only when a handful of rows are flagged: the
         # one-block-per-CU tail takes ~100 us for a few thousand rows where the refine launch takes 20.  The cue is the count the
         # host has seen last (iteration i - 2 when launching iteration i: the host runs one iteration behind the device)
         refined_seen = [None]
         # the incremental M-step (LloydBuffers.step_delta) pays while few labels move; same cue, the count of iteration i - 2
-        changed_seen = [None]
+        changed_seen = [None, None]        # [seen last, the one before]
         n_u = data_u.n if hasattr(data_u, "n") else len(cat) - l_num
 
         def settle(p):
@@ -382,6 +391,7 @@ class KMeansEngine:
             p[4].synchronize()
             host = p[3].numpy()
             refined_seen[0] = float(host[3])
+            changed_seen[1] = changed_seen[0]
             changed_seen[0] = float(host[4])
             inertia = np.float32(np.float32(host[1]) + np.float32(host[0]))
             if best[1] is None or inertia < best[1]:
@@ -396,7 +406,11 @@ class KMeansEngine:
                 self.stats["estep_calls"] += 1
                 few = it >= 2 and refined_seen[0] is not None and refined_seen[0] <= 64
                 if getattr(fused, "inc", False):
-                    full = it < 2 or changed_seen[0] is None or changed_seen[0] > max(256, n_u // 64)
+                    # (the same rule as scd_kmeans_lloyd_run: the count seen last is two iterations old, extrapolated with the last ratio)
+                    pred = changed_seen[0]
+                    if it >= 3 and changed_seen[1] is not None and changed_seen[1] > 0 and pred is not None and pred < changed_seen[1]:
+                        pred = pred * (changed_seen[0] / changed_seen[1]) * (changed_seen[0] / changed_seen[1])
+                    full = it < 2 or pred is None or pred > max(256, n_u // 32)
                     fused.step_delta(old, centers, stats, few, full)
                     self.stats["delta_steps"] = self.stats.get("delta_steps", 0) + (0 if full else 1)
                 else:

@@ -252,6 +252,11 @@ class LloydBuffers:
             self.sumsq = torch.empty(4, dtype=torch.float64, device=dev)
             self.sums_lab = self.counts_lab = None
             self._fit_ready = False
+            # scd_kmeans_lloyd_run: iteration i's labels / centres in slot i % 3 of these rings
+            self.c_ring = torch.empty((3, k, d), dtype=torch.float32, device=dev)
+            self.stats_ring = torch.zeros((2, 5), dtype=torch.float64, device=dev)
+            self.lab_ring = torch.empty((3, n_cat), dtype=torch.int32, device=dev)
+            self.result = np.zeros(4, dtype=np.float64)
 
     def step(self, c_in, c_out, stats, expect_few):
         d = self.data
@@ -285,6 +290,25 @@ class LloydBuffers:
                                                ptr(self.lab32), ptr(self.lab_prev), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
                                                ptr(self.sums_lab), ptr(self.counts_lab), ptr(self.sumsq), ptr(stats), flags,
                                                ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
+
+
+    def run(self, max_iter, tol):
+        """A whole restart from self.c0 (the seeding; labelled rows' labels in self.lab32[:l_num]) behind one call:
+        scd_kmeans_lloyd_run.  Returns (labels int32 [n_cat], float32 inertia, centres [k, d], iterations done, iterations with the
+        incremental M-step, iterations launched) of the least-inertia iteration - fresh tensors."""
+        if not self._fit_ready:
+            self._prepare_fit()
+        d = self.data
+        n_cat = self.cat.shape[0]
+        best_lab = torch.empty(n_cat, dtype=torch.int32, device=self.cat.device)
+        best_c = torch.empty((self.k, d.d), dtype=torch.float32, device=self.cat.device)
+        check(_L().scd_kmeans_lloyd_run(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), n_cat, d.d, self.k,
+                                        ptr(self.lab32) if n_cat > d.n else None, ptr(self.lab_ring), ptr(self.lab_prev), ptr(self.c0),
+                                        ptr(self.c_ring), ptr(self.sums), ptr(self.counts), ptr(self.sums_lab), ptr(self.counts_lab),
+                                        ptr(self.sumsq), ptr(self.stats_ring), int(max_iter), float(tol), ptr(best_lab), ptr(best_c),
+                                        self.result.ctypes.data, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
+        r = self.result
+        return best_lab, np.float32(r[0]), best_c, int(r[1]), int(r[2]), int(r[3])
 
 
 def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):

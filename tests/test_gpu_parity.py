@@ -1319,8 +1319,10 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     x = x.astype(np.float16).astype(np.float32)
     mask = (y < k // 2) & (np.random.RandomState(7).rand(n) < 0.5) if labelled else np.zeros(n, dtype=bool)
     res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("SCD_MSTEP_DELTA", mode)
+    # "1": scd_kmeans_lloyd_run (the restart's loop in C); "py": the same steps driven from Python; "0": a fresh M-step per iteration
+    for mode in ("1", "py", "0"):
+        monkeypatch.setenv("SCD_MSTEP_DELTA", "0" if mode == "0" else "1")
+        monkeypatch.setenv("SCD_LLOYD_RUN", "0" if mode == "py" else "1")
         km = KMeansEngine(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
         if labelled:
             km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
@@ -1331,6 +1333,8 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     # (an empty cluster's centre is NaN in the reference and here: equal_nan)
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
     assert res["1"][2] == res["0"][2] and res["1"][3] == res["0"][3]
+    assert np.array_equal(res["1"][0], res["py"][0]) and np.array_equal(res["1"][1], res["py"][1], equal_nan=True)
+    assert res["1"][2] == res["py"][2] and res["1"][3] == res["py"][3] and res["1"][4] == res["py"][4]
     okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
     if labelled:
         okm.fit_mix(x[~mask], x[mask], y[mask])

@@ -8,6 +8,7 @@ template <int OP>
 __global__ void __launch_bounds__(256) probe(float* out, float seed) {
     double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3;
     float f0 = seed, f1 = seed * 2, f2 = seed * 3, f3 = seed * 4;
+    float g0 = seed * 5, g1 = seed * 6, g2 = seed * 7, g3 = seed * 8;
     for (int i = 0; i < LOOPS; ++i) {
 #pragma unroll
         for (int r = 0; r < REP / 4; ++r) {
@@ -24,10 +25,14 @@ __global__ void __launch_bounds__(256) probe(float* out, float seed) {
             if (OP == 11) { asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1" : "+v"(a0), "+v"(a1)); asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_mul_f32 %1, %1, %1" : "+v"(a2), "+v"(a3)); }
             if (OP == 12) { asm volatile("v_pk_mul_f16 %0, %0, %0\n v_pk_mul_f16 %1, %1, %1\n v_pk_mul_f16 %2, %2, %2\n v_pk_mul_f16 %3, %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
             if (OP == 13) { asm volatile("v_max_f64 %0, %0, %0\n v_max_f64 %1, %1, %1\n v_max_f64 %2, %2, %2\n v_max_f64 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
+            // OP 14 / 15: a transcendental and one / two independent full-rate instructions alternating (counted as REP transcendentals):
+            // does the transcendental unit run beside the main VALU?
+            if (OP == 14) { asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %4, %4\n v_exp_f32 %1, %1\n v_fma_f32 %5, %5, %5, %5\n v_exp_f32 %2, %2\n v_fma_f32 %6, %6, %6, %6\n v_exp_f32 %3, %3\n v_fma_f32 %7, %7, %7, %7" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3)); }
+            if (OP == 15) { asm volatile("v_exp_f32 %0, %0\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %6, %6, %6, %6\n v_exp_f32 %1, %1\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %7, %7, %7, %7\n v_exp_f32 %2, %2\n v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %6, %6, %6, %6\n v_exp_f32 %3, %3\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %7, %7, %7, %7" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3)); }
             if (OP == 7) { asm volatile("v_cvt_f32_f64 %4, %0\n v_cvt_f32_f64 %5, %1\n v_cvt_f32_f64 %6, %2\n v_cvt_f32_f64 %7, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)); }
         }
     }
-    out[blockIdx.x * 256 + threadIdx.x] = (float)(a0 + a1 + a2 + a3) + f0 + f1 + f2 + f3;
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(a0 + a1 + a2 + a3) + f0 + f1 + f2 + f3 + g0 + g1 + g2 + g3;
 }
 template <int OP>
 static void run(const char* name, int waves_per_simd) {
@@ -65,6 +70,8 @@ int main() {
         run<11>("v_pk_mul_f32", w);
         run<12>("v_pk_mul_f16", w);
         run<13>("v_max_f64", w);
+        run<14>("v_exp_f32+1fma", w);
+        run<15>("v_exp_f32+2fma", w);
     }
     return 0;
 }
