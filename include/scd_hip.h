@@ -188,6 +188,16 @@ int scd_kmeans_min_update_multi(scd_handle h, const float* X, const float* c_new
 int scd_kpp_draw_multi(scd_handle h, const float* d2, int64_t n, int64_t ld, int R, const float* r_dev, const double* total,
                        const double* prefix, int64_t* idx_out, double* probsum_out, void* ws, size_t ws_bytes, void* stream);
 int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_t ld, int R, double* out, void* stream);
+/* The rounds of the lock-step seeding behind one call (kpp of sskm_constrained.py:28-44 for R restarts at once): for t < T: draw
+ * one row per restart from d2 with the uniforms r_dev[t][R] (scd_kpp_draw_multi), store it as centre m0 + t of C_buf [R][k][d],
+ * d2[r] = min(d2[r], ||x - that row||^2).  On entry d2 [R][ld] holds the distances to the m0 centres chosen so far.  picks_out
+ * int64 [T][R] on the device (-1: no row drawn; the reference raises there).  X16: the exact fp16 copy of X (scd_f16_exact) or
+ * NULL: with it the distance update reads 2 bytes per value through a filter (16x16x32 MFMA lower bounds rule out the rows a new
+ * centre cannot improve, the rest get the float64 value) - the same float32 results as scd_kmeans_min_update_multi. */
+size_t scd_kpp_seed_ws_bytes(int64_t n, int d, int R);
+int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
+                          const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws, size_t ws_bytes,
+                          void* stream);
 /* deterministic float64 sum of a float32 vector (inertia, d2.sum()) */
 int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out, void* stream);
 

@@ -70,6 +70,9 @@ SIGNATURES = {
     "scd_kmeans_lloyd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "scd_kmeans_min_update_multi": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp]),
     "scd_kpp_draw_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_kpp_seed_ws_bytes": (_sz, [_i64, _i, _i]),
+    # h, X, X16, n, d, R, d2, ld, r_dev, T, C_buf, k, m0, picks_out, ws, nb, stream
+    "scd_kpp_seed_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "scd_sum_f32_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "scd_sum_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),

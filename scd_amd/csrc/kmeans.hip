@@ -1949,7 +1949,7 @@ extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, co
 constexpr int MU_COLS = 32, MU_LD = 36, MU_ROWS = 256;
 template <int RB, bool VEC>
 __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
-                                                          int r0, int R, float* __restrict__ d2, long long ld) {
+                                                          int r0, int R, float* __restrict__ d2, long long ld, long long ldc) {
     __shared__ __attribute__((aligned(16))) float xs[MU_ROWS * MU_LD];       // reused for the high-half partials at the end
     __shared__ __attribute__((aligned(16))) double cs[RB * MU_COLS];
     static_assert(128 * 2 * RB * 8 <= MU_ROWS * MU_LD * 4, "partials must fit the x tile");
@@ -1980,7 +1980,7 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int e = t + 256 * i, r = r0 + e / MU_COLS, c = c0 + e % MU_COLS;
-            prc[i] = (e < RB * MU_COLS && r < R && c < d) ? Cn[(size_t)r * d + c] : 0.f;
+            prc[i] = (e < RB * MU_COLS && r < R && c < d) ? Cn[(size_t)r * ldc + c] : 0.f;
         }
     };
     double acc[2][RB];
@@ -2052,10 +2052,19 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
 }
 
 template <int RB>
-static int minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st) {
+static int minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st,
+                         long long ldc) {
     const unsigned g = (unsigned)scd_cdiv(n, MU_ROWS);
-    if ((d & 3) == 0) minupd_tile_kernel<RB, true><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
-    else minupd_tile_kernel<RB, false><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld);
+    if ((d & 3) == 0) minupd_tile_kernel<RB, true><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc);
+    else minupd_tile_kernel<RB, false><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc);
+    return SCD_OK;
+}
+// c_new row r at Cn + r * ldc
+static int minupd_all(const float* X, const float* c_new, long long n, int d, int R, float* d2, long long ld, long long ldc, hipStream_t st) {
+    int r0 = 0;
+    while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 10; }
+    while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 4; }
+    while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 1; }
     return SCD_OK;
 }
 
@@ -2064,10 +2073,7 @@ extern "C" int scd_kmeans_min_update_multi(scd_handle h, const float* X, const f
     SCD_DEVICE_ENTRY(h, "scd_kmeans_min_update_multi");
     SCD_REQUIRE(h && X && c_new && d2_inout && n > 0 && d > 0 && R > 0 && ld >= n, "scd_kmeans_min_update_multi: bad arguments");
     hipStream_t st = (hipStream_t)stream_;
-    int r0 = 0;
-    while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 10; }
-    while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 4; }
-    while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2_inout, ld, st); r0 += 1; }
+    minupd_all(X, c_new, n, d, R, d2_inout, ld, d, st);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
@@ -2190,6 +2196,239 @@ extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_
     SCD_DEVICE_ENTRY(h, "scd_sum_f32_multi");
     SCD_REQUIRE(h && x && out && n > 0 && ld >= n && R > 0, "scd_sum_f32_multi: bad arguments");
     sum_multi_kernel<<<R, 1024, 0, (hipStream_t)stream_>>>(x, n, ld, out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the lock-step seeding loop in C
+// scd_kpp_seed_lockstep: the rounds of KMeansEngine.kpp_lockstep behind one call - draw, fetch the drawn rows, update the distances -
+// so that nothing but these kernels enters the stream (the Python loop added an index_select, a clamp and a strided copy per round).
+//
+// With the exact fp16 copy of X (scd_f16_exact) the distance update is a FILTER: d2 changes only where the new centre is closer than
+// every earlier one - about n / k rows per restart and round - and for the other rows a lower bound of the distance is enough to prove
+// it.  muf_filter_kernel evaluates ||x||^2 + ||c||^2 - 2 x.c for 16 rows x up to 16 new centres per 16x16x32 MFMA chain (x and the new
+// centres - rows of X themselves - are exact in fp16, their products exact in fp32: only the fp32 accumulation rounds), reads X once
+// at 2 bytes per value, and lists the (row, restart) pairs it cannot rule out; muf_exact_kernel gives those the float64 value of
+// minupd_tile_kernel's definition (float32(sum_j (x_j - c_j)^2), float64 accumulation) and takes the minimum.  Every float32 that
+// is written is such an exactly rounded value, so the d2 arrays - and the draws - are those of the tile kernel.
+// The pairs a block cannot rule out go to the block's OWN region of the list (LDS counter; one global counter took ~10 ns per wave
+// atomic, 120 us per round at 12,000 pairs), and block b of muf_exact_kernel works region b off.
+constexpr int MUF_GRID = 768;
+__global__ void __launch_bounds__(256) muf_rown2_kernel(const half_t* __restrict__ X16, long long n, int d, float* __restrict__ rn2) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < d; j += 64) {
+        const double v = (double)(float)X16[row * d + j];
+        s = fma(v, v, s);
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) rn2[row] = (float)s;
+}
+// block r < 16: fetches the drawn row (C_r = X[max(pick[r], 0)]: a negative pick - no row drawn - is reported by the caller after the
+// loop) and writes c16[r][0..dp) = fp16(c_r) (zero beyond d, zero rows beyond R); info[r] = {||c16_r||^2, ||c_r - c16_r||}
+__global__ void __launch_bounds__(256) muf_prep_kernel(const float* __restrict__ X, const long long* __restrict__ pick, float* __restrict__ Cn,
+                                                       long long ldc, int R, int d, int dp, half_t* __restrict__ c16, double* __restrict__ info) {
+    __shared__ double red[4][2];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s2 = 0.0, e2 = 0.0;
+    const long long src = r < R ? (pick[r] < 0 ? 0 : pick[r]) : 0;
+    for (int j = threadIdx.x; j < dp; j += 256) {
+        const float c = (r < R && j < d) ? X[src * d + j] : 0.f;
+        if (r < R && j < d) Cn[(size_t)r * ldc + j] = c;
+        const half_t hc = (half_t)c;
+        c16[(size_t)r * dp + j] = hc;
+        const double hv = (double)(float)hc, e = (double)c - hv;
+        s2 = fma(hv, hv, s2);
+        e2 = fma(e, e, e2);
+    }
+    s2 = wave_sum_f64(s2);
+    e2 = wave_sum_f64(e2);
+    if (lane == 0) { red[wave][0] = s2; red[wave][1] = e2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[r * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        info[r * 2 + 1] = sqrt((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+    }
+}
+// NKS = dp / 32 k-steps.  A = the centres (m = restart), B = 16 rows of X (n = row): lane l holds row l & 15 and restarts 4 (l >> 4) + j.
+template <int NKS>
+__global__ void __launch_bounds__(256) muf_filter_kernel(const half_t* __restrict__ X16, const float* __restrict__ rn2, const half_t* __restrict__ c16,
+                                                         const double* __restrict__ info, long long n, int d, int R,
+                                                         const float* __restrict__ d2, long long ld, unsigned* __restrict__ counts,
+                                                         unsigned long long* __restrict__ list, long long cap) {
+    constexpr int DP = NKS * 32;
+    __shared__ unsigned lcount;
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+    unsigned long long* mine = list + (size_t)blockIdx.x * cap;
+    const int lane = threadIdx.x & 63, c16i = lane & 15, q = lane >> 4;
+    half8 ca[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) ca[ks] = *(const half8*)(c16 + (size_t)c16i * DP + ks * 32 + 8 * q);
+    double cn2[4], cdl[4], cnr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cn2[j] = info[(4 * q + j) * 2]; cdl[j] = info[(4 * q + j) * 2 + 1]; cnr[j] = sqrt(cn2[j]); }
+    // fp32 accumulation of DP exact products: |acc - x.c| <= DP * 2^-24 * sum |x_j c_j| <= DP * 2^-24 ||x|| ||c||; x1.5 safety
+    const double gam = 1.5 * DP * 5.9604644775390625e-8;
+    const long long ntile = (n + 15) >> 4;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long long)gridDim.x * 4;
+    for (long long tile = wave_id; tile < ntile; tile += nwave) {
+        const long long row = tile * 16 + c16i;
+        const long long rowc = row < n ? row : n - 1;
+        const half_t* xr = X16 + rowc * d + 8 * q;
+        half8 xb[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks * 32 + 8 * q < d) xb[ks] = *(const half8*)(xr + ks * 32);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[ks][e] = (half_t)0.f;
+            }
+        }
+        const double xn2 = (double)rn2[rowc];
+        float old[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) old[j] = (4 * q + j < R) ? d2[(size_t)(4 * q + j) * ld + rowc] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[ks], xb[ks], acc, 0, 0, 0);
+        const double xnr = sqrt(xn2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = 4 * q + j;
+            // lower bound of ||x - c||^2: the fp32 dot product's error, the float32 rounding of ||x||^2 (2^-24 relative) and, for a
+            // centre that is not exact in fp16, |x.(c - c16)| and the change of ||c||^2
+            const double a = xn2 + cn2[j] - 2.0 * (double)acc[j];
+            const double E = 2.0 * gam * xnr * cnr[j] + 1.2e-7 * xn2 + 2.0 * (xnr + cnr[j]) * cdl[j] + cdl[j] * cdl[j];
+            const bool need = m < R && row < n && !(a - E > (double)old[j]);      // NaN anywhere: not ruled out
+            const unsigned long long mask = __ballot(need);
+            if (mask) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&lcount, (unsigned)__popcll(mask));
+                base = __shfl(base, 0, 64);
+                if (need) mine[base + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned long long)row << 8) | (unsigned)m;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = lcount;
+}
+// the listed (row, restart) pairs: d2 = min(d2, float32(sum_j (x_j - c_j)^2)), float64 accumulation, x from the exact fp16 copy.
+// Sixteen lanes per pair, four pairs per wave at a time, and every load of a pair - its list entry's row, the centre, the old d2 -
+// is issued before the first is used: a pair is one chain of memory latencies (one pair per wave took 6.6 us per pair).
+__global__ void __launch_bounds__(256) muf_exact_kernel(const half_t* __restrict__ X16, const float* __restrict__ Cn, long long ldc, int d,
+                                                        const unsigned* __restrict__ counts, const unsigned long long* __restrict__ list,
+                                                        long long cap, float* __restrict__ d2, long long ld) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l16 = lane & 15;
+    const unsigned cnt = counts[blockIdx.x];
+    const unsigned long long* mine = list + (size_t)blockIdx.x * cap;
+    for (unsigned p0 = (threadIdx.x >> 6) * 4; p0 < cnt; p0 += 16) {
+        const unsigned p = p0 + sub;
+        const bool on = p < cnt;
+        const unsigned long long e = mine[on ? p : p0];
+        const long long row = (long long)(e >> 8);
+        const int m = (int)(e & 255);
+        const half_t* x = X16 + row * d;
+        const float* c = Cn + (size_t)m * ldc;
+        float* qd = d2 + (size_t)m * ld + row;
+        const float old = *qd;
+        double s = 0.0;
+        for (int j0 = l16 * 8; j0 < d; j0 += 512) {
+            half8 xv[4];
+            float4 cv[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 128 * u;
+                if (j < d) {
+                    xv[u] = *(const half8*)(x + j);
+                    cv[u][0] = *(const float4*)(c + j);
+                    cv[u][1] = *(const float4*)(c + j + 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 128 * u;
+                if (j < d) {
+                    const float cc[8] = {cv[u][0].x, cv[u][0].y, cv[u][0].z, cv[u][0].w, cv[u][1].x, cv[u][1].y, cv[u][1].z, cv[u][1].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const double t = (double)(float)xv[u][q] - (double)cc[q];
+                        s = fma(t, t, s);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (on && l16 == 0) *qd = fminf(old, (float)s);
+    }
+}
+// C[r][slot] = X[max(pick[r], 0)]  (a negative pick - no row drawn - is reported by the caller after the loop)
+__global__ void __launch_bounds__(256) kpp_fetch_rows_kernel(const float* __restrict__ X, const long long* __restrict__ pick, int d,
+                                                             float* __restrict__ Cslot, long long ldc) {
+    const long long i = pick[blockIdx.x] < 0 ? 0 : pick[blockIdx.x];
+    for (int j = threadIdx.x; j < d; j += 256) Cslot[(size_t)blockIdx.x * ldc + j] = X[i * d + j];
+}
+
+static inline int muf_dp(int d) { return (d + 31) / 32 * 32; }
+// list capacity per block: the rows of the tiles its four waves can be dealt (16 rows x 16 restarts per tile)
+static inline long long muf_cap(int64_t n) { return 4 * scd_cdiv(scd_cdiv(n, 16), 4 * MUF_GRID) * 256; }
+extern "C" size_t scd_kpp_seed_ws_bytes(int64_t n, int d, int R) {
+    return (size_t)R * scd_kpp_draw_ws_bytes(n) + scd_align(4 * (size_t)n) + scd_align(2 * 16 * (size_t)muf_dp(d)) + 256 + scd_align(4 * MUF_GRID) +
+           scd_align(8 * (size_t)muf_cap(n) * MUF_GRID) + 256;
+}
+extern "C" int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
+                                     const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_seed_lockstep");
+    SCD_REQUIRE(X && d2 && r_dev && C_buf && picks_out && ws && n > 0 && d > 0 && R > 0 && ld >= n && T >= 0 && m0 >= 1 && m0 + T <= k,
+                "scd_kpp_seed_lockstep: bad arguments");
+    SCD_REQUIRE(ws_bytes >= scd_kpp_seed_ws_bytes(n, d, R), "scd_kpp_seed_lockstep: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const size_t draw_nb = (size_t)R * scd_kpp_draw_ws_bytes(n);
+    const int dp = muf_dp(d);
+    char* w = (char*)ws;
+    void* draw_ws = w;
+    float* rn2 = (float*)(w + draw_nb);
+    half_t* c16 = (half_t*)((char*)rn2 + scd_align(4 * (size_t)n));
+    double* info = (double*)((char*)c16 + scd_align(2 * 16 * (size_t)dp));
+    unsigned* counts = (unsigned*)((char*)info + 256);
+    unsigned long long* list = (unsigned long long*)((char*)counts + scd_align(4 * MUF_GRID));
+    const long long cap = muf_cap(n);
+    const long long ldc = (long long)k * d;
+    const int filt_env = getenv("SCD_KPP_FILTER") ? atoi(getenv("SCD_KPP_FILTER")) : 1;     // 0: the tile kernel reads the float32 rows (A/B)
+    const bool filt = X16 && filt_env && R <= 16 && d % 32 == 0 && (dp == 128 || dp == 256 || dp == 384 || dp == 512 || dp == 768 || dp == 1024) &&
+                      n < (1ll << 40) && T > 1;
+    if (filt) muf_rown2_kernel<<<(unsigned)scd_cdiv(n, 4), 256, 0, st>>>((const half_t*)X16, n, d, rn2);
+    for (int t = 0; t < T; ++t) {
+        int64_t* pick = picks_out + (size_t)t * R;
+        const int rc = scd_kpp_draw_multi(h, d2, n, ld, R, r_dev + (size_t)t * R, nullptr, nullptr, pick, nullptr, draw_ws, draw_nb, stream_);
+        if (rc) return rc;
+        float* slot = C_buf + (size_t)(m0 + t) * d;
+        const bool use_filter = filt && m0 + t >= 8 && t + 1 < T;
+        if (!use_filter) kpp_fetch_rows_kernel<<<R, 256, 0, st>>>(X, (const long long*)pick, d, slot, ldc);
+        if (t + 1 == T) break;
+        // with m centres a new one is the nearest for ~1 / (m + 1) of the rows: the filter pays once that is a small share (the float64
+        // pass costs ~1 us per pair and wave); the first rounds update most rows and stay on the tile kernel
+        if (!filt || m0 + t < 8) {
+            minupd_all(X, slot, n, d, R, d2, ld, ldc, st);
+            continue;
+        }
+        muf_prep_kernel<<<16, 256, 0, st>>>(X, (const long long*)pick, slot, ldc, R, d, dp, c16, info);     // fetch + operands in one launch
+#define MUF_GO(NKS) muf_filter_kernel<NKS><<<MUF_GRID, 256, 0, st>>>((const half_t*)X16, rn2, c16, info, n, d, R, d2, ld, counts, list, cap)
+        switch (dp / 32) {
+            case 4: MUF_GO(4); break;
+            case 8: MUF_GO(8); break;
+            case 12: MUF_GO(12); break;
+            case 16: MUF_GO(16); break;
+            case 24: MUF_GO(24); break;
+            default: MUF_GO(32); break;
+        }
+#undef MUF_GO
+        muf_exact_kernel<<<MUF_GRID, 256, 0, st>>>((const half_t*)X16, slot, ldc, d, counts, list, cap, d2, ld);
+    }
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

@@ -78,6 +78,9 @@ class HipBackend:
     def sum_f32_multi(self, x):
         return self.ops.sum_f32_multi(x)
 
+    def kpp_seed_lockstep(self, data, x16, d2, rv, buf, m0):
+        return self.ops.kpp_seed_lockstep(data.x, x16, d2, rv, buf, m0)
+
     def transport(self, cost, size_min, size_max):
         return self.ops.transport_solve(cost, size_min, size_max)
 
@@ -210,13 +213,15 @@ class KMeansEngine:
             raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
         return C
 
-    def kpp_lockstep(self, data, pre_centers, k, rs, restarts):
+    def kpp_lockstep(self, data, pre_centers, k, rs, restarts, x16=None):
         """The k-means++ seedings of all `restarts` restarts of one fit, advanced together: restart j's t-th centre depends only
         on restart j's earlier centres and on the (t)-th uniform of ITS slice of the random stream, and the reference's restarts
         consume the stream back to back (kpp draws k-m uniforms, Lloyd draws none; sskm.py:28-44, :190-204), so drawing the
         whole stream up front and adding centre t of every restart in one round gives the same centres as running kpp
         `restarts` times.  Per round: one pass over X for all restarts' distance updates and one batched draw; under a process
-        group the same three all-gathers as kpp, each carrying `restarts` values.  Returns float32 [restarts, k, D]."""
+        group the same three all-gathers as kpp, each carrying `restarts` values.  Without a process group the rounds run behind
+        one call (scd_kpp_seed_lockstep; x16 = the exact fp16 copy of data.x when there is one: the distance update then reads it
+        through a filter).  Returns float32 [restarts, k, D]."""
         be = self._be()
         dd = self._dist()
         x = data.x
@@ -248,6 +253,11 @@ class KMeansEngine:
         ar = torch.arange(restarts, device=dev)
         # float32(uniform) is what the draw compares with (the reference's `cumsum(prob) >= r` promotes r to prob's float32)
         rv = torch.from_numpy(np.ascontiguousarray(rv.T.astype(np.float32))).to(dev)       # [k - m, restarts], one upload
+        if dd is None and hasattr(be, "kpp_seed_lockstep") and os.environ.get("SCD_KPP_SEED_RUN", "1") != "0":
+            pk = be.kpp_seed_lockstep(data, x16, d2, rv, buf, m)
+            if pk.numel() and bool((pk < 0).any()):
+                raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+            return buf
         for t in range(k - m):
             r = rv[t]
             if dd is None:
@@ -505,24 +515,27 @@ class KMeansEngine:
 
     def fit(self, X):
         data = self._be().prepare(X)
+        per = self._per_fit(data, data.x)
         inits = None
         if self._lockstep():
             def inits(rs):
-                c = self.kpp_lockstep(data, None, self.k, rs, self.n_init)
+                c = self.kpp_lockstep(data, None, self.k, rs, self.n_init, x16=per["cat16"])
                 return [dict(init_centers=c[j]) for j in range(self.n_init)]
-        self._run(self.fit_once, X, data=data, inits=inits, **self._per_fit(data, data.x))
+        self._run(self.fit_once, X, data=data, inits=inits, **per)
 
     def fit_mix(self, u_feats, l_feats, l_targets):
         data = self._be().prepare(u_feats)
         l = l_feats.to(device=data.x.device, dtype=torch.float32).contiguous()
         cat = torch.cat((l, data.x)).contiguous()
+        per = self._per_fit(data, cat)
         inits = None
         if self._lockstep():
             def inits(rs):
                 _, l_rank, l_centers = self._class_means(l, l_targets.to(data.x.device))
-                c = self.kpp_lockstep(data, l_centers, self.k, rs, self.n_init)
+                x16 = per["cat16"][len(l):] if per["cat16"] is not None else None       # the unlabelled rows' part of the copy
+                c = self.kpp_lockstep(data, l_centers, self.k, rs, self.n_init, x16=x16)
                 return [dict(init_centers=c[j], l_rank=l_rank) for j in range(self.n_init)]
-        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat, inits=inits, **self._per_fit(data, cat))
+        self._run(self.fit_mix_once, u_feats, l_feats, l_targets, data=data, cat=cat, inits=inits, **per)
         self.cluster_centers_ = self.cluster_centers_.type_as(u_feats) if torch.is_floating_point(u_feats) else self.cluster_centers_
 
 

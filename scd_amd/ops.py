@@ -400,6 +400,24 @@ def kpp_draw_multi(d2, r, total=None, prefix=None, want_idx=True, want_probsum=F
     return idx, ps
 
 
+def kpp_seed_lockstep(x, x16, d2, rv, buf, m0):
+    """The rounds of the lock-step k-means++ seeding behind one call (scd_kpp_seed_lockstep): for t < T: draw one row per restart
+    from d2 [R, n] with the uniforms rv[t] (float32 [T, R] on the device), store it as centre m0 + t of buf [R, k, d], update d2.
+    x16: the exact fp16 copy of x (or None).  Returns the picks, int64 [T, R] on the device (-1: no row drawn)."""
+    _need_cuda(x, d2, rv, buf)
+    t_rounds, rr = rv.shape
+    n, d = x.shape
+    assert d2.shape[0] == rr and buf.shape[0] == rr and buf.shape[2] == d and buf.is_contiguous() and rv.is_contiguous()
+    picks = torch.empty((t_rounds, rr), dtype=torch.int64, device=x.device)
+    nb = _L().scd_kpp_seed_ws_bytes(n, d, rr)
+    ws = _kpp_ws.get((x.device, "seed", nb))
+    if ws is None:
+        ws = _kpp_ws[(x.device, "seed", nb)] = _ws(nb, x.device)
+    check(_L().scd_kpp_seed_lockstep(handle(), ptr(x), ptr(x16), n, d, rr, ptr(d2), d2.stride(0), ptr(rv), t_rounds, ptr(buf), buf.shape[1],
+                                     int(m0), ptr(picks), ptr(ws), nb, stream_ptr()))
+    return picks
+
+
 def sum_f32_multi(x):
     """float64 row sums of a float32 matrix [R, n] (deterministic order)."""
     _need_cuda(x)

@@ -320,6 +320,47 @@ def test_kpp_multi_kernels_equal_single(ops):
             assert got == int(idx[j])
 
 
+@pytest.mark.parametrize("n,d,k,R,exact", [(20011, 512, 40, 10, True), (9000, 768, 25, 3, True), (5000, 96, 12, 4, True), (20011, 512, 30, 10, False),
+                                           (3000, 256, 20, 16, True)])
+def test_kpp_seed_lockstep_rounds_in_c(ops, monkeypatch, n, d, k, R, exact):
+    """scd_kpp_seed_lockstep (draw, fetch, distance update of every round behind one call; with the exact fp16 copy the update goes
+    through the MFMA filter + float64 pass) leaves the bits of the round-by-round calls it replaces: picks, centres and the final
+    distance arrays (sskm_constrained.py:28-44 per restart)."""
+    x, _, _ = synth.clustered_features(n, d, 12, seed=n + d, noise=0.7)
+    if exact:
+        x = x.astype(np.float16).astype(np.float32)
+    xt = dev(x)
+    x16 = ops.f16_exact(xt)
+    assert (x16 is not None) == exact
+    rs = np.random.RandomState(5)
+    first = rs.randint(0, n, size=R)
+    rv = dev(rs.rand(k - 1, R).astype(np.float32))
+    rv[3, 0] = 0.0
+    def start():
+        buf = torch.zeros((R, k, d), dtype=torch.float32, device="cuda")
+        buf[:, 0] = xt[torch.as_tensor(first, device="cuda")]
+        d2 = torch.full((R, n), float("inf"), dtype=torch.float32, device="cuda")
+        ops.min_update_multi(xt, buf[:, 0].contiguous(), d2)
+        return buf, d2
+    # the rounds one call at a time (what KMeansEngine.kpp_lockstep does under a process group)
+    buf0, d20 = start()
+    picks0 = []
+    for t in range(k - 1):
+        idx, _ = ops.kpp_draw_multi(d20, rv[t])
+        picks0.append(idx)
+        rows = xt.index_select(0, idx.clamp(min=0)).contiguous()
+        buf0[:, 1 + t] = rows
+        if t + 1 < k - 1:
+            ops.min_update_multi(xt, rows, d20)
+    res = {}
+    for filt in ("1", "0"):
+        monkeypatch.setenv("SCD_KPP_FILTER", filt)
+        buf, d2 = start()
+        picks = ops.kpp_seed_lockstep(xt, x16, d2, rv, buf, 1)
+        assert torch.equal(picks, torch.stack(picks0)) and torch.equal(buf, buf0) and torch.equal(d2, d20), filt
+        assert int((picks < 0).sum()) == 0
+
+
 @pytest.mark.parametrize("mixed", [False, True])
 def test_kpp_lockstep_equals_sequential_restarts_gpu(ops, monkeypatch, mixed):
     """KMeansEngine on the device: seedings of the n_init restarts drawn in lock-step == one kpp per restart (sskm.py:190-204)."""
