@@ -22,3 +22,9 @@ prof sim_bench $R/tools/sim_bench.py 126976 3
 prof kmeans_bench $R/tools/kmeans_bench.py 768 0.8 95000 100
 prof kmeans_bench_c4 $R/tools/kmeans_bench.py 512 0.8 160146 1000
 prof sskm_phases $R/tools/sskm_phases.py 95000 768 100
+# the Lloyd loop's kernel timeline (last 70 kernels of a fit) and the seeding A/B
+cd $R
+bash tools/gpu_km_trace.sh 95000 768 100 70 > /dev/null 2>&1; cp gpurun_out/km_trace/timeline.txt $out/r03_lloyd_timeline.txt
+{ echo "# tools/trace_gaps.py on a rocprofv3 --kernel-trace of tools/lloyd_trace.py 95000 768 100: start (us), duration, gap to the previous kernel's end"; cat gpurun_out/km_trace/run.log | grep "^fit"; } > $out/hdr.tmp; cat $out/hdr.tmp $out/r03_lloyd_timeline.txt > $out/t.tmp; mv $out/t.tmp $out/r03_lloyd_timeline.txt; rm -f $out/hdr.tmp
+{ echo "# tools/gpu_seed_ab.sh: SSKM fit (tools/sskm_phases.py n d k), seeding rounds from Python (SEED_RUN=0), in C on the float32 tile kernel (FILTER=0), in C through the fp16 filter"; bash tools/gpu_seed_ab.sh; } > $out/r03_seed_ab.txt 2>&1
+cat $out/r03_seed_ab.txt | cut -c1-150

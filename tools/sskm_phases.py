@@ -29,8 +29,8 @@ for rep in range(3):
     smp = ops.kmeans_timing(False) * 1e3                    # us per launch, call order: restart r, iteration i = smp[10 r + i]
     late = np.array([smp[j] for j in range(len(smp)) if j % 10 >= 2]) if len(smp) % 10 == 0 else smp
     print("fit %.2f ms: seeding (lock-step, %d rounds) %.2f ms, Lloyd %.2f ms over %d iterations (%.0f us each); estep_stream_kernel "
-          "inside the loop: %d launches, %.1f us average (iterations 0-1 of a restart: %.1f us, refine in a launch of its own; iterations "
-          ">= 2, refine in the kernel's tail: average %.1f / median %.1f / min %.1f us = %.0f GB/s on %.1f MB at the average)"
+          "inside the loop: %d launches, %.1f us average (iterations 0-1 of a restart: %.1f us; iterations "
+          ">= 2: average %.1f / median %.1f / min %.1f us = %.0f GB/s on %.1f MB at the average; HIP-event brackets, dispatch latency included)"
           % (tot * 1e3, k - 1, t["kpp"] * 1e3, t["lloyd"] * 1e3, t["iters"], t["lloyd"] * 1e6 / max(t["iters"], 1), len(smp),
              smp.mean(), np.mean([smp[j] for j in range(len(smp)) if j % 10 < 2]) if len(smp) % 10 == 0 else float("nan"),
              late.mean(), np.median(late), late.min(), algo / late.mean() / 1e3, algo / 1e6))
