@@ -1385,6 +1385,32 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     assert res["1"][2] == float(okm.inertia_)
 
 
+@pytest.mark.parametrize("tol,max_it", [(5e-2, 10), (1e30, 10), (1e-4, 1), (1e-4, 2), (0.0, 4)])
+def test_lloyd_run_stops_like_the_reference_loop(ops, monkeypatch, tol, max_it):
+    """scd_kmeans_lloyd_run's loop control: it stops after the first iteration whose centre shift is below the tolerance (the
+    speculative iteration behind it is dropped), honours max_iterations, and keeps the least-inertia iteration - n_iter_, labels,
+    centres and inertia equal the Python-driven loop's and the float64 oracle's (faster_mix_k_means_pytorch.py:187-214)."""
+    from scd_amd.kmeans import KMeansEngine
+    n, d, k = 12000, 128, 8
+    x, y, _ = synth.clustered_features(n, d, k, seed=71, center_seed=72, noise=0.5)
+    x = x.astype(np.float16).astype(np.float32)
+    mask = (y < k // 2) & (np.random.RandomState(3).rand(n) < 0.5)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCD_LLOYD_RUN", mode)
+        km = KMeansEngine(k=k, tolerance=tol, max_iterations=max_it, n_init=4, random_state=11)
+        km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
+        res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, km.stats["estep_calls"])
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
+    assert res["1"][2:] == res["0"][2:]
+    okm = ko.K_Means(k=k, tolerance=tol, max_iterations=max_it, n_init=4, random_state=11)
+    okm.fit_mix(x[~mask], x[mask], y[mask])
+    assert np.array_equal(res["1"][0], okm.labels_) and np.array_equal(res["1"][1], okm.cluster_centers_, equal_nan=True)
+    assert res["1"][2] == float(okm.inertia_)
+    if max_it == 1 or tol == 1e30:
+        assert res["1"][4] <= 2 * 4          # at most the speculative second iteration per restart was launched
+
+
 @pytest.mark.parametrize("n,k", [(75700, 1000), (100000, 520)])
 def test_estep_rb_split_last_round(ops, n, k):
     """estep_rb_kernel splits the row blocks of the chip's partial last round over the centres (n = 75,700: 40 of 296 row blocks,
