@@ -505,6 +505,98 @@ __device__ __forceinline__ void refine_full_row(const float* __restrict__ X, con
     }
 }
 
+// The same re-evaluation for FOUR listed rows at once (the refine launch): a centre value loaded once serves four rows.  At K = 1000 a
+// row's sweep reads 2 MB of centres from L2 and the launch was bound by exactly that (279 rows: 72 us; 22,000 rows behind a data-point
+// seeding: 1 ms); per (row, centre) the additions and their order are those of refine_full_row, so the sums are the same bits.
+template <int NW>
+__device__ __forceinline__ void refine_full_rows4(const float* __restrict__ X, const float* __restrict__ C, const int* __restrict__ rows, int nr,
+                                                  int d, int k, double* xs, double* rv, int* ri, int32_t* labels) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int r = 0; r < 4; ++r) {
+        const long long row = rows[r < nr ? r : 0];
+        for (int j = threadIdx.x; j < d; j += 64 * NW) xs[r * d + j] = (double)X[row * d + j];
+    }
+    __syncthreads();
+    double best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int c0 = wv; c0 < k; c0 += 8 * NW) {
+        double a[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[r][u] = 0.0;
+        if ((d & 3) == 0) {
+            // one 256-column slice at a time: eight centres' float4 in flight per lane (four rows of work per loaded value hide them)
+            for (int j = 4 * lane; j < d; j += 256) {
+                float4 cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + NW * u;
+                    if (c < k) cv[u] = *(const float4*)(C + (size_t)c * d + j);
+                }
+                double x[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { x[r][0] = xs[r * d + j]; x[r][1] = xs[r * d + j + 1]; x[r][2] = xs[r * d + j + 2]; x[r][3] = xs[r * d + j + 3]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c0 + NW * u < k) {
+                        const double cx = (double)cv[u].x, cy = (double)cv[u].y, cz = (double)cv[u].z, cw = (double)cv[u].w;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double t;
+                            t = x[r][0] - cx; a[r][u] = fma(t, t, a[r][u]);
+                            t = x[r][1] - cy; a[r][u] = fma(t, t, a[r][u]);
+                            t = x[r][2] - cz; a[r][u] = fma(t, t, a[r][u]);
+                            t = x[r][3] - cw; a[r][u] = fma(t, t, a[r][u]);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int j = lane; j < d; j += 64) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + NW * u;
+                    if (c < k) {
+                        const double cvv = (double)C[(size_t)c * d + j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double t = xs[r * d + j] - cvv;
+                            a[r][u] = fma(t, t, a[r][u]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double tot[8];
+            wave_sum8_f64(a[r], tot);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + NW * u;
+                if (c < k) {
+                    const double sum = tot[u];
+                    if (sum < best[r] || (sum == best[r] && c < bi[r])) { best[r] = sum; bi[r] = c; }      // NaN never wins
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rv[wv * 4 + r] = best[r]; ri[wv * 4 + r] = bi[r]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+        const int r = threadIdx.x;
+        int w = 0;
+        for (int q = 1; q < NW; ++q)
+            if (rv[q * 4 + r] < rv[w * 4 + r] || (rv[q * 4 + r] == rv[w * 4 + r] && ri[q * 4 + r] < ri[w * 4 + r])) w = q;
+        labels[rows[r]] = ri[w * 4 + r] == 0x7fffffff ? 0 : ri[w * 4 + r];
+    }
+}
+
 template <int NCH>
 __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm,
                                                            const half_t* __restrict__ ch, const float* __restrict__ cn,
@@ -1161,8 +1253,8 @@ __global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __r
                                                                 const int* flag_cand, const int* full_list, int d, int k, int kp,
                                                                 int32_t* labels, int32_t* refine_rows_out, int pair_blocks) {
     extern __shared__ double xs[];
-    __shared__ double rv[8];
-    __shared__ int ri[8];
+    __shared__ double rv[32];
+    __shared__ int ri[32];
     // the first gridDim.x - pair_blocks blocks: the all-centres list, one block per row (the long chain of latencies: scheduled first);
     // the others: the pair list, one wave per row.  A block without work ends at once and makes room.
     const int full_grid = gridDim.x - pair_blocks;
@@ -1175,12 +1267,17 @@ __global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __r
         }
         return;
     }
-    // all-centres list: the row as doubles in LDS; the eight waves sweep every eighth centre, eight centres per pass, whole
+    // all-centres list: four rows as doubles in LDS; the eight waves sweep every eighth centre, eight centres per pass, whole
     // centre rows in coalesced float4 loads that are all issued before the first is consumed (a walk down the transposed
     // matrix paid one memory latency per 4 columns)
+    // up to a round of rows: one row per block (every CU busy, latency-bound); many rows (behind a data-point seeding): four rows per block
+    // against the same centre loads (the sweep's L2 traffic is the bound then)
     const int cnt = eh->full_cnt;
-    for (int f = blockIdx.x; f < cnt; f += full_grid) {
-        refine_full_row<8>(X, C, full_list[f], d, k, xs, rv, ri, labels);
+    if (cnt <= 2 * full_grid) {
+        for (int f = blockIdx.x; f < cnt; f += full_grid) refine_full_row<8>(X, C, full_list[f], d, k, xs, rv, ri, labels);
+    } else {
+        for (int f = blockIdx.x * 4; f < cnt; f += full_grid * 4)
+            refine_full_rows4<8>(X, C, full_list + f, cnt - f < 4 ? cnt - f : 4, d, k, xs, rv, ri, labels);
     }
 }
 
@@ -1251,7 +1348,7 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             SCD_HIP(hipEventRecord(ev1, st));
             h->km_ev.emplace_back(ev0, ev1);
         }
-        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 32 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
                                                                                 refine_rows_out, REFINE_PAIR);
         SCD_LAUNCH_CHECK();
         return SCD_OK;
@@ -1304,7 +1401,7 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
             estep_refine_full_kernel<<<2048, 128, (size_t)d * 8 + 64, st>>>(X, ct, eh, fulls, d, k, kp, labels_out);
             if (refine_rows_out) refine_count_kernel<<<1, 1, 0, st>>>(eh, refine_rows_out);
         } else
-        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 8 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
+        estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 32 + 64, st>>>(X, C, ct, eh, flags, fcand, fulls, d, k, kp, labels_out,
                                                                                 refine_rows_out, REFINE_PAIR);
         SCD_LAUNCH_CHECK();
         return SCD_OK;
