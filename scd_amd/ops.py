@@ -604,13 +604,16 @@ class Encoder:
             self._ws = _ws(nb, self.device)
         return self._ws, nb
 
-    def encode_image(self, pixels, normalize=False):
+    def encode_image(self, pixels, normalize=False, out=None):
+        """out: an fp16 [B, out_dim] contiguous tensor (e.g. a row slice of the feature matrix) the features are written into."""
         _need_cuda(pixels)
         pixels = pixels.contiguous()
         if pixels.dtype not in (torch.float16, torch.float32):
             pixels = pixels.float()
         b = pixels.shape[0]
-        out = torch.empty((b, self.out_dim), dtype=torch.float16, device=pixels.device)
+        if out is None:
+            out = torch.empty((b, self.out_dim), dtype=torch.float16, device=pixels.device)
+        assert out.dtype == torch.float16 and out.shape == (b, self.out_dim) and out.is_contiguous() and out.device == pixels.device
         ws, nb = self._workspace(b)
         dt = SCD_F16 if pixels.dtype == torch.float16 else SCD_F32
         check(_L().scd_vit_encode_image(handle(), self._enc, ptr(pixels), dt, b, ptr(out), 1 if normalize else 0, ptr(ws), nb,

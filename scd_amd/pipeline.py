@@ -21,7 +21,7 @@ def encode_images(model, images, batch, out=None):
         out = torch.empty((n, model.visual.output_dim), dtype=torch.float16, device=images.device)
     enc = model.visual.enc
     for s in range(0, n, batch):
-        out[s:s + batch] = enc.encode_image(images[s:s + batch], normalize=True)
+        enc.encode_image(images[s:s + batch], normalize=True, out=out[s:s + batch])       # straight into the feature matrix's rows
     return out
 
 
