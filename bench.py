@@ -331,6 +331,37 @@ def secondary_rooflines(out, wt, dev):
                     "fit_wall_ms_incl_seeding": round(wall * 1e3, 2),
                     "note": "HIP-event brackets include the dispatch latency of the bracketed launch (~5-8 us on a 30 us kernel); the "
                             "rocprofv3 kernel trace of tools/sskm_phases.py (profiles/r03_sskm_phases_kernel_stats.csv) has the kernel alone"})
+    # (iv) one round of the lock-step k-means++ seeding (N*D*s + 8*N bytes per added centre; the ten restarts'
+    # centres of a round share ONE pass over the exact fp16 copy, s = 2): scd_kpp_seed_lockstep on the clustered features, rounds with
+    # 20+ centres present (distance update through the MFMA filter), HIP events around the call / rounds
+    x16 = ops.f16_exact(xc.half().float())
+    if x16 is not None and d % 32 == 0:
+        xe = xc.half().float().contiguous()
+        rr, kk, m0, tr = 10, 64, 24, 32
+        gg = torch.Generator(device=dev).manual_seed(3)
+        buf = torch.zeros((rr, kk, d), dtype=torch.float32, device=dev)
+        d2 = torch.full((rr, n), float("inf"), dtype=torch.float32, device=dev)
+        for j in range(m0):                                   # distances to the first m0 (random) centres of every restart
+            rows = xe[torch.randint(0, n, (rr,), device=dev, generator=gg)].contiguous()
+            buf[:, j] = rows
+            ops.min_update_multi(xe, rows, d2)
+        rv = torch.rand((tr, rr), device=dev, generator=gg, dtype=torch.float32).contiguous()
+        d2w = d2.clone()
+        ops.kpp_seed_lockstep(xe, x16, d2w, rv, buf, m0)      # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d2w.copy_(d2)
+        e0.record()
+        ops.kpp_seed_lockstep(xe, x16, d2w, rv, buf, m0)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / tr
+        byr = n * d * 2 + 8 * n * rr
+        res.append({"kernel": "one round of scd_kpp_seed_lockstep (draw: 3 launches; fetch + centre operands; muf_filter_kernel + muf_exact_kernel), "
+                              "10 restarts in lock-step, N=%d D=%d, %d-%d centres present, clustered synthetic features" % (n, d, m0, m0 + tr),
+                    "bound": "hbm", "achieved": round(byr / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byr / t / 8e12, 4),
+                    "round_us": round(t * 1e6, 1),
+                    "note": "the round's distance update alone (muf_filter_kernel 33 us + muf_exact_kernel 11 us at this size, "
+                            "profiles/r03_seed_kernel_stats.csv) moves these bytes at ~3.2 TB/s; the draw's three dependent launches add 23 us"})
     return res
 
 
