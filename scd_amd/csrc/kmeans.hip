@@ -2310,7 +2310,9 @@ extern "C" int scd_sum_f32_multi(scd_handle h, const float* x, int64_t n, int64_
 // is written is such an exactly rounded value, so the d2 arrays - and the draws - are those of the tile kernel.
 // The pairs a block cannot rule out go to the block's OWN region of the list (LDS counter; one global counter took ~10 ns per wave
 // atomic, 120 us per round at 12,000 pairs), and block b of muf_exact_kernel works region b off.
-constexpr int MUF_GRID = 768;
+// Grid = the blocks that are resident at once (the kernel's registers allow 4 / 3 / 2 waves per SIMD at Dp <= 128 / <= 256 / <= 768):
+// a larger grid would run its last blocks in a half-empty second round.
+static inline int muf_grid(int dp) { return dp <= 128 ? 1024 : dp <= 256 ? 768 : 512; }
 __global__ void __launch_bounds__(256) muf_rown2_kernel(const half_t* __restrict__ X16, long long n, int d, float* __restrict__ rn2) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2471,10 +2473,11 @@ __global__ void __launch_bounds__(256) kpp_fetch_rows_kernel(const float* __rest
 
 static inline int muf_dp(int d) { return (d + 31) / 32 * 32; }
 // list capacity per block: the rows of the tiles its four waves can be dealt (16 rows x 16 restarts per tile)
-static inline long long muf_cap(int64_t n) { return 4 * scd_cdiv(scd_cdiv(n, 16), 4 * MUF_GRID) * 256; }
+static inline long long muf_cap(int64_t n, int g) { return 4 * scd_cdiv(scd_cdiv(n, 16), 4 * g) * 256; }
 extern "C" size_t scd_kpp_seed_ws_bytes(int64_t n, int d, int R) {
-    return (size_t)R * scd_kpp_draw_ws_bytes(n) + scd_align(4 * (size_t)n) + scd_align(2 * 16 * (size_t)muf_dp(d)) + 256 + scd_align(4 * MUF_GRID) +
-           scd_align(8 * (size_t)muf_cap(n) * MUF_GRID) + 256;
+    const int g = muf_grid(muf_dp(d));
+    return (size_t)R * scd_kpp_draw_ws_bytes(n) + scd_align(4 * (size_t)n) + scd_align(2 * 16 * (size_t)muf_dp(d)) + 256 + scd_align(4 * 1024) +
+           scd_align(8 * (size_t)muf_cap(n, g) * g) + 256;
 }
 extern "C" int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
                                      const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws,
@@ -2492,11 +2495,12 @@ extern "C" int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X
     half_t* c16 = (half_t*)((char*)rn2 + scd_align(4 * (size_t)n));
     double* info = (double*)((char*)c16 + scd_align(2 * 16 * (size_t)dp));
     unsigned* counts = (unsigned*)((char*)info + 256);
-    unsigned long long* list = (unsigned long long*)((char*)counts + scd_align(4 * MUF_GRID));
-    const long long cap = muf_cap(n);
+    unsigned long long* list = (unsigned long long*)((char*)counts + scd_align(4 * 1024));
+    const int g = muf_grid(dp);
+    const long long cap = muf_cap(n, g);
     const long long ldc = (long long)k * d;
     const int filt_env = getenv("SCD_KPP_FILTER") ? atoi(getenv("SCD_KPP_FILTER")) : 1;     // 0: the tile kernel reads the float32 rows (A/B)
-    const bool filt = X16 && filt_env && R <= 16 && d % 32 == 0 && (dp == 128 || dp == 256 || dp == 384 || dp == 512 || dp == 768 || dp == 1024) &&
+    const bool filt = X16 && filt_env && R <= 16 && d % 32 == 0 && (dp == 128 || dp == 256 || dp == 384 || dp == 512 || dp == 768) &&
                       n < (1ll << 40) && T > 1;
     if (filt) muf_rown2_kernel<<<(unsigned)scd_cdiv(n, 4), 256, 0, st>>>((const half_t*)X16, n, d, rn2);
     for (int t = 0; t < T; ++t) {
@@ -2514,17 +2518,16 @@ extern "C" int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X
             continue;
         }
         muf_prep_kernel<<<16, 256, 0, st>>>(X, (const long long*)pick, slot, ldc, R, d, dp, c16, info);     // fetch + operands in one launch
-#define MUF_GO(NKS) muf_filter_kernel<NKS><<<MUF_GRID, 256, 0, st>>>((const half_t*)X16, rn2, c16, info, n, d, R, d2, ld, counts, list, cap)
+#define MUF_GO(NKS) muf_filter_kernel<NKS><<<g, 256, 0, st>>>((const half_t*)X16, rn2, c16, info, n, d, R, d2, ld, counts, list, cap)
         switch (dp / 32) {
             case 4: MUF_GO(4); break;
             case 8: MUF_GO(8); break;
             case 12: MUF_GO(12); break;
             case 16: MUF_GO(16); break;
-            case 24: MUF_GO(24); break;
-            default: MUF_GO(32); break;
+            default: MUF_GO(24); break;
         }
 #undef MUF_GO
-        muf_exact_kernel<<<MUF_GRID, 256, 0, st>>>((const half_t*)X16, slot, ldc, d, counts, list, cap, d2, ld);
+        muf_exact_kernel<<<g, 256, 0, st>>>((const half_t*)X16, slot, ldc, d, counts, list, cap, d2, ld);
     }
     SCD_LAUNCH_CHECK();
     return SCD_OK;

@@ -321,7 +321,7 @@ def test_kpp_multi_kernels_equal_single(ops):
 
 
 @pytest.mark.parametrize("n,d,k,R,exact", [(20011, 512, 40, 10, True), (9000, 768, 25, 3, True), (5000, 96, 12, 4, True), (20011, 512, 30, 10, False),
-                                           (3000, 256, 20, 16, True)])
+                                           (3000, 256, 20, 16, True), (7000, 128, 24, 5, True), (4100, 384, 20, 10, True), (2500, 1024, 14, 3, True)])
 def test_kpp_seed_lockstep_rounds_in_c(ops, monkeypatch, n, d, k, R, exact):
     """scd_kpp_seed_lockstep (draw, fetch, distance update of every round behind one call; with the exact fp16 copy the update goes
     through the MFMA filter + float64 pass) leaves the bits of the round-by-round calls it replaces: picks, centres and the final
