@@ -383,3 +383,27 @@ def test_kpp_lockstep_equals_sequential_restarts(monkeypatch, mixed):
         out.append((km.labels_.numpy(), km.cluster_centers_.numpy(), float(km.inertia_), rs.rand()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
+
+
+def test_host_solvers_under_sanitizers(tmp_path):
+    """munkres.cpp, munkres_sparse.cpp and transport.cpp compiled for the host with clang's AddressSanitizer + UndefinedBehaviorSanitizer
+    and driven by tests/sanitize_host.cpp: random assignment problems against brute force, sparse = dense on vote-shaped matrices,
+    transport labels inside their bounds - and no sanitizer report (cluster_utils.py:234-493, clip_lang_util.py:167-178,
+    sskm_constrained.py:277-356).  The GPU sanitizers are not available on this pool; the host code is what can be covered."""
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        clang = shutil.which("clang++")
+    if not clang:
+        pytest.skip("no clang++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "scd_amd", "csrc")
+    exe = str(tmp_path / "sanitize_host")
+    cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-g", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"), "-I", src,
+           os.path.join(src, "munkres.cpp"), os.path.join(src, "munkres_sparse.cpp"), os.path.join(src, "transport.cpp"),
+           os.path.join(root, "tests", "sanitize_host.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
