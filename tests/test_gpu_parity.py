@@ -1385,6 +1385,50 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     assert res["1"][2] == float(okm.inertia_)
 
 
+def test_workspaces_are_not_overrun(ops, monkeypatch):
+    """Every workspace the wrappers size with a *_ws_bytes function gets 4 KB of canary bytes behind it; after the similarity call, a
+    C4-shaped and a C2-shaped E-step, M-steps, a whole SSKM fit (seeding rounds through the filter, Lloyd loops in C) and a vote
+    histogram the canaries are intact: no kernel writes past the size the header promises (the GPU sanitizers are not available
+    on this pool; this is the check that can be had)."""
+    from scd_amd.kmeans import KMeansEngine
+    guards = []
+    real_ws = ops._ws
+
+    def guarded(nbytes, device):
+        t = torch.empty(int(nbytes) + 4096, dtype=torch.uint8, device=device)
+        t[int(nbytes):] = 0xA5
+        guards.append((t, int(nbytes)))
+        return t
+
+    monkeypatch.setattr(ops, "_ws", guarded)
+    ops._kpp_ws.clear()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f = torch.nn.functional.normalize(torch.randn(3000, 512, device="cuda", generator=g), dim=-1).half()
+    wt = torch.nn.functional.normalize(torch.randn(2100, 512, device="cuda", generator=g), dim=-1).half()
+    ops.sim_topk(f, wt, 3, "softmax")
+    ops.sim_topk(f[:257], wt, 5, "raw")
+    for n, d, k in ((9000, 512, 1000), (7000, 768, 100), (5000, 96, 20)):
+        x, y, _ = synth.clustered_features(n, d, min(k, 50), seed=n, noise=0.7)
+        x = x.astype(np.float16).astype(np.float32)
+        data = ops.KMeansData(dev(x))
+        c = dev(x[np.random.RandomState(1).choice(n, k, replace=False)])
+        lab = data.estep(c)
+        ops.kmeans_mstep(dev(x), lab.to(torch.int32), c, k, 0)
+    x, y, _ = synth.clustered_features(20000, 512, 30, seed=5, noise=0.7)
+    x = x.astype(np.float16).astype(np.float32)
+    mask = (y < 15) & (np.random.RandomState(7).rand(len(y)) < 0.5)
+    km = KMeansEngine(k=30, tolerance=1e-4, max_iterations=6, n_init=3, random_state=1)
+    km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
+    nidx = torch.randint(0, 2100, (4000, 5), device="cuda", generator=g)
+    preds = torch.randint(0, 30, (4000,), device="cuda", generator=g)
+    ops.vote_hist(nidx, 5, preds, list(range(30)), 10)
+    torch.cuda.synchronize()
+    assert len(guards) >= 6
+    for t, nb in guards:
+        assert bool((t[nb:] == 0xA5).all()), "a kernel wrote past a %d-byte workspace" % nb
+    ops._kpp_ws.clear()
+
+
 def test_c_abi_host_program_without_torch(ops, tmp_path):
     """examples/c_abi_host.cpp - a C++ host that links libscd_hip.so and uses nothing but include/scd_hip.h and hipMalloc - builds
     with hipcc and reproduces float64 host loops: top-3 names + softmax probabilities (main_unsup.py:504-531) and E-step labels
