@@ -171,6 +171,27 @@ int scd_labels_changed(scd_handle h, const int32_t* a, const int32_t* b, int64_t
  * ws: scd_kpp_draw_ws_bytes(n). */
 int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, const double* u, int n_draws, int64_t* idx_out,
                          double* pot_out, void* ws, size_t ws_bytes, void* stream);
+/* The same greedy seeding for the R = n_init starts of a fit in lock-step, the rounds in C (the starts share X; each owns a fixed
+ * slice of the host RandomState's stream: its first centre, then L = 2 + int(ln k) uniforms per added centre - `_k_init` of the
+ * scikit-learn the reference vendors, local_utils/k_means_constrained/sklearn_import/cluster/k_means_.py:33-132, = `_kmeans_plusplus`
+ * of the pinned 1.0.2).  first: device int64 [R] rows of the first centres; u: device double [k-1][R][L]; C_buf float [R][k][d] and
+ * picks_out int64 [k][R] receive the centres and their row indices.  X16: the exact fp16 copy of X (scd_f16_exact) or NULL: with it
+ * the R * L candidates of a round are measured through the MFMA lower-bound filter of scd_kpp_seed_lockstep, without it densely -
+ * the same potentials (float64 sums of float32(float64-exact) distances), the same picks. */
+size_t scd_kpp_greedy_ws_bytes(int64_t n, int d, int R, int L);
+int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, int L, int k, const int64_t* first,
+                            const double* u, float* C_buf, int64_t* picks_out, void* ws, size_t ws_bytes, void* stream);
+/* sklearn's `_kmeans_single_lloyd` behind one call, for rows with an exact fp16 copy (the Lloyd loop of `KMeans.fit`, main_unsup.py:362):
+ * iterations of scd_kmeans_lloyd_step_delta with sklearn's centre shift (sum_k ||dc_k||^2) from C_start until no label changes
+ * (never at the first iteration) or the shift is <= tol or max_iter is reached, then the E-step of the final centres.  The host stays
+ * one iteration behind the device as in scd_kmeans_lloyd_run (same rings: lab_ring int32 [3][n], C_ring float [3][k,d], stats_ring
+ * double [2][5]; labels_prev int32 [n]).  final_labels int32 [n], final_C [k,d] (device, valid in stream order).  result_host (HOST
+ * double [4]) = {status, n_iter, iterations with the incremental M-step, iterations launched}; status 1: an iteration left a cluster
+ * empty - sklearn re-seeds it with a far point (`_relocate_empty_clusters_dense`), the caller runs that start itself. */
+int scd_kmeans_lloyd_run_sk(scd_handle h, const float* X, const void* prep, int64_t n, const void* X16, int d, int k, int32_t* lab_ring,
+                            int32_t* labels_prev, const float* C_start, float* C_ring, double* sums, int64_t* counts,
+                            const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* final_labels, float* final_C,
+                            double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream);
 /* incremental k-means++ (kpp, sskm_constrained.py:28-44): d2 = min(d2, ||x - c_new||^2) */
 int scd_kmeans_min_update(scd_handle h, const float* X, const float* c_new, int64_t n, int d, float* d2_inout,
                           void* stream);

@@ -232,6 +232,63 @@ def gen_sklearn_kmeans():
     np.savez_compressed(os.path.join(OUT, "kmeans_sklearn.npz"), **out)
 
 
+def _reference_k_init():
+    """The reference's own k-means++ (`_k_init`, scikit-learn 0.19's pure-Python seeding, vendored under
+    local_utils/k_means_constrained/sklearn_import/cluster/k_means_.py:33-132) with the vendored helpers it calls
+    (metrics/pairwise.py `euclidean_distances` :20-114, `check_pairwise_arrays` :246-313, `_return_float_dtype` :556-577;
+    utils/extmath.py `row_norms` :10-27, `stable_cumsum` :93-119, `safe_sparse_dot` :122-149), exec'd from their line ranges:
+    the modules themselves import Cython extensions built for another Python.  Draw sequence = scikit-learn 1.0.2's
+    `_kmeans_plusplus` (randint first centre, `random_sample(n_local_trials) * current_pot`, searchsorted on the stable cumsum)."""
+    import scipy.sparse as sp
+    from scipy.sparse import issparse, csr_matrix
+    from sklearn.utils.validation import check_array as _check_array
+
+    def check_array(a, **kw):           # input validation only; 0.19's keywords that today's validator dropped are ignored
+        kw.pop("warn_on_dtype", None)
+        kw.pop("estimator", None)
+        return _check_array(a, **kw)
+    base = "local_utils/k_means_constrained/sklearn_import/"
+    ns = dict(np=np, sp=sp, issparse=issparse, csr_matrix=csr_matrix, warnings=warnings, check_array=check_array,
+              np_version=tuple(int(v) for v in np.__version__.split(".")[:2]))
+    for rel, lo, hi in (("utils/extmath.py", 10, 27), ("utils/extmath.py", 93, 119), ("utils/extmath.py", 122, 149),
+                        ("metrics/pairwise.py", 556, 577), ("metrics/pairwise.py", 246, 313), ("metrics/pairwise.py", 20, 114),
+                        ("cluster/k_means_.py", 33, 132)):
+        exec(ref_lines(base + rel, lo, hi), ns)
+    return ns["_k_init"], ns["row_norms"]
+
+
+def gen_sklearn_kinit():
+    """Pins for the DEFAULT mode of `--cluster KM` (scikit-learn 1.0.2 semantics, the reference's requirements.txt pin): the
+    picks of the reference-held `_k_init` on the four cases of kmeans_sklearn.npz and on a CUB-shaped case (BASELINE configs[0]:
+    4,500 x 768, K = 200), `RandomState(0)` as `KMeans(random_state=0)` seeds it, for the float32 rows `KMeans.fit` would pass
+    and for their float64 copy.  Ten consecutive seedings on ONE RandomState = the stream of the n_init = 10 default.
+    Stored next to the existing goldens in kmeans_sklearn.npz (keys `*_kinit_*`)."""
+    from oracle import synth
+    k_init, row_norms = _reference_k_init()
+    path = os.path.join(OUT, "kmeans_sklearn.npz")
+    out = dict(np.load(path))
+    cases = [("a", 600, 8, 5, 1, 0.8), ("b", 2500, 64, 12, 2, 0.9), ("c", 4000, 768, 20, 3, 0.8), ("e", 900, 16, 6, 4, 0.7),
+             ("c1", 4500, 768, 200, 5, 0.6)]
+    for tag, n, d, k, seed, noise in cases:
+        x, y, cent = synth.clustered_features(n, d, k, seed=seed, center_seed=seed + 40, noise=noise)
+        out["%s_shape" % tag] = np.array([n, d, k, seed])
+        out["%s_noise" % tag] = np.array(noise)
+        for dt, name in ((np.float32, "f32"), (np.float64, "f64")):
+            xs = x.astype(dt)
+            rs = np.random.RandomState(0)
+            picks = []
+            for _ in range(10 if tag != "c1" else 2):
+                centers = k_init(xs, k, row_norms(xs, squared=True), rs)
+                # rows of X are distinct, so a centre identifies its row
+                idx = [int(np.nonzero((xs == c).all(axis=1))[0][0]) for c in centers]
+                picks.append(idx)
+            out["%s_kinit_%s" % (tag, name)] = np.array(picks, dtype=np.int64)
+            out["%s_kinit_%s_next" % (tag, name)] = np.array(rs.random_sample())      # position in the stream afterwards
+        same = np.array_equal(out["%s_kinit_f32" % tag], out["%s_kinit_f64" % tag])
+        print("_k_init", tag, "first start", out["%s_kinit_f32" % tag][0][:8], "f32 == f64 picks:", same)
+    np.savez_compressed(path, **out)
+
+
 def gen_constrained():
     import sskm_constrained as con           # local_utils/sskm_constrained.py
     out = {}
@@ -497,9 +554,9 @@ def main():
         sys.exit(2)
     os.makedirs(OUT, exist_ok=True)
     install_stubs(NxMinCostFlow)
-    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "constrained", "naming", "encoders"]
+    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "kinit", "constrained", "naming", "encoders"]
     for w in which:
-        dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, sklearn=gen_sklearn_kmeans, constrained=gen_constrained,
+        dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, sklearn=gen_sklearn_kmeans, kinit=gen_sklearn_kinit, constrained=gen_constrained,
              naming=gen_naming, encoders=gen_encoders)[w]()
 
 

@@ -47,11 +47,34 @@ def pairwise_distance64(a, b, block=2048):
     a = np.asarray(a, dtype=F64)
     b = np.asarray(b, dtype=F64)
     out = np.empty((a.shape[0], b.shape[0]), dtype=F64)
+    if a.shape[0] < b.shape[0] and b.shape[0] > block:          # few rows against many (k-means++ candidates): block over the many
+        return pairwise_distance64(b, a, block).T
+    block = max(1, min(block, int(2 ** 21 // max(1, b.shape[0] * a.shape[1]))))       # the [block, k, d] temporary stays in cache
     for s in range(0, a.shape[0], block):
         blk = a[s:s + block]
         # (x-c)^2 summed; keep the difference form (no ||x||^2 - 2xc + ||c||^2 cancellation)
         d = blk[:, None, :] - b[None, :, :]
         out[s:s + block] = np.einsum("nkd,nkd->nk", d, d)
+    return out
+
+
+def dist_f32(a, b):
+    """float32(difference-form float64 squared distance) of every pair - pairwise_distance64(a, b).astype(float32) - at BLAS speed for
+    the large test shapes (CUB-sized k-means++ rounds): the float64 GEMM form g = |a|^2 + |b|^2 - 2 a.b is within ~D 2^-52 (|a|^2 + |b|^2)
+    of the difference form; where float32(g - e) == float32(g + e) for e = 1e-11 (|a|^2 + |b|^2) the rounding of the true value is
+    decided, every other pair (and every NaN) is recomputed in the difference form."""
+    a64, b64 = np.asarray(a, dtype=F64), np.asarray(b, dtype=F64)
+    if a64.shape[0] * b64.shape[0] * a64.shape[1] <= 2 ** 22:
+        return pairwise_distance64(a64, b64).astype(F32)
+    an, bn = np.einsum("nd,nd->n", a64, a64), np.einsum("kd,kd->k", b64, b64)
+    g = an[:, None] + bn[None, :] - 2.0 * (a64 @ b64.T)
+    e = 1e-11 * (an[:, None] + bn[None, :])
+    lo, hi = (g - e).astype(F32), (g + e).astype(F32)
+    out = g.astype(F32)
+    ia, ib = np.nonzero(lo != hi)
+    for s in range(0, ia.size, 65536):
+        df = a64[ia[s:s + 65536]] - b64[ib[s:s + 65536]]
+        out[ia[s:s + 65536], ib[s:s + 65536]] = np.einsum("nd,nd->n", df, df).astype(F32)
     return out
 
 
@@ -68,10 +91,37 @@ def estep(x, centers):
     which is what torch.min does not guarantee - documented divergence, the
     reference propagates NaN.
     """
-    d = pairwise_distance64(x, centers)
+    x64 = np.asarray(x, dtype=F64)
+    c64 = np.asarray(centers, dtype=F64)
+    n, k = x64.shape[0], c64.shape[0]
+    if n * k * x64.shape[1] <= 2 ** 24:              # small cases: the difference form for every pair
+        d = pairwise_distance64(x64, c64)
+        d = np.where(np.isnan(d), np.inf, d)
+        lab = np.argmin(d, axis=1)
+        return lab.astype(np.int64), d[np.arange(n), lab].astype(F32), d
+    # large cases (C1 / C3-shaped tests): the same decisions at BLAS speed.  The float64 GEMM form |x|^2 + |c|^2 - 2 x.c is within
+    # ~D 2^-52 (|x|^2 + |c|^2) of the difference form; a row whose two smallest values are further apart than 1e-9 (|x|^2 + max |c|^2)
+    # - four orders above that bound - has the difference form's argmin, every other row is re-evaluated in the difference form.  The
+    # returned distances of the chosen centres are difference-form values in either case.
+    xn, cn = np.einsum("nd,nd->n", x64, x64), np.einsum("kd,kd->k", c64, c64)
+    d = xn[:, None] + cn[None, :] - 2.0 * (x64 @ c64.T)
     d = np.where(np.isnan(d), np.inf, d)
     lab = np.argmin(d, axis=1)
-    mind = d[np.arange(d.shape[0]), lab]
+    if k > 1:
+        two = np.partition(d, 1, axis=1)[:, :2]
+        near = ~((two[:, 1] - two[:, 0]) > 1e-9 * (xn + np.nanmax(cn)))
+    else:
+        near = np.zeros(n, dtype=bool)
+    rows = np.nonzero(near)[0]
+    if rows.size:
+        dr = pairwise_distance64(x64[rows], c64)
+        dr = np.where(np.isnan(dr), np.inf, dr)
+        d[rows] = dr
+        lab[rows] = np.argmin(dr, axis=1)
+    diff = x64 - c64[lab]
+    mind = np.einsum("nd,nd->n", diff, diff)
+    mind = np.where(np.isnan(mind), np.inf, mind)
+    d[np.arange(n), lab] = mind
     return lab.astype(np.int64), mind.astype(F32), d
 
 
@@ -293,13 +343,13 @@ def sklearn_kpp(x, k, random_state, compat="1.7.2"):
     else:
         p = np.ones(n, dtype=F32)
         picks = [int(rs.choice(n, p=p / p.sum()))]
-    d2 = pairwise_distance64(x, x[picks[0]][None])[:, 0].astype(F32)
+    d2 = dist_f32(x, x[picks[0]][None])[:, 0]
     for _ in range(1, k):
         pot = F32(d2.astype(F64).sum())
         rv = rs.uniform(size=trials) * F64(pot)
         cand = np.searchsorted(np.cumsum(d2.astype(F64)), rv)
         np.clip(cand, None, n - 1, out=cand)
-        dc = np.minimum(d2[None, :], pairwise_distance64(x[cand], x).astype(F32))
+        dc = np.minimum(d2[None, :], dist_f32(x[cand], x))
         best = int(np.argmin(dc.astype(F64).sum(axis=1)))
         picks.append(int(cand[best]))
         d2 = dc[best]

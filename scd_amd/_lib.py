@@ -73,6 +73,13 @@ SIGNATURES = {
     "scd_kpp_seed_ws_bytes": (_sz, [_i64, _i, _i]),
     # h, X, X16, n, d, R, d2, ld, r_dev, T, C_buf, k, m0, picks_out, ws, nb, stream
     "scd_kpp_seed_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "scd_kpp_greedy_ws_bytes": (_sz, [_i64, _i, _i, _i]),
+    # h, X, X16, n, d, R, L, k, first, u, C_buf, picks_out, ws, nb, stream
+    "scd_kpp_greedy_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    # h, X, prep, n, X16, d, k, lab_ring, labels_prev, C_start, C_ring, sums, counts, sumsq4, stats_ring, max_iter, tol, final_labels,
+    # final_C, result_host, ws_e, nb_e, ws_m, nb_m, stream
+    "scd_kmeans_lloyd_run_sk": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp,
+                                     _vp, _sz, _vp, _sz, _vp]),
     "scd_sum_f32_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "scd_sum_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),

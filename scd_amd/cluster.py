@@ -54,35 +54,50 @@ class KMeans:
         self.algorithm = algorithm
 
     # ------------------------------------------------------------------ seeding (sklearn `_kmeans_plusplus`)
+    def _draws(self, rs, n, starts):
+        """What `starts` consecutive k-means++ seedings take from the RandomState, in sklearn's order: per start the first centre
+        (1.0.2 / the reference's vendored `_k_init`: `randint(n)`; 1.7.2: `choice(n, p=uniform)`), then 2 + int(ln k) uniforms per
+        added centre.  The Lloyd iterations between two seedings draw nothing, so the stream can be consumed up front."""
+        k = self.n_clusters
+        trials = 2 + int(np.log(k))
+        first = np.empty(starts, dtype=np.int64)
+        u = np.empty((starts, k - 1, trials), dtype=np.float64)
+        for j in range(starts):
+            if self.sklearn_compat == "1.0.2":
+                first[j] = rs.randint(n)
+            else:
+                p = np.ones(n, dtype=np.float32)
+                first[j] = rs.choice(n, p=p / p.sum())
+            for c in range(k - 1):
+                u[j, c] = rs.uniform(size=trials)
+        return first, u
+
+    def _seed(self, data, x16, rs, starts):
+        """The greedy k-means++ seedings of `starts` consecutive starts, advanced in lock-step behind one call
+        (scd_kpp_greedy_lockstep).  Returns float32 [starts, k, d] on the device."""
+        first, u = self._draws(rs, data.n, starts)
+        out = []
+        step = max(1, min(starts, 64, 256 // u.shape[2]))           # the filter's list format holds 256 candidates per round
+        for a in range(0, starts, step):
+            cent, _ = ops.kpp_greedy_lockstep(data.x, x16, first[a:a + step], u[a:a + step], self.n_clusters)
+            out.append(cent)
+        return out[0] if len(out) == 1 else torch.cat(out)
+
     def _kpp(self, data, rs):
-        x = data.x
-        n, k = x.shape[0], self.n_clusters
-        n_local_trials = 2 + int(np.log(k))
-        if self.sklearn_compat == "1.0.2":
-            first = int(rs.randint(n))
-        else:
-            p = np.ones(n, dtype=np.float32)
-            first = int(rs.choice(n, p=p / p.sum()))
-        centers = torch.empty((k, x.shape[1]), dtype=torch.float32, device=x.device)
-        centers[0] = x[first]
-        d2 = torch.full((n,), float("inf"), dtype=torch.float32, device=x.device)
-        data.min_update(centers[0], d2)
-        tmp = torch.empty((n_local_trials, n), dtype=torch.float32, device=x.device)
-        for c in range(1, k):
-            cand, _ = ops.kpp_searchsorted(d2, rs.uniform(size=n_local_trials))
-            rows = x.index_select(0, cand)
-            pots = []
-            for t in range(n_local_trials):
-                tmp[t].copy_(d2)
-                data.min_update(rows[t], tmp[t])
-                pots.append(ops.sum_f32(tmp[t]))
-            best = torch.argmin(torch.cat(pots))          # first minimum, like np.argmin
-            centers[c] = rows.index_select(0, best.reshape(1))[0]
-            d2 = tmp.index_select(0, best.reshape(1))[0].clone()
-        return centers
+        """One seeding (the reference-held `_k_init` / sklearn's `_kmeans_plusplus`): centres float32 [k, d]."""
+        return self._seed(data, ops.f16_exact(data.x), rs, 1)[0]
 
     # ------------------------------------------------------------------ sklearn `_kmeans_single_lloyd`
-    def _lloyd(self, data, centers, tol_abs):
+    def _lloyd(self, data, centers, tol_abs, lb=None):
+        """lb: ops.LloydBuffers over the rows' exact fp16 copy -> the loop runs in C (scd_kmeans_lloyd_run_sk); an empty cluster
+        (sklearn relocates it) or rows without such a copy take the loop below."""
+        if lb is not None and lb.inc and os.environ.get("SCD_LLOYD_RUN", "1") != "0":
+            lb.c0.copy_(centers)
+            got = lb.run_sk(self.max_iter, tol_abs)
+            if got is not None:
+                labels, cen, n_iter = got
+                inertia = float(ops.sum_f32(data.rowdist(cen, labels)).item())
+                return labels, inertia, cen, n_iter
         x = data.x
         n, k = x.shape[0], self.n_clusters
         labels_old = torch.full((n,), -1, dtype=torch.int32, device=x.device)
@@ -131,6 +146,8 @@ class KMeans:
             xt = xt.cuda()
         data = ops.KMeansData(xt.float())
         x = data.x
+        x16 = ops.f16_exact(x)                    # features that left an fp16 encoder: filter seeding, incremental M-step, C loops
+        lb = ops.LloydBuffers(data, x, x16, self.n_clusters) if x16 is not None else None
         n, d = x.shape
         if n < self.n_clusters:
             raise ValueError(f"n_samples={n} should be >= n_clusters={self.n_clusters}.")
@@ -148,17 +165,18 @@ class KMeans:
         if explicit:
             n_init = 1
         best = None
-        for _ in range(n_init):
+        seeds = self._seed(data, x16, rs, n_init) if (not explicit and self.init == "k-means++") else None
+        for j in range(n_init):
             if explicit:
                 centers = torch.as_tensor(np.asarray(self.init, dtype=np.float32)).to(x.device).contiguous()
             elif self.init == "k-means++":
-                centers = self._kpp(data, rs)
+                centers = seeds[j]
             elif self.init == "random":
                 seeds = rs.choice(n, size=self.n_clusters, replace=False)
                 centers = x[torch.as_tensor(seeds, device=x.device)].contiguous()
             else:
                 raise ValueError("init must be 'k-means++', 'random' or an array")
-            labels, inertia, centers, n_iter = self._lloyd(data, centers, tol_abs)
+            labels, inertia, centers, n_iter = self._lloyd(data, centers, tol_abs, lb)
             if best is None:
                 better = True
             elif self.sklearn_compat == "1.0.2":

@@ -732,7 +732,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     if (chunks <= 0) return;
     const int tstride = per_xcd;
     if (stagger > 0) {   // phase-shift the blocks of an XCD (see launch_w4): wall_clock64 ticks at 100 MHz
-        const long long target = wall_clock64() + (long long)(slot_id & 7) * stagger;
+        // stagger >= 2^20: whole XCDs are shifted against each other (their 32 blocks stay in lock-step and keep sharing panels in
+        // the XCD's L2) instead of the blocks inside an XCD
+        const long long target = wall_clock64() + (stagger >= (1 << 20) ? (long long)xcd * (stagger - (1 << 20)) : (long long)(slot_id & 7) * stagger);
         while (wall_clock64() < target) __builtin_amdgcn_s_sleep(32);
     }
     auto it_step = [&](TileIt& it) {       // t += tstride

@@ -1631,6 +1631,16 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
             if (threadIdx.x < o) tred[threadIdx.x] += tred[threadIdx.x + o];
             __syncthreads();
         }
+        // clusters that received no row (scd_kmeans_lloyd_run_sk: sklearn relocates them, the caller has to step in)
+        __shared__ int n_empty;
+        if (threadIdx.x == 0) n_empty = 0;
+        __syncthreads();
+        if (mirror) {
+            int ne = 0;
+            for (int i = threadIdx.x; i < k; i += 256) ne += counts[i] == 0;
+            if (ne) atomicAdd(&n_empty, ne);
+        }
+        __syncthreads();
         double in_l = 0.0, in_u = 0.0;
         if (inertia_out) {                        // the K partials in the fixed tree order of inertia_dd_kernel
             __shared__ double tr[256][4];
@@ -1678,6 +1688,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const double* sums, const
                 mirror[2] = sh;
                 mirror[3] = ((volatile const double*)stats5)[3];
                 mirror[4] = chg;
+                mirror[5] = (double)n_empty;
                 __threadfence_system();
                 ((volatile double*)mirror)[7] = seq;
             }
@@ -2356,7 +2367,9 @@ template <int NKS>
 __global__ void __launch_bounds__(256) muf_filter_kernel(const half_t* __restrict__ X16, const float* __restrict__ rn2, const half_t* __restrict__ c16,
                                                          const double* __restrict__ info, long long n, int d, int R,
                                                          const float* __restrict__ d2, long long ld, unsigned* __restrict__ counts,
-                                                         unsigned long long* __restrict__ list, long long cap) {
+                                                         unsigned long long* __restrict__ list, long long cap, int mbase = 0, int L = 1) {
+    // mbase, L (the greedy seeding of kmeans_sk_impl.h): the 16 centres of this launch are candidates mbase .. mbase + 15 of R in all,
+    // candidate m is measured against row m / L of d2 (L candidates per start); the lock-step seeding has one per restart (0, 1)
     constexpr int DP = NKS * 32;
     __shared__ unsigned lcount;
     if (threadIdx.x == 0) lcount = 0;
@@ -2369,6 +2382,9 @@ __global__ void __launch_bounds__(256) muf_filter_kernel(const half_t* __restric
     double cn2[4], cdl[4], cnr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cn2[j] = info[(4 * q + j) * 2]; cdl[j] = info[(4 * q + j) * 2 + 1]; cnr[j] = sqrt(cn2[j]); }
+    int drow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) drow[j] = (mbase + 4 * q + j) / L;
     // fp32 accumulation of DP exact products: |acc - x.c| <= DP * 2^-24 * sum |x_j c_j| <= DP * 2^-24 ||x|| ||c||; x1.5 safety
     const double gam = 1.5 * DP * 5.9604644775390625e-8;
     const long long ntile = (n + 15) >> 4;
@@ -2389,14 +2405,14 @@ __global__ void __launch_bounds__(256) muf_filter_kernel(const half_t* __restric
         const double xn2 = (double)rn2[rowc];
         float old[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) old[j] = (4 * q + j < R) ? d2[(size_t)(4 * q + j) * ld + rowc] : 0.f;
+        for (int j = 0; j < 4; ++j) old[j] = (mbase + 4 * q + j < R) ? d2[(size_t)drow[j] * ld + rowc] : 0.f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ca[ks], xb[ks], acc, 0, 0, 0);
         const double xnr = sqrt(xn2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = 4 * q + j;
+            const int m = mbase + 4 * q + j;
             // lower bound of ||x - c||^2: the fp32 dot product's error, the float32 rounding of ||x||^2 (2^-24 relative) and, for a
             // centre that is not exact in fp16, |x.(c - c16)| and the change of ||c||^2
             const double a = xn2 + cn2[j] - 2.0 * (double)acc[j];
@@ -2706,7 +2722,8 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
                                  int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
                                  float* C_out, double* sums, int64_t* counts, const double* sums_lab,
                                  const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
-                                 size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq) {
+                                 size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq,
+                                 int shift_mode = 0) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
     SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
                 "scd_kmeans_lloyd_step_delta: null argument");
@@ -2735,8 +2752,8 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
                                                  (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144 + 32), stats);
     }
     SCD_LAUNCH_CHECK();
-    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3, stats + 4, stats,
-                         mirror, seq, sums_lab, counts_lab, sumsq4, fused_inertia ? stats : nullptr);
+    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, shift_mode, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3, stats + 4,
+                         stats, mirror, seq, sums_lab, counts_lab, sumsq4, fused_inertia ? stats : nullptr);
 }
 
 extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
@@ -2772,6 +2789,8 @@ extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* 
         for (int i = 0; i < 16; ++i) h->run_host[i] = 0.0;
         SCD_HIP(hipHostGetDevicePointer((void**)&h->run_dev, h->run_host, 0));
     }
+    h->prep_C = nullptr;                            // no hand-over survives from an earlier fit on this handle
+    h->prep_ok = 0;
     const size_t kd = (size_t)k * d;
     const int64_t l_num = n_cat - n_u;
     for (int sl = 0; sl < 3 && l_num > 0; ++sl)     // the labelled rows' labels never change: every slot carries them
@@ -2834,7 +2853,9 @@ extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* 
         double pred = changed_seen;
         if (it >= 3 && changed_prev > 0. && changed_seen < changed_prev) pred = changed_seen * (changed_seen / changed_prev) * (changed_seen / changed_prev);
         const bool full = it < 2 || changed_seen < 0. || pred > many;
-        const int flags = (few ? SCD_ESTEP_FEW : 0) | SCD_ESTEP_CENTRES_FROM_FINALIZE | (full ? SCD_LLOYD_FULL : 0);
+        // the hand-over is vouched for only when c_in IS the previous step's C_out: C_start was not produced by a finalize of this
+        // run, and a recycled address from an earlier fit must not be mistaken for one
+        const int flags = (few ? SCD_ESTEP_FEW : 0) | (it > 0 ? SCD_ESTEP_CENTRES_FROM_FINALIZE : 0) | (full ? SCD_LLOYD_FULL : 0);
         h->run_seq += 1.0;
         seq_of[it & 1] = h->run_seq;
         const int rc = lloyd_step_delta_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, lab_ring + (size_t)(it % 3) * n_cat, labels_prev, c_in,
@@ -2886,3 +2907,5 @@ extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void*
     if (!rc) rc = finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, 0, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3);
     return rc;
 }
+
+#include "kmeans_sk_impl.h"

@@ -1,0 +1,438 @@
+// kmeans_sk_impl.h - included at the end of kmeans.hip (it uses that file's static kernels and helpers; not a stand-alone header).
+//
+// The `--cluster KM` path of the reference (`KMeans(n_clusters, random_state=0).fit(u_feats).labels_`, /root/reference/main_unsup.py:362,
+// main_ptsup.py:381; the default clustering of scripts/evaluate_unsupervised.sh) on the machinery the SSKM path got in round 3:
+//   scd_kpp_greedy_lockstep   scikit-learn's greedy k-means++ (`_k_init` of the scikit-learn the reference vendors,
+//                             local_utils/k_means_constrained/sklearn_import/cluster/k_means_.py:33-132 = `_kmeans_plusplus` of 1.0.2 /
+//                             1.7.2) for the n_init starts of a fit in lock-step, the rounds in C;
+//   scd_kmeans_lloyd_run_sk   `_kmeans_single_lloyd` (strict / tolerance stop, final E-step) with the host one iteration behind.
+//
+// Greedy seeding, one round (centre t of every start r < R): L = 2 + int(ln k) candidates per start by searchsorted on the cumulative
+// closest distances; the candidate with the smallest new potential sum_i min(d2[r][i], ||x_i - x_cand||^2) is kept.  With the exact fp16
+// copy of X the M = R * L candidates of a round go through the MFMA lower-bound filter of the lock-step seeding (muf_filter_kernel, 16
+// candidates per pass over X): for most rows the bound proves min(d2, dist) = d2, the (row, candidate) pairs it cannot rule out get the
+// exact float32(float64 sum) distance, and a candidate's potential is sum(d2) + sum over its listed pairs of (min(d2, dist) - d2): the
+// same float32 values summed in float64 as a dense evaluation would.  The winner's listed values are then written into d2.  Without the
+// copy (float32 features that do not survive the fp16 round trip) and in the first rounds (a candidate improves most rows) the
+// candidates are evaluated densely by the tile kernel of the lock-step seeding (minupd_tile_kernel).
+
+// candidates: idx_out[r * L + l] = searchsorted(cumsum_f64(d2[r]), u[r * L + l] * float32(sum d2[r])) clipped to n - 1; grid (L, R)
+__global__ void __launch_bounds__(1024) kg_search_kernel(const float* __restrict__ d2_all, long long n, long long ld, const double* __restrict__ u,
+                                                         const double* __restrict__ bsum_all, int nb, int L, long long* __restrict__ idx_out) {
+    __shared__ double sh[32];
+    __shared__ long long best;
+    __shared__ int owner;
+    __shared__ double owner_pre;
+    const int r = blockIdx.y, slot = r * L + blockIdx.x;
+    const float* d2 = d2_all + (size_t)r * ld;
+    const double* bsum = bsum_all + (size_t)r * nb;
+    if (threadIdx.x == 0) {
+        double pot = 0.0;
+        for (int b = 0; b < nb; ++b) pot += bsum[b];
+        const double rv = u[slot] * (double)(float)pot;
+        double run = 0.0;
+        int ow = -1;
+        double opre = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            const double nxt = run + bsum[b];
+            if (ow < 0 && nxt >= rv) { ow = b; opre = run; }
+            run = nxt;
+        }
+        owner = ow;
+        owner_pre = opre;
+        best = 0x7fffffffffffffffll;
+        sh[31] = rv;
+    }
+    __syncthreads();
+    const double rv = sh[31];
+    if (owner < 0) {
+        if (threadIdx.x == 0) idx_out[slot] = n - 1;
+        return;
+    }
+    double pre = owner_pre;
+    for (int b = owner; b < nb; ++b) {
+        const long long i0 = (long long)b * KPP_TILE + threadIdx.x * 4;
+        float pv[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pv[q] = (i0 + q < n) ? d2[i0 + q] : 0.f;
+            s += (double)pv[q];
+        }
+        double tot;
+        double run = pre + block_scan_excl_1024(s, sh, &tot);
+        long long found = 0x7fffffffffffffffll;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            run += (double)pv[q];
+            if (found == 0x7fffffffffffffffll && i0 + q < n && run >= rv) found = i0 + q;
+        }
+        if (found != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&best, (unsigned long long)found);
+        __syncthreads();
+        if (best != 0x7fffffffffffffffll) break;
+        pre += tot;
+    }
+    if (threadIdx.x == 0) idx_out[slot] = (best == 0x7fffffffffffffffll) ? n - 1 : best;
+}
+
+// block m < Mp (Mp = M rounded up to 16): Cn[m] = X[cand[m]] (float32), c16[m] = its fp16 image (zero rows beyond M, zero columns
+// beyond d), info[m] = {||c16||^2, ||c - c16||}; block 0 also clears the potentials of the round
+__global__ void __launch_bounds__(256) kg_prep_kernel(const float* __restrict__ X, const long long* __restrict__ cand, int M, int d, int dp,
+                                                      float* __restrict__ Cn, half_t* __restrict__ c16, double* __restrict__ info,
+                                                      double* __restrict__ potd) {
+    __shared__ double red[4][2];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (m == 0)
+        for (int i = threadIdx.x; i < M; i += 256) potd[i] = 0.0;
+    double s2 = 0.0, e2 = 0.0;
+    const long long src = m < M ? cand[m] : 0;
+    for (int j = threadIdx.x; j < dp; j += 256) {
+        const float c = (m < M && j < d) ? X[src * d + j] : 0.f;
+        if (m < M && j < d) Cn[(size_t)m * d + j] = c;
+        if (c16) {
+            const half_t hc = (half_t)c;
+            c16[(size_t)m * dp + j] = hc;
+            const double hv = (double)(float)hc, e = (double)c - hv;
+            s2 = fma(hv, hv, s2);
+            e2 = fma(e, e, e2);
+        }
+    }
+    if (!c16) return;
+    s2 = wave_sum_f64(s2);
+    e2 = wave_sum_f64(e2);
+    if (lane == 0) { red[wave][0] = s2; red[wave][1] = e2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[m * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        info[m * 2 + 1] = sqrt((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+    }
+}
+
+// the listed (row, candidate) pairs of batch blockIdx.y: v = min(d2[m / L][row], float32(sum_j (x_j - c_j)^2)) (float64 accumulation, x
+// from the exact fp16 copy: muf_exact_kernel's value), kept in vals[] for the winner's update; potd[m] += v - d2 (float64, <= 0).
+__global__ void __launch_bounds__(256) kg_exact_kernel(const half_t* __restrict__ X16, const float* __restrict__ Cn, int d, int L, int M,
+                                                       const unsigned* __restrict__ counts_all, const unsigned long long* __restrict__ list_all,
+                                                       float* __restrict__ vals_all, long long cap, int g, const float* __restrict__ d2,
+                                                       long long ld, double* __restrict__ potd) {
+    __shared__ double lpot[256];
+    const int lane = threadIdx.x & 63, sub = lane >> 4, l16 = lane & 15;
+    const size_t region = (size_t)blockIdx.y * g + blockIdx.x;
+    const unsigned cnt = counts_all[region];
+    const unsigned long long* mine = list_all + region * cap;
+    float* myv = vals_all + region * cap;
+    lpot[threadIdx.x] = 0.0;
+    __syncthreads();
+    for (unsigned p0 = (threadIdx.x >> 6) * 4; p0 < cnt; p0 += 16) {
+        const unsigned p = p0 + sub;
+        const bool on = p < cnt;
+        const unsigned long long e = mine[on ? p : p0];
+        const long long row = (long long)(e >> 8);
+        const int m = (int)(e & 255);
+        const half_t* x = X16 + row * d;
+        const float* c = Cn + (size_t)m * d;
+        const float old = d2[(size_t)(m / L) * ld + row];
+        double s = 0.0;
+        for (int j0 = l16 * 8; j0 < d; j0 += 512) {
+            half8 xv[4];
+            float4 cv[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 128 * u;
+                if (j < d) {
+                    xv[u] = *(const half8*)(x + j);
+                    cv[u][0] = *(const float4*)(c + j);
+                    cv[u][1] = *(const float4*)(c + j + 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 128 * u;
+                if (j < d) {
+                    const float cc[8] = {cv[u][0].x, cv[u][0].y, cv[u][0].z, cv[u][0].w, cv[u][1].x, cv[u][1].y, cv[u][1].z, cv[u][1].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const double t = (double)(float)xv[u][q] - (double)cc[q];
+                        s = fma(t, t, s);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (on && l16 == 0) {
+            const float v = fminf(old, (float)s);
+            myv[p] = v;
+            if (v < old) atomicAdd(&lpot[m], (double)v - (double)old);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < M && lpot[threadIdx.x] != 0.0) atomicAdd(&potd[threadIdx.x], lpot[threadIdx.x]);
+}
+
+// best[r] = the first candidate of start r with the smallest potential (np.argmin / the strict `<` of `_k_init`); NaN never wins
+__device__ __forceinline__ int kg_best_of(const double* __restrict__ potd, int r, int L) {
+    int b = 0;
+    double bv = potd[r * L];
+    for (int l = 1; l < L; ++l) {
+        const double v = potd[r * L + l];
+        if (v < bv || (bv != bv && v == v)) { bv = v; b = l; }
+    }
+    return b;
+}
+// filter path: the winner's listed values into d2; block (0, 0) also records the round's picks and centres
+__global__ void __launch_bounds__(256) kg_apply_kernel(const unsigned* __restrict__ counts_all, const unsigned long long* __restrict__ list_all,
+                                                       const float* __restrict__ vals_all, long long cap, int g, const double* __restrict__ potd,
+                                                       int R, int L, float* __restrict__ d2, long long ld, const long long* __restrict__ cand,
+                                                       const float* __restrict__ Cn, int d, float* __restrict__ C_slot, long long ldc,
+                                                       long long* __restrict__ picks_t) {
+    __shared__ int win[64];
+    if ((int)threadIdx.x < R) win[threadIdx.x] = threadIdx.x * L + kg_best_of(potd, threadIdx.x, L);
+    __syncthreads();
+    const size_t region = (size_t)blockIdx.y * g + blockIdx.x;
+    const unsigned cnt = counts_all[region];
+    const unsigned long long* mine = list_all + region * cap;
+    const float* myv = vals_all + region * cap;
+    for (unsigned p = threadIdx.x; p < cnt; p += 256) {
+        const unsigned long long e = mine[p];
+        const int m = (int)(e & 255), r = m / L;
+        if (win[r] == m) d2[(size_t)r * ld + (long long)(e >> 8)] = myv[p];
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int r = 0; r < R; ++r) {
+            const int m = win[r];
+            if (threadIdx.x == 0) picks_t[r] = cand[m];
+            for (int j = threadIdx.x; j < d; j += 256) C_slot[(size_t)r * ldc + j] = Cn[(size_t)m * d + j];
+        }
+    }
+}
+// dense path: potd[r * L + l] holds the whole potential of trial l (sum of tmp[l][r]); d2[r] = tmp[winner][r]; block (0, 0) records
+__global__ void __launch_bounds__(256) kg_select_kernel(const float* __restrict__ tmp, long long n, long long ld, const double* __restrict__ potd,
+                                                        int R, int L, float* __restrict__ d2, const long long* __restrict__ cand,
+                                                        const float* __restrict__ Cn, int d, float* __restrict__ C_slot, long long ldc,
+                                                        long long* __restrict__ picks_t) {
+    const int r = blockIdx.y;
+    const int b = kg_best_of(potd, r, L);
+    const float* src = tmp + ((size_t)b * R + r) * ld;
+    float* dst = d2 + (size_t)r * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0) {
+        const int m = r * L + b;
+        if (threadIdx.x == 0) picks_t[r] = cand[m];
+        for (int j = threadIdx.x; j < d; j += 256) C_slot[(size_t)r * ldc + j] = Cn[(size_t)m * d + j];
+    }
+}
+// out[blockIdx.x * stride] = float64 sum of row blockIdx.x of x (the arithmetic of sum_multi_kernel)
+__global__ void __launch_bounds__(1024) kg_potential_kernel(const float* __restrict__ x, long long n, long long ld, double* __restrict__ out, int stride) {
+    __shared__ double sh[32];
+    const float* v = x + (size_t)blockIdx.x * ld;
+    const long long seg = scd_cdiv_dev(n, 1024);
+    const long long a = threadIdx.x * seg, b = (a + seg < n) ? a + seg : n;
+    double s = 0.0;
+    for (long long i = a; i < b; ++i) s += (double)v[i];
+    double tot;
+    block_scan_excl_1024(s, sh, &tot);
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * stride] = tot;
+}
+__global__ void __launch_bounds__(256) kg_fill_kernel(float* __restrict__ p, long long n_elems, float v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (long long)gridDim.x * 256) p[i] = v;
+}
+
+struct KgLayout {
+    long long ld, cap;
+    int g, dp, nbat, Mp, nb;
+    size_t o_d2, o_bsum, o_cand, o_potd, o_cn, o_c16, o_info, o_rn2, o_counts, o_list, o_vals, o_tmp, total;
+};
+static KgLayout kg_layout(int64_t n, int d, int R, int L, bool filt) {
+    KgLayout y;
+    const int M = R * L;
+    y.ld = (n + 63) / 64 * 64;
+    y.dp = muf_dp(d);
+    y.g = muf_grid(y.dp);
+    y.cap = muf_cap(n, y.g);
+    y.nbat = (M + 15) / 16;
+    y.Mp = y.nbat * 16;
+    y.nb = (int)scd_cdiv(n, KPP_TILE);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += scd_align(bytes); return at; };
+    y.o_d2 = take(4 * (size_t)R * y.ld);
+    y.o_bsum = take(8 * (size_t)R * y.nb);
+    y.o_cand = take(8 * (size_t)y.Mp);
+    y.o_potd = take(8 * (size_t)y.Mp);
+    y.o_cn = take(4 * (size_t)y.Mp * d);
+    y.o_c16 = take(2 * (size_t)y.Mp * y.dp);
+    y.o_info = take(16 * (size_t)y.Mp);
+    y.o_rn2 = take(4 * (size_t)n);
+    y.o_counts = take(4 * (size_t)y.nbat * y.g);
+    y.o_list = take(filt ? 8 * (size_t)y.nbat * y.g * y.cap : 0);
+    y.o_vals = take(filt ? 4 * (size_t)y.nbat * y.g * y.cap : 0);
+    y.o_tmp = take(4 * (size_t)L * R * y.ld);          // dense path (first rounds, or no exact fp16 copy)
+    y.total = o + 256;
+    return y;
+}
+static bool kg_can_filter(int64_t n, int d, int R, int L) {
+    const int dp = muf_dp(d);
+    return R * L <= 256 && R <= 64 && d % 32 == 0 && (dp == 128 || dp == 256 || dp == 384 || dp == 512 || dp == 768) && n < (1ll << 40);
+}
+extern "C" size_t scd_kpp_greedy_ws_bytes(int64_t n, int d, int R, int L) { return kg_layout(n, d, R, L, kg_can_filter(n, d, R, L)).total; }
+
+extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, int L, int k,
+                                       const int64_t* first, const double* u_dev, float* C_buf, int64_t* picks_out, void* ws,
+                                       size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_greedy_lockstep");
+    SCD_REQUIRE(X && first && C_buf && picks_out && ws && n > 0 && d > 0 && R > 0 && R <= 64 && L > 0 && L <= 64 && k >= 1 && (k == 1 || u_dev),
+                "scd_kpp_greedy_lockstep: bad arguments");
+    const bool can = kg_can_filter(n, d, R, L);
+    SCD_REQUIRE(ws_bytes >= kg_layout(n, d, R, L, can).total, "scd_kpp_greedy_lockstep: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const KgLayout y = kg_layout(n, d, R, L, can);
+    char* w = (char*)ws;
+    float* d2 = (float*)(w + y.o_d2);
+    double* bsum = (double*)(w + y.o_bsum);
+    long long* cand = (long long*)(w + y.o_cand);
+    double* potd = (double*)(w + y.o_potd);
+    float* Cn = (float*)(w + y.o_cn);
+    half_t* c16 = (half_t*)(w + y.o_c16);
+    double* info = (double*)(w + y.o_info);
+    float* rn2 = (float*)(w + y.o_rn2);
+    unsigned* counts = (unsigned*)(w + y.o_counts);
+    unsigned long long* list = (unsigned long long*)(w + y.o_list);
+    float* vals = (float*)(w + y.o_vals);
+    float* tmp = (float*)(w + y.o_tmp);
+    const int M = R * L;
+    const long long ldc = (long long)k * d;
+    static const int from_env = getenv("SCD_KM_FILTER_FROM") ? atoi(getenv("SCD_KM_FILTER_FROM")) : 4;   // centres before the filter pays
+    const bool filt = can && X16 != nullptr && from_env >= 0;
+    // centre 0 of every start: the row the host's RandomState drew; d2 = its distances
+    kpp_fetch_rows_kernel<<<R, 256, 0, st>>>(X, (const long long*)first, d, C_buf, ldc);
+    SCD_HIP(hipMemcpyAsync(picks_out, first, 8 * (size_t)R, hipMemcpyDeviceToDevice, st));
+    kg_fill_kernel<<<1024, 256, 0, st>>>(d2, (long long)R * y.ld, __builtin_inff());
+    minupd_all(X, C_buf, n, d, R, d2, y.ld, ldc, st);
+    if (filt && k > 1) muf_rown2_kernel<<<(unsigned)scd_cdiv(n, 4), 256, 0, st>>>((const half_t*)X16, n, d, rn2);
+    for (int t = 1; t < k; ++t) {
+        kpp_tile_sum_multi_kernel<<<dim3(y.nb, R), 1024, 0, st>>>(d2, n, y.ld, bsum, y.nb);
+        kg_search_kernel<<<dim3(L, R), 1024, 0, st>>>(d2, n, y.ld, u_dev + (size_t)(t - 1) * M, bsum, y.nb, L, cand);
+        const bool use_filter = filt && t >= from_env;
+        kg_prep_kernel<<<use_filter ? y.Mp : M, 256, 0, st>>>(X, cand, M, d, y.dp, Cn, use_filter ? c16 : nullptr, info, potd);
+        float* slot = C_buf + (size_t)t * d;
+        long long* picks_t = (long long*)picks_out + (size_t)t * R;
+        if (use_filter) {
+            for (int b = 0; b < y.nbat; ++b) {
+#define KG_GO(NKS)                                                                                                        \
+    muf_filter_kernel<NKS><<<y.g, 256, 0, st>>>((const half_t*)X16, rn2, c16 + (size_t)b * 16 * y.dp, info + b * 32, n, d, M, d2, y.ld, \
+                                                counts + (size_t)b * y.g, list + (size_t)b * y.g * y.cap, y.cap, b * 16, L)
+                switch (y.dp / 32) {
+                    case 4: KG_GO(4); break;
+                    case 8: KG_GO(8); break;
+                    case 12: KG_GO(12); break;
+                    case 16: KG_GO(16); break;
+                    default: KG_GO(24); break;
+                }
+#undef KG_GO
+            }
+            kg_exact_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>((const half_t*)X16, Cn, d, L, M, counts, list, vals, y.cap, y.g, d2, y.ld, potd);
+            kg_apply_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>(counts, list, vals, y.cap, y.g, potd, R, L, d2, y.ld, cand, Cn, d, slot, ldc, picks_t);
+        } else {
+            SCD_HIP(hipMemcpyAsync(tmp, d2, 4 * (size_t)R * y.ld, hipMemcpyDeviceToDevice, st));
+            for (int l = 1; l < L; ++l) SCD_HIP(hipMemcpyAsync(tmp + (size_t)l * R * y.ld, tmp, 4 * (size_t)R * y.ld, hipMemcpyDeviceToDevice, st));
+            for (int l = 0; l < L; ++l) {
+                float* tl = tmp + (size_t)l * R * y.ld;
+                minupd_all(X, Cn + (size_t)l * d, n, d, R, tl, y.ld, (long long)L * d, st);
+            }
+            // potentials: potd[r * L + l] = float64 sum of tmp[l][r] - one launch per trial, written with stride L
+            for (int l = 0; l < L; ++l) kg_potential_kernel<<<R, 1024, 0, st>>>(tmp + (size_t)l * R * y.ld, n, y.ld, potd + l, L);
+            kg_select_kernel<<<dim3(64, R), 256, 0, st>>>(tmp, n, y.ld, potd, R, L, d2, cand, Cn, d, slot, ldc, picks_t);
+        }
+    }
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sklearn's Lloyd loop in C
+// `_kmeans_single_lloyd` (scikit-learn, third-party; call site /root/reference/main_unsup.py:362) for rows with an exact fp16 copy:
+//     for i < max_iter: E-step, centre update; stop when no label changed (strict; never at i = 0) or sum_k ||dc_k||^2 <= tol;
+//     afterwards the E-step of the final centres (the labels `KMeans.labels_` returns).
+// Iteration i is scd_kmeans_lloyd_step_delta (shift mode 1) with the host one iteration behind, as in scd_kmeans_lloyd_run; the
+// speculative iteration i + 1 that is always in flight when i turns out to be the last one IS the final E-step - its labels are the
+// result, its centre update is discarded.  final_C = iteration i's centres.  result_host (HOST double [4]) = {status, n_iter,
+// iterations with the incremental M-step, iterations launched}; status 1: an iteration left a cluster empty (sklearn relocates it
+// to a far point: `_relocate_empty_clusters_dense`) - nothing valid is returned and the caller runs that start itself.
+extern "C" int scd_kmeans_lloyd_run_sk(scd_handle h, const float* X, const void* prep, int64_t n, const void* X16, int d, int k,
+                                       int32_t* lab_ring, int32_t* labels_prev, const float* C_start, float* C_ring, double* sums,
+                                       int64_t* counts, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                                       int32_t* final_labels, float* final_C, double* result_host, void* ws_e, size_t ws_e_bytes,
+                                       void* ws_m, size_t ws_m_bytes, void* stream) {
+    SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_run_sk");
+    SCD_REQUIRE(X && prep && X16 && lab_ring && labels_prev && C_start && C_ring && sums && counts && sumsq4 && stats_ring && final_labels &&
+                    final_C && result_host, "scd_kmeans_lloyd_run_sk: null argument");
+    SCD_REQUIRE(max_iter >= 1 && n > 0, "scd_kmeans_lloyd_run_sk: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->run_host) {
+        SCD_HIP(hipHostMalloc((void**)&h->run_host, 2 * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        for (int i = 0; i < 16; ++i) h->run_host[i] = 0.0;
+        SCD_HIP(hipHostGetDevicePointer((void**)&h->run_dev, h->run_host, 0));
+    }
+    h->prep_C = nullptr;
+    h->prep_ok = 0;
+    const size_t kd = (size_t)k * d;
+    double refined_seen = -1., changed_seen = -1., changed_prev = -1.;
+    const double many = (double)(n / 32 > 256 ? n / 32 : 256);
+    double seq_of[2] = {0., 0.};
+    int delta_steps = 0, launched = 0, stop_it = -1, status = 0;
+    // wait for iteration i's statistics: 0 = go on, 1 = i is the last iteration, 2 = empty cluster, < 0 = error
+    auto settle = [&](int i) -> int {
+        volatile double* host = h->run_host + (i & 1) * 8;
+        const double want = seq_of[i & 1];
+        long long spins = 0;
+        while (host[7] != want) {
+            if ((++spins & 0xFFFFF) == 0) {
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipSuccess && e != hipErrorNotReady) {
+                    scd_set_error("scd_kmeans_lloyd_run_sk: stream error while waiting for iteration %d: %s", i, hipGetErrorString(e));
+                    return SCD_EHIP;
+                }
+                if (e == hipSuccess && host[7] != want) {
+                    scd_set_error("scd_kmeans_lloyd_run_sk: iteration %d finished without publishing its statistics", i);
+                    return SCD_EHIP;
+                }
+            }
+        }
+        refined_seen = host[3];
+        changed_prev = changed_seen;
+        changed_seen = host[4];
+        if (host[5] > 0.) return 2;
+        if (i > 0 && host[4] == 0.) return 1;          // strict: np.array_equal(labels, labels_old)
+        return host[2] <= tol ? 1 : 0;                  // center_shift_tot <= tol
+    };
+    for (int it = 0;; ++it) {
+        const float* c_in = it == 0 ? C_start : C_ring + (size_t)((it - 1) % 3) * kd;
+        float* c_out = C_ring + (size_t)(it % 3) * kd;
+        const bool few = it >= 2 && refined_seen >= 0. && refined_seen <= 64.;
+        double pred = changed_seen;
+        if (it >= 3 && changed_prev > 0. && changed_seen < changed_prev) pred = changed_seen * (changed_seen / changed_prev) * (changed_seen / changed_prev);
+        const bool full = it < 2 || changed_seen < 0. || pred > many;
+        const int flags = (few ? SCD_ESTEP_FEW : 0) | (it > 0 ? SCD_ESTEP_CENTRES_FROM_FINALIZE : 0) | (full ? SCD_LLOYD_FULL : 0);
+        h->run_seq += 1.0;
+        seq_of[it & 1] = h->run_seq;
+        const int rc = lloyd_step_delta_impl(h, X, prep, n, X16, n, d, k, lab_ring + (size_t)(it % 3) * n, labels_prev, c_in, c_out, sums, counts,
+                                             nullptr, nullptr, sumsq4, stats_ring + (it & 1) * 5, flags, ws_e, ws_e_bytes, ws_m, ws_m_bytes, stream,
+                                             h->run_dev + (it & 1) * 8, h->run_seq, 1);
+        if (rc) return rc;
+        ++launched;
+        delta_steps += full ? 0 : 1;
+        if (it > 0) {
+            const int s = settle(it - 1);
+            if (s < 0) return s;
+            if (s == 2) { status = 1; stop_it = it - 1; break; }
+            if (s == 1 || it == max_iter) { stop_it = it - 1; break; }
+        }
+    }
+    if (!status) {
+        SCD_HIP(hipMemcpyAsync(final_labels, lab_ring + (size_t)((stop_it + 1) % 3) * n, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        SCD_HIP(hipMemcpyAsync(final_C, C_ring + (size_t)(stop_it % 3) * kd, kd * 4, hipMemcpyDeviceToDevice, st));
+    }
+    result_host[0] = (double)status;
+    result_host[1] = (double)(stop_it + 1);
+    result_host[2] = (double)delta_steps;
+    result_host[3] = (double)launched;
+    return SCD_OK;
+}

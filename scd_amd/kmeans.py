@@ -249,6 +249,8 @@ class KMeansEngine:
             buf[:, 0] = rows
             d2 = torch.full((restarts, n), float("inf"), dtype=torch.float32, device=dev)
             be.min_update_multi(data, rows.contiguous(), d2)
+        if k - m == 0:                 # k = 1: the first centre is the whole seeding (no rounds, no draws)
+            return buf
         picks = []
         ar = torch.arange(restarts, device=dev)
         # float32(uniform) is what the draw compares with (the reference's `cumsum(prob) >= r` promotes r to prob's float32)

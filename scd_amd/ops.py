@@ -260,9 +260,9 @@ class LloydBuffers:
 
     def step(self, c_in, c_out, stats, expect_few):
         d = self.data
-        # c_in is c0 (a fresh copy: no hand-over registered for it) or the buffer the previous step wrote - these buffers are private
-        # to this object, nothing else writes them
-        flags = (ESTEP_FEW if expect_few else 0) | ESTEP_CENTRES_FROM_FINALIZE
+        # the hand-over is vouched for only when c_in is the buffer the previous step of THIS object wrote (private buffers, nothing
+        # else writes them); c0 is a fresh seeding no finalize produced, and its address may be a recycled one
+        flags = (ESTEP_FEW if expect_few else 0) | (ESTEP_CENTRES_FROM_FINALIZE if c_in is not self.c0 else 0)
         check(_L().scd_kmeans_lloyd_step(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat), ptr(self.cat16), self.cat.shape[0],
                                          d.d, self.k, ptr(self.lab32), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
                                          ptr(stats), flags, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m,
@@ -285,7 +285,7 @@ class LloydBuffers:
         if not self._fit_ready:
             self._prepare_fit()
         d = self.data
-        flags = (ESTEP_FEW if expect_few else 0) | ESTEP_CENTRES_FROM_FINALIZE | (LLOYD_FULL if full else 0)
+        flags = (ESTEP_FEW if expect_few else 0) | (ESTEP_CENTRES_FROM_FINALIZE if c_in is not self.c0 else 0) | (LLOYD_FULL if full else 0)
         check(_L().scd_kmeans_lloyd_step_delta(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), self.cat.shape[0], d.d, self.k,
                                                ptr(self.lab32), ptr(self.lab_prev), ptr(c_in), ptr(c_out), ptr(self.sums), ptr(self.counts),
                                                ptr(self.sums_lab), ptr(self.counts_lab), ptr(self.sumsq), ptr(stats), flags,
@@ -309,6 +309,50 @@ class LloydBuffers:
                                         self.result.ctypes.data, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
         r = self.result
         return best_lab, np.float32(r[0]), best_c, int(r[1]), int(r[2]), int(r[3])
+
+
+    def run_sk(self, max_iter, tol):
+        """sklearn's `_kmeans_single_lloyd` from self.c0 behind one call (scd_kmeans_lloyd_run_sk; no labelled rows).  Returns
+        (labels int32 [n], centres [k, d], n_iter) - the E-step of the final centres and those centres, fresh tensors - or None when an
+        iteration left a cluster empty (sklearn relocates it; the caller runs that start through its own loop)."""
+        if not self._fit_ready:
+            self._prepare_fit()
+        d = self.data
+        n = self.cat.shape[0]
+        assert n == d.n and self.inc
+        self.lab_prev.fill_(-1)
+        lab = torch.empty(n, dtype=torch.int32, device=self.cat.device)
+        cen = torch.empty((self.k, d.d), dtype=torch.float32, device=self.cat.device)
+        check(_L().scd_kmeans_lloyd_run_sk(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), d.d, self.k, ptr(self.lab_ring),
+                                           ptr(self.lab_prev), ptr(self.c0), ptr(self.c_ring), ptr(self.sums), ptr(self.counts),
+                                           ptr(self.sumsq), ptr(self.stats_ring), int(max_iter), float(tol), ptr(lab), ptr(cen),
+                                           self.result.ctypes.data, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
+        r = self.result
+        if r[0] != 0:
+            return None
+        return lab, cen, int(r[1])
+
+
+def kpp_greedy_lockstep(x, x16, first, u, k):
+    """scikit-learn's greedy k-means++ for R starts in lock-step (scd_kpp_greedy_lockstep).  x float32 [n, d]; x16 its exact fp16 copy
+    or None; first: host int64 [R] (the starts' first centres); u: host float64 [R, k - 1, L] (the uniforms each start's RandomState
+    slice provides, L per added centre).  Returns (centres float32 [R, k, d], picks int64 [k, R]) on the device."""
+    _need_cuda(x)
+    n, d = x.shape
+    first = np.ascontiguousarray(first, dtype=np.int64)
+    r = first.shape[0]
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(r, max(k - 1, 0), -1)
+    ell = u.shape[2] if k > 1 else 1
+    dev = x.device
+    first_d = torch.from_numpy(first).to(dev)
+    u_d = torch.from_numpy(np.ascontiguousarray(u.transpose(1, 0, 2))).to(dev) if k > 1 else None       # [k - 1][R][L]
+    cbuf = torch.empty((r, k, d), dtype=torch.float32, device=dev)
+    picks = torch.empty((k, r), dtype=torch.int64, device=dev)
+    nb = _L().scd_kpp_greedy_ws_bytes(n, d, r, ell)
+    ws = _ws(nb, dev)
+    check(_L().scd_kpp_greedy_lockstep(handle(), ptr(x), ptr(x16), n, d, r, ell, k, ptr(first_d), ptr(u_d), ptr(cbuf), ptr(picks),
+                                       ptr(ws), nb, stream_ptr()))
+    return cbuf, picks
 
 
 def kmeans_finalize(sums, counts, c_old=None, shift_mode=0, data=None):

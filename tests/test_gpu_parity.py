@@ -922,7 +922,8 @@ def test_sklearn_kmeans_seeding_and_default_call(ops, golden, tag):
     """`KMeans(n_clusters, random_state=0).fit(u_feats).labels_` (main_unsup.py:362, main_ptsup.py:381) against scikit-learn
     1.7.2 ITSELF (golden): the device k-means++ picks the rows `sklearn.cluster.kmeans_plusplus(x, k, random_state=0)` picks,
     the default call (one start) and the n_init=10 call (ten starts on one RandomState, the 1.0.2 default) return sklearn's
-    labels; in the reference's pinned 1.0.2 mode (not installed here) the result equals the oracle's restatement of that mode."""
+    labels; in the reference's pinned 1.0.2 mode the result equals the oracle's, whose seeding stream the reference-held `_k_init`
+    pins (test_sklearn_102_seeding_matches_reference_k_init)."""
     from scd_amd.cluster import KMeans
     from scd_amd import ops as o
     g = golden("kmeans_sklearn.npz")
@@ -1158,33 +1159,149 @@ def test_zero_shot_bounds_and_cidx_names(ops):
     assert np.array_equal(preds, lg.argmax(1))
 
 
-def _write_cache_tree(root, n=1600, k=8, v=500, seed=51):
+def _write_cache_tree(root, n=1600, k=8, v=500, seed=51, dataset="cifar10", corpus="wordnet", d_feat=512, noise=0.9, layers=1):
     """The reference's on-disk boundary: feature dicts (main_unsup.py:141-146), the [512, V] classifier
     (:389-394), the vocabulary file get_nouns reads (clip_lang_util.py:139-149), a class-name table and a CLIP checkpoint."""
     import json
     from scd_amd.clip import weights as W
-    x, y, cent = synth.clustered_features(n, 512, k, seed=seed, center_seed=seed + 1, noise=0.9)
+    x, y, cent = synth.clustered_features(n, 512, k, seed=seed, center_seed=seed + 1, noise=noise)
     perm, mask_lab = synth.labelled_split(y, k, prop=0.5, seed=seed + 2)
     x, y = x[perm], y[perm]
+    xf = x                                                        # clustering features: the CLIP ones, or d_feat-wide "DINO" ones
+    if d_feat != 512:
+        xf, yf, _ = synth.clustered_features(n, d_feat, k, seed=seed, center_seed=seed + 5, noise=noise)
+        assert np.array_equal(yf[perm], y)
+        xf = xf[perm]
     w = synth.vocabulary(v, 512, cent, seed=seed + 3, jitter=0.4)
     nouns = ["noun-%03d" % i for i in range(v)]                   # get_nouns output is lower-cased and '-' -> '_' by the mains
+    zname, vfile = {"wordnet": ("nouns", "wordnet_all_noun.txt"), "wikibird": ("wikibird", "wiki_birdclass_names.txt")}[corpus]
     os.makedirs(os.path.join(root, "extracted_features"))
     os.makedirs(os.path.join(root, "zeroshot_weights"))
     os.makedirs(os.path.join(root, "data"))
     os.makedirs(os.path.join(root, "clip"))
-    feats = dict(all_feats=x.astype(np.float32), mask_lab=mask_lab, mask_cls=(y < k // 2), targets=y.astype(np.float64))
-    torch.save(feats, os.path.join(root, "extracted_features", "dino_vit_cifar10_all.pt"))
-    torch.save(dict(feats, all_feats=x.astype(np.float16)), os.path.join(root, "extracted_features", "clip_cifar10_all.pt"))
-    torch.save(torch.from_numpy(w), os.path.join(root, "zeroshot_weights", "zeroshot_weights_all_nouns_vit_b_16.pt"))
-    with open(os.path.join(root, "data", "wordnet_all_noun.txt"), "w") as f:
+    feats = dict(all_feats=xf.astype(np.float32), mask_lab=mask_lab, mask_cls=(y < k // 2), targets=y.astype(np.float64))
+    torch.save(feats, os.path.join(root, "extracted_features", "dino_vit_%s_all.pt" % dataset))
+    torch.save(dict(feats, all_feats=x.astype(np.float16)), os.path.join(root, "extracted_features", "clip_%s_all.pt" % dataset))
+    torch.save(torch.from_numpy(w), os.path.join(root, "zeroshot_weights", "zeroshot_weights_all_%s_vit_b_16.pt" % zname))
+    with open(os.path.join(root, "data", vfile), "w") as f:
         f.write("\n".join(nouns) + "\n")
     # classes 0..k-2 carry vocabulary names, the last one a name the vocabulary lacks (row a7 runs on the text tower)
     class_to_idx = {("noun_%03d" % c if c < k - 1 else "not_a_noun"): c for c in range(k)}
     with open(os.path.join(root, "class_names.json"), "w") as f:
         json.dump(class_to_idx, f)
-    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=1, t_layers=1))
+    sd = W.synthetic_clip_state_dict(seed=0, cfg=dict(v_layers=layers, t_layers=layers))
     torch.save({kk: (vv.half() if vv.dim() >= 2 else vv) for kk, vv in sd.items()}, os.path.join(root, "clip", "ViT-B-16.pt"))
+    if d_feat != 512:
+        return x, y, mask_lab, w, xf
     return x, y, mask_lab, w
+
+
+def test_c1_shape_end_to_end(ops, tmp_path, monkeypatch, capsys):
+    """BASELINE configs[0] at its own shape, through main_unsup.main() on the reference's cache files: CUB-200 unsupervised - 5,994
+    images of which ~4,500 unlabelled, cached 768-wide float32 "DINO" features for the clustering, fp16 CLIP features and a 1,000-name
+    vocabulary for the naming, K = 200, the flags main_unsup.py:222-224 name for cub (--topk 3 --num_common_vote 10
+    --num_common_linear 2).  The whole chain k-means -> full-vocabulary top-k -> vote loop -> names equals the ORACLE chain run on the
+    same files bit for bit, for the shipped default `--cluster KM` (`KMeans(n_clusters, random_state=0)`: the scikit-learn 1.0.2 rules
+    the reference pins, ten starts, whose seeding stream is pinned by the reference-held `_k_init` at this shape; and the 1.7.2 rules
+    pinned by scikit-learn itself) and for `--cluster SSKM` (reference: main_unsup.py:334-364, 504-531, 568-614)."""
+    import importlib
+    import scd_amd.clip as clip
+    root = str(tmp_path)
+    n, k, v = 5994, 200, 1000
+    x, y, mask_lab, w, xf = _write_cache_tree(root, n=n, k=k, v=v, seed=61, dataset="cub", corpus="wikibird", d_feat=768)
+    monkeypatch.setenv("SCD_ROOT", root)
+    monkeypatch.setenv("SCD_DATA", os.path.join(root, "data"))
+    monkeypatch.setattr(clip, "_tokenizer", None)
+    monkeypatch.setenv("SCD_SYNTHETIC", "1")                     # hash tokenizer for the one class name the vocabulary lacks
+    mu = importlib.import_module("main_unsup")
+    common = ["--root_dir", root, "--dataset_name", "cub", "--corpus", "wikibird", "--feat_model", "dino_vit", "--n_cluster", str(k),
+              "--topk", "3", "--num_common_vote", "10", "--num_common_linear", "2", "--run_cluster", "true",
+              "--class_names", os.path.join(root, "class_names.json")]
+    n_u = int((~mask_lab).sum())
+    assert 4300 <= n_u <= 4700
+    xu, xl, yl = xf[~mask_lab], xf[mask_lab], y[mask_lab]
+    nouns = ["noun_%03d" % i for i in range(v)]                  # load_vocabulary: lower-cased, '-' -> '_' 
+    f16, w16 = x.astype(np.float16), w.astype(np.float16)
+    oidx, _ = no.sim_topk(f16, w16, 3, "softmax")
+
+    def oracle_names(preds0):
+        tr = no.vote_loop_unsup(oidx[~mask_lab], preds0, f16[~mask_lab], w16, nouns, k, 3, 10, 2)
+        return [nouns[c] for c in tr[-1]["cand"].tolist()], tr[-1]["u_preds"], len(tr)
+
+    for compat in ("1.0.2", "1.7.2"):
+        monkeypatch.setenv("SCD_SKLEARN_COMPAT", compat)
+        cand, u_preds = mu.main(common + ["--cluster", "KM", "--save_cluster", "true"])
+        saved = torch.load(os.path.join(root, "cluster", "KM_dino_vit_cub_%d.pt" % k), weights_only=False)
+        olab, _, _, _ = ko.sklearn_kmeans(xu, k, 0, "auto", compat=compat)
+        assert saved["u_preds"].dtype == np.int32 and np.array_equal(saved["u_preds"], olab), compat
+        ocand, opreds, oit = oracle_names(olab)
+        assert list(cand) == ocand and np.array_equal(np.asarray(u_preds), opreds), compat
+        out = capsys.readouterr().out
+        assert "voting converged after %d iterations" % oit in out and "sACC_avg" in out
+        assert len(set("noun_%03d" % c for c in range(k - 1)) & set(cand)) >= 150          # the planted names are found
+    monkeypatch.delenv("SCD_SKLEARN_COMPAT")
+    # SSKM: the reference passes random_state=None (main_unsup.py:350): both sides draw from numpy's global RandomState
+    np.random.seed(7)
+    cand, u_preds = mu.main(common + ["--cluster", "SSKM", "--save_cluster", "true"])
+    saved = torch.load(os.path.join(root, "cluster", "SSKM_dino_vit_cub_%d.pt" % k), weights_only=False)
+    np.random.seed(7)
+    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=10, random_state=None)
+    okm.fit_mix(xu, xl, yl)
+    assert np.array_equal(saved["all_preds"], okm.labels_)
+    ocand, opreds, _ = oracle_names(okm.labels_[len(yl):])
+    assert list(cand) == ocand and np.array_equal(np.asarray(u_preds), opreds)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "e", "c", "c1"])
+def test_sklearn_102_seeding_matches_reference_k_init(ops, golden, tag):
+    """The default mode of scd_amd.cluster.KMeans (scikit-learn 1.0.2 rules, the reference's pin): scd_kpp_greedy_lockstep picks the
+    rows the reference-held `_k_init` picks (tests/golden/kmeans_sklearn.npz `*_kinit_*`, oracle/gen_golden.py: ten consecutive
+    seedings on RandomState(0) = the n_init = 10 stream) - on the float32 rows (dense candidate evaluation) and, for rows rounded to
+    fp16 (features that left an fp16 encoder: MFMA lower-bound filter + exact pairs), the rows the oracle picks on the same rows."""
+    from scd_amd.cluster import KMeans
+    from scd_amd import ops as o
+    g = golden("kmeans_sklearn.npz")
+    n, d, k, seed = g[tag + "_shape"].tolist()
+    x, _, _ = synth.clustered_features(n, d, k, seed=seed, center_seed=seed + 40, noise=float(g[tag + "_noise"]))
+    gold = g[tag + "_kinit_f32"]
+    km = KMeans(n_clusters=k, random_state=0)
+    assert km.sklearn_compat == "1.0.2"
+    rs = ko.check_random_state(0)
+    first, u = km._draws(rs, n, gold.shape[0])
+    assert rs.random_sample() == float(g[tag + "_kinit_f32_next"])
+    cent, picks = o.kpp_greedy_lockstep(dev(x), None, first, u, k)
+    assert np.array_equal(picks.cpu().numpy().T, gold)
+    assert np.array_equal(cent.cpu().numpy(), x[gold])
+    xh = x.astype(np.float16).astype(np.float32)
+    x16 = o.f16_exact(dev(xh))
+    assert x16 is not None
+    starts = 2 if tag in ("c", "c1") else gold.shape[0]
+    cent, picks = o.kpp_greedy_lockstep(dev(xh), x16, first[:starts], u[:starts], k)
+    rs = ko.check_random_state(0)
+    opicks = np.stack([ko.sklearn_kpp(xh, k, rs, compat="1.0.2") for _ in range(starts)])
+    assert np.array_equal(picks.cpu().numpy().T, opicks)
+    cent2, picks2 = o.kpp_greedy_lockstep(dev(xh), None, first[:starts], u[:starts], k)           # dense path, same rows
+    assert torch.equal(picks2, picks) and torch.equal(cent2, cent)
+
+
+@pytest.mark.parametrize("shape", [(3000, 64, 12, 0.9), (4500, 768, 200, 0.9), (2000, 512, 8, 1.2)])
+def test_sklearn_kmeans_c_loops_equal_python_loops(ops, monkeypatch, shape):
+    """`KMeans.fit` on fp16-exact rows takes the C loops (scd_kpp_greedy_lockstep with the filter, scd_kmeans_lloyd_run_sk with the
+    incremental M-step); labels, centres, inertia and n_iter equal the oracle's and the Python-driven loop's (SCD_LLOYD_RUN=0)."""
+    from scd_amd.cluster import KMeans
+    n, d, k, noise = shape
+    x, _, _ = synth.clustered_features(n, d, k, seed=n % 97, center_seed=d % 89, noise=noise)
+    xh = x.astype(np.float16).astype(np.float32)
+    for compat, n_init in (("1.0.2", 3), ("1.7.2", "auto")):
+        km = KMeans(n_clusters=k, random_state=0, n_init=n_init, sklearn_compat=compat).fit(xh)
+        olab, oin, ocent, oit = ko.sklearn_kmeans(xh, k, 0, n_init, compat=compat)
+        assert np.array_equal(km.labels_, olab) and km.n_iter_ == oit and np.array_equal(km.cluster_centers_, ocent)
+        assert abs(km.inertia_ - oin) <= 1e-9 * oin
+        monkeypatch.setenv("SCD_LLOYD_RUN", "0")
+        km2 = KMeans(n_clusters=k, random_state=0, n_init=n_init, sklearn_compat=compat).fit(xh)
+        monkeypatch.delenv("SCD_LLOYD_RUN")
+        assert np.array_equal(km2.labels_, km.labels_) and km2.n_iter_ == km.n_iter_ and km2.inertia_ == km.inertia_
+        assert np.array_equal(km2.cluster_centers_, km.cluster_centers_)
 
 
 def test_mains_run_on_reference_cache_files(ops, tmp_path, monkeypatch, capsys):
