@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--batch", type=int, default=3990)
     p.add_argument("--vocab", type=int, default=VOCAB)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cluster", choices=["SSKM", "KM"], default="SSKM",
+                   help="clustering stage: SSKM (semi-supervised K-Means, the north-star path; default) or KM = the flag of the shipped "
+                        "scripts/evaluate_unsupervised.sh, `KMeans(n_clusters, random_state=0).fit(u_feats)` (main_unsup.py:362)")
     a = p.parse_args()
     a.images = a.images or CONFIGS[a.config]["images"]
     a.n_cluster = a.n_cluster or CONFIGS[a.config]["n_cluster"]
@@ -277,7 +280,7 @@ def secondary_rooflines(out, wt, dev):
                 "achieved": round(fl / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(fl / t / 2.5e15, 4),
                 "call_us": round(t * 1e6, 1), "rows_through_exact_pass": fb_rows})
     x = feats.float()
-    c = out["kmeans"].cluster_centers_.to(torch.float32).contiguous()
+    c = torch.as_tensor(out["kmeans"].cluster_centers_).to(dev).to(torch.float32).contiguous()
     k = int(c.shape[0])
     data = ops.KMeansData(x)
     dp = (d + 127) // 128 * 128
@@ -331,6 +334,21 @@ def secondary_rooflines(out, wt, dev):
                     "fit_wall_ms_incl_seeding": round(wall * 1e3, 2),
                     "note": "HIP-event brackets include the dispatch latency of the bracketed launch (~5-8 us on a 30 us kernel); the "
                             "rocprofv3 kernel trace of tools/sskm_phases.py (profiles/r03_sskm_phases_kernel_stats.csv) has the kernel alone"})
+    # (iii') `--cluster KM` (the shipped script's flag): `KMeans(k, random_state=0).fit` on the clustered features' unlabelled share
+    # (95,000 rows at C2) - greedy k-means++ of the ten starts in lock-step + ten Lloyd runs in C (scd_kpp_greedy_lockstep,
+    # scd_kmeans_lloyd_run_sk); wall time of the whole fit
+    if k <= 2048:
+        from scd_amd.cluster import KMeans
+        n_km = min(n, int(n * 0.75))
+        xk = xc[:n_km].half().float().contiguous()
+        KMeans(n_clusters=k, random_state=0).fit(xk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kmf = KMeans(n_clusters=k, random_state=0).fit(xk)
+        torch.cuda.synchronize()
+        res.append({"kernel": "scd_amd.cluster.KMeans(n_clusters=%d, random_state=0).fit on %d x %d clustered fp16-exact features "
+                              "(--cluster KM, scikit-learn 1.0.2 rules: 10 starts, greedy k-means++, Lloyd to tol 1e-4)" % (k, n_km, d),
+                    "bound": "latency", "fit_wall_ms": round((time.perf_counter() - t0) * 1e3, 2), "n_iter_kept_start": int(kmf.n_iter_)})
     # (iv) one round of the lock-step k-means++ seeding (N*D*s + 8*N bytes per added centre; the ten restarts'
     # centres of a round share ONE pass over the exact fp16 copy, s = 2): scd_kpp_seed_lockstep on the clustered features, rounds with
     # 20+ centres present (distance update through the MFMA filter), HIP events around the call / rounds
@@ -417,7 +435,7 @@ def main():
     def step(i, timed):
         timers = [] if timed else None
         out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, n_cls, topk=3, num_common_vote=10,
-                           num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers)
+                           num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers, cluster=args.cluster)
         if timed:
             torch.cuda.synchronize()
             for (n0, e0), (n1, e1) in zip(timers[:-1], timers[1:]):
@@ -454,7 +472,9 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": CONFIGS[args.config]["workload"] % args.vocab,
+            "config": {"workload": (CONFIGS[args.config]["workload"] % args.vocab) if args.cluster == "SSKM" else
+                       (CONFIGS[args.config]["workload"] % args.vocab).replace("SSKM k=", "sklearn-style KMeans (--cluster KM, n_init=10) k=").replace(" (10 restarts x 10 iters)", ""),
+                       "cluster": args.cluster,
                        "images_per_gpu": args.images, "vocab": args.vocab, "n_cluster": n_cls, "encode_batch": args.batch,
                        "weights": "random-init (seeded), no checkpoint offline", "parallelism": "dp%d" % world},
             "stage_ms_per_step": {k: round(v / args.steps, 2) for k, v in stage_ms.items()},

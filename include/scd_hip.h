@@ -54,6 +54,12 @@ int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_t c, void* 
 /* out[i,:] = Wt[idx[i],:]  (the `zeroshot_weights[:, nouns.index(n)]` gather, main_unsup.py:601-602) */
 int scd_gather_rows_f16(scd_handle h, const void* Wt, const int64_t* idx, int64_t m, int d, void* out, void* stream);
 
+/* The row selections of main_unsup.py:318-321,561 (`all_feats[~mask_lab]`, `all_feats[mask_lab]`, `name_idx_top5[~mask_lab]`: numpy /
+ * torch fancy indexing in the reference) in one launch: for the m rows idx[i] of F (fp16 [n,d]) out16[i] = the row, out32[i] = its
+ * float32 image (the K-Means input), nidx_out[i] = name_idx[idx[i]] (int64 rows of k); any of the three outputs may be NULL. */
+int scd_select_rows(scd_handle h, const void* F, const int64_t* name_idx, const int64_t* idx, int64_t m, int d, int k, void* out16,
+                    float* out32, int64_t* nidx_out, void* stream);
+
 /* out = fp16((a + b) / 2) over n_elems fp16 values (n_elems % 8 == 0): the textual-enhancement feature of BASELINE configs[4],
  * `100 * (f @ W + t @ W) / 2` (commented at main_unsup.py:518,523,604,609) = 100 * mean(f, t) @ W -> scd_sim_topk on the mean. */
 int scd_mean2_f16(scd_handle h, const void* a, const void* b, int64_t n_elems, void* out, void* stream);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "scd_sim_topk": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scd_transpose_f16": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scd_gather_rows_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_select_rows": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "scd_mean2_f16": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "scd_prompt_pool": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp]),
     "scd_kmeans_prep_bytes": (_sz, [_i64, _i]),

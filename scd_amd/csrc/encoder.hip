@@ -31,9 +31,27 @@ enum { L_LN1_W = 0, L_LN1_B, L_QKV_W, L_QKV_B, L_PROJ_W, L_PROJ_B, L_LN2_W, L_LN
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // one wave per row; width % 256 == 0; lane owns 4-element groups (i*64+lane)*4
+// st1 / st2 (may be NULL): this lane's share of the STORED row's {sum, sum of squares} (the fp16 values as written, fp32 accumulation,
+// groups and elements ascending - the order of round 3's separate row_stats_kernel pass over x, whose bits these are)
+__device__ __forceinline__ void stats_acc(const half4& o, float* st1, float* st2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float f = (float)o[j];
+        *st1 += f;
+        *st2 = fmaf(f, f, *st2);
+    }
+}
+__device__ __forceinline__ void stats_store(float s1, float s2, long long* stats, long long r, int lane) {
+    s1 = wave_sum_f32(s1);
+    s2 = wave_sum_f32(s2);
+    if (lane == 0) {   // the fixed-point format of scd_gemm_ln (gemm.h)
+        stats[2 * r] = __float2ll_rn(s1 * 16777216.f);
+        stats[2 * r + 1] = __float2ll_rn(s2 * 1048576.f);
+    }
+}
 template <int MAXG>
 __device__ __forceinline__ void ln_row(const float (&v)[MAXG][4], int groups, int width, float eps, const float* g,
-                                       const float* b, half_t* out, int lane) {
+                                       const float* b, half_t* out, int lane, float* st1 = nullptr, float* st2 = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXG; ++i)
@@ -62,6 +80,7 @@ __device__ __forceinline__ void ln_row(const float (&v)[MAXG][4], int groups, in
             o[2] = (half_t)((v[i][2] - mean) * rstd * gg.z + bb.z);
             o[3] = (half_t)((v[i][3] - mean) * rstd * gg.w + bb.w);
             *(half4*)(out + c) = o;
+            if (st1) stats_acc(o, st1, st2);
         }
 }
 
@@ -116,7 +135,10 @@ __global__ void __launch_bounds__(256) im2col_kernel(const T* __restrict__ img, 
 __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __restrict__ patch, const float* __restrict__ patch_b,
                                                               const float* __restrict__ cls, const float* __restrict__ pos,
                                                               long long rows, int batch, int T, int width, const float* __restrict__ lg,
-                                                              const float* __restrict__ lb, float eps, half_t* __restrict__ out) {
+                                                              const float* __restrict__ lb, float eps, half_t* __restrict__ out,
+                                                              long long* __restrict__ stats) {
+    // stats (may be NULL): the first block's LayerNorm statistics of the rows written here (round 3 ran a
+    // kernel of its own over x for them)
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -125,8 +147,10 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
     const int groups = width >> 8;
     if (b >= batch) {   // padding rows (the row count is rounded up to the GEMM tile): zeros
         for (int c = lane * 4; c < width; c += 256) *(half4*)(out + r * width + c) = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (stats && lane < 2) stats[2 * r + lane] = 0;
         return;
     }
+    float s1 = 0.f, s2 = 0.f;
     float v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -147,7 +171,7 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
             v[i][0] = a.x + pp.x; v[i][1] = a.y + pp.y; v[i][2] = a.z + pp.z; v[i][3] = a.w + pp.w;
         }
     if (lg) {
-        ln_row<4>(v, groups, width, eps, lg, lb, out + r * width, lane);
+        ln_row<4>(v, groups, width, eps, lg, lb, out + r * width, lane, stats ? &s1 : nullptr, &s2);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -156,15 +180,18 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (half_t)v[i][j];
                 *(half4*)(out + r * width + (i * 64 + lane) * 4) = o;
+                if (stats) stats_acc(o, &s1, &s2);
             }
     }
+    if (stats) stats_store(s1, s2, stats, r, lane);
 }
 
 // text: x[b][t] = tok_emb[token] + pos[t]; eot_row[b] = b*T + argmax_t token (first maximum, like torch.argmax)
 // S = positions per row of `tokens` (77), T <= S = positions computed; the EOT position (argmax over all S) must be < T
 __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__ tokens, int batch, const half_t* __restrict__ emb,
                                                          int vocab, const float* __restrict__ pos, long long rows, int T, int S,
-                                                         int width, half_t* __restrict__ out, int* __restrict__ eot_row) {
+                                                         int width, half_t* __restrict__ out, int* __restrict__ eot_row,
+                                                         long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -173,6 +200,7 @@ __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__
     int tok = 0;
     if (b < batch) tok = tokens[b * S + t];
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 4; c < width; c += 256) {
         const half4 e4 = *(const half4*)(emb + (size_t)tok * width + c);
         const float4 pp = *(const float4*)(pos + (size_t)t * width + c);
@@ -180,7 +208,9 @@ __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__
         o[0] = (half_t)((float)e4[0] + pp.x); o[1] = (half_t)((float)e4[1] + pp.y);
         o[2] = (half_t)((float)e4[2] + pp.z); o[3] = (half_t)((float)e4[3] + pp.w);
         *(half4*)(out + r * width + c) = o;
+        if (stats) stats_acc(o, &s1, &s2);
     }
+    if (stats) stats_store(s1, s2, stats, r, lane);          // the first block's LayerNorm statistics
     if (t == 0 && lane == 0) {
         int best = 0, bt = -2147483647;
         if (b < batch) {
@@ -564,29 +594,6 @@ __global__ void __launch_bounds__(256) fold_ln_kernel(const half_t* __restrict__
     }
 }
 
-// stats[r] = {sum, sum of squares} of row r (fp16 values, fp32 accumulation, stored as 64-bit fixed point); one wave per row
-__global__ void __launch_bounds__(256) row_stats_kernel(const half_t* __restrict__ x, long long rows, int width, long long* __restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < width; c += 256) {
-        const half4 h4 = *(const half4*)(x + r * width + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float f = (float)h4[j];
-            s1 += f;
-            s2 = fmaf(f, f, s2);
-        }
-    }
-    s1 = wave_sum_f32(s1);
-    s2 = wave_sum_f32(s2);
-    if (lane == 0) {   // the fixed-point format of scd_gemm_ln (gemm.h)
-        stats[2 * r] = __float2ll_rn(s1 * 16777216.f);
-        stats[2 * r + 1] = __float2ll_rn(s2 * 1048576.f);
-    }
-}
-
 // dst[i] = x[rows[i]] and, when stats != null, dst_stats[i] = stats[rows[i]] (one wave per row)
 __global__ void __launch_bounds__(256) gather_rows_stats_kernel(const half_t* __restrict__ x, const long long* __restrict__ stats,
                                                                 const int* __restrict__ rows, int n, int width,
@@ -830,6 +837,11 @@ static int attn_xmode() {
     return x;
 }
 
+// LayerNorm folded into the QKV / fc1 GEMMs?  (then the kernel that writes the first block's input also writes its row statistics)
+static bool ln_fused(const scd_encoder* e, const EncPad& pad) {
+    static const int ln_fuse_env = getenv("SCD_LN_FUSE") ? atoi(getenv("SCD_LN_FUSE")) : 1;
+    return ln_fuse_env && !e->folded.empty() && pad.rows % 256 == 0;
+}
 static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, hipStream_t st, bool* selected_out) {
     const scd_encoder_desc& d = e->d;
     const long long rows = pad.rows;
@@ -838,16 +850,15 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
     const int causal = d.kind == 1;
     // LayerNorm folded into the GEMMs (gemm.h scd_gemm_ln): the QKV / fc1 GEMMs read the raw residual stream x and apply
     // mean / rstd in their epilogue; the row statistics come from the epilogue of the GEMM that wrote x (proj / fc2), for
-    // layer 0 from row_stats_kernel.  Two of the seven kernels of a block disappear.  SCD_LN_FUSE=0 restores the LN kernels.
-    static const int ln_fuse_env = getenv("SCD_LN_FUSE") ? atoi(getenv("SCD_LN_FUSE")) : 1;
-    const bool fuse = ln_fuse_env && !e->folded.empty() && rows % 256 == 0;
+    // layer 0 from the kernel that writes x (assemble_visual_kernel / embed_text_kernel).  Two of the seven kernels of a block disappear.  SCD_LN_FUSE=0 restores the LN kernels.
+    const bool fuse = ln_fused(e, pad);
     // Only the CLS (EOT) row of the last block's output is ever used (LN_post -> projection): after its attention the last
     // block continues on those rows alone - the output projection, LayerNorm, fc1 and fc2 of the other 196 (76) tokens of
     // every image are never computed.  Identical features (each row's arithmetic is unchanged).  SCD_LAST_SEL=0 disables it.
     static const int last_sel_env = getenv("SCD_LAST_SEL") ? atoi(getenv("SCD_LAST_SEL")) : 1;
     const bool last_sel = last_sel_env && d.mlp_dim % 256 == 0 && d.width % 256 == 0;
     *selected_out = last_sel;
-    if (fuse) row_stats_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, rows, d.width, w.stats_a);
+    // (layer 0's statistics of x were written by assemble_visual_kernel / embed_text_kernel together with x)
     for (int l = 0; l < d.layers; ++l) {
         const void* const* lw = &e->w[W_LAYER0 + l * W_PER_LAYER];
         int rc;
@@ -1013,7 +1024,7 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
     assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
                                                                          (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
                                                                          (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
-                                                                         d.ln_eps, w.x);
+                                                                         d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);
     cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 0);
     bool selected = false;
     rc = run_blocks(e, w, pad, st, &selected);
@@ -1045,7 +1056,8 @@ extern "C" int scd_clip_encode_text_len(scd_handle h, const scd_encoder* e, cons
     EncWs w = carve(d, pad, (char*)ws);
     const long long rows = pad.rows;
     embed_text_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(tokens, batch, (const half_t*)e->w[W_PATCH], d.vocab,
-                                                                    (const float*)e->w[W_POS], rows, pad.tokens, d.tokens, d.width, w.x, w.rows);
+                                                                    (const float*)e->w[W_POS], rows, pad.tokens, d.tokens, d.width, w.x, w.rows,
+                                                                    ln_fused(e, pad) ? w.stats_a : nullptr);
     cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, pad.tokens, batch, 1);
     bool selected = false;
     int rc = run_blocks(e, w, pad, st, &selected);

@@ -2051,6 +2051,47 @@ extern "C" int scd_gather_rows_f16(scd_handle h, const void* Wt, const int64_t* 
     return SCD_OK;
 }
 
+// the row selections of main_unsup.py:318-321,561 (`all_feats[~mask_lab]`, `all_feats[mask_lab]`, `name_idx_top5[~mask_lab]`) in one launch:
+// for the m rows idx[i] of F (fp16 [n, d]): out16[i] = the row (the vote loop's features), out32[i] = its float32 image (the K-Means
+// input) and nidx_out[i] = name_idx[idx[i]] (int64 [n, k]); any output may be NULL.  One wave per selected row.
+__global__ void __launch_bounds__(256) select_rows_kernel(const half_t* __restrict__ F, const long long* __restrict__ name_idx,
+                                                          const long long* __restrict__ idx, long long m, int d, int k,
+                                                          half_t* __restrict__ out16, float* __restrict__ out32, long long* __restrict__ nidx_out) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const int lane = threadIdx.x & 63;
+    const long long src = idx[row];
+    if ((d & 7) == 0) {
+        for (int j = lane * 8; j < d; j += 512) {
+            const half8 v = *(const half8*)(F + src * d + j);
+            if (out16) *(half8*)(out16 + row * d + j) = v;
+            if (out32) {
+                float4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+                *(float4*)(out32 + row * d + j) = a;
+                *(float4*)(out32 + row * d + j + 4) = b;
+            }
+        }
+    } else {
+        for (int j = lane; j < d; j += 64) {
+            const half_t v = F[src * d + j];
+            if (out16) out16[row * d + j] = v;
+            if (out32) out32[row * d + j] = (float)v;
+        }
+    }
+    if (nidx_out && lane < k) nidx_out[row * k + lane] = name_idx[src * k + lane];
+}
+extern "C" int scd_select_rows(scd_handle h, const void* F, const int64_t* name_idx, const int64_t* idx, int64_t m, int d, int k,
+                               void* out16, float* out32, int64_t* nidx_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_select_rows");
+    SCD_REQUIRE(h && F && idx && m > 0 && d > 0 && (out16 || out32 || nidx_out) && (!nidx_out || (name_idx && k > 0 && k <= 64)),
+                "scd_select_rows: bad arguments");
+    select_rows_kernel<<<(unsigned)scd_cdiv(m, 4), 256, 0, (hipStream_t)stream_>>>((const half_t*)F, (const long long*)name_idx,
+                                                                                 (const long long*)idx, m, d, k, (half_t*)out16, out32,
+                                                                                 (long long*)nidx_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
 // F.normalize(x, dim=-1): x / max(||x||, 1e-12); one wave per row, float32 math on the stored values
 template <typename T>
 __global__ void __launch_bounds__(256) l2norm_kernel(const T* __restrict__ x, long long n, int d, T* __restrict__ out) {

@@ -72,6 +72,26 @@ def gather_rows_f16(wt, idx):
     return out
 
 
+def select_rows(feats16, idx, name_idx=None, want16=True, want32=True):
+    """`all_feats[mask]` (main_unsup.py:318-321) for the rows `idx` (device int64) of the fp16 feature matrix, in one launch: returns
+    (rows fp16 or None, rows float32 or None, name_idx[idx] or None)."""
+    _need_cuda(feats16, idx)
+    assert feats16.dtype == torch.float16 and feats16.is_contiguous() and idx.dtype == torch.int64
+    m, d = idx.numel(), feats16.shape[1]
+    dev = feats16.device
+    o16 = torch.empty((m, d), dtype=torch.float16, device=dev) if want16 else None
+    o32 = torch.empty((m, d), dtype=torch.float32, device=dev) if want32 else None
+    k = 0
+    on = None
+    if name_idx is not None:
+        assert name_idx.dtype == torch.int64 and name_idx.is_contiguous()
+        k = name_idx.shape[1]
+        on = torch.empty((m, k), dtype=torch.int64, device=dev)
+    if m:
+        check(_L().scd_select_rows(handle(), ptr(feats16), ptr(name_idx), ptr(idx), m, d, k, ptr(o16), ptr(o32), ptr(on), stream_ptr()))
+    return o16, o32, on
+
+
 def mean2_f16(a, b):
     """fp16((a + b) / 2): the textual-enhancement feature (main_unsup.py:518 commented formula)."""
     _need_cuda(a, b)

@@ -1,6 +1,7 @@
 """End-to-end hot path (encode -> L2-norm -> full-vocab sim+top-k -> semi-supervised K-Means -> vote loop), i.e. the
 stage order of /root/reference/main_unsup.py:298-641 with the I/O and eval prints removed.  Used by bench.py,
-__graft_entry__.smoke() and main_unsup.py --synthetic.  Everything numeric is a libscd_hip.so call.
+__graft_entry__.smoke() and main_unsup.py --synthetic.  Everything numeric inside `run` is a libscd_hip.so call (row selections
+included: scd_select_rows); torch allocates, uploads the row numbers and carries the collectives.
 
 Multi-GPU: images (and their features) are sharded over ranks; W is replicated; K-Means exchanges one packed
 all-reduce per Lloyd iteration; the vote histograms each rank's own rows into a dense [clusters, V] table, all-reduces it
@@ -26,7 +27,7 @@ def encode_images(model, images, batch, out=None):
 
 
 def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2,
-        batch=3990, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None):
+        batch=3990, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None, cluster="SSKM"):
     """One pass over `images` (this rank's shard).  Returns dict(feats, labels, cand_names, u_preds, name_idx)."""
     def mark(name):
         if timers is not None:
@@ -38,16 +39,28 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
     mark("encode")
     name_idx, name_val = naming.full_vocab_topk(feats, None, topk, True, wt=wt)
     mark("sim_topk")
-    mask = torch.as_tensor(mask_lab, device=feats.device)
-    f32 = feats.float()
-    u_feats, l_feats = f32[~mask], f32[mask]
+    # `all_feats[~mask_lab]`, `all_feats[mask_lab]`, `name_idx[~mask_lab]` (main_unsup.py:318-321,561): the row numbers come from the
+    # host mask (two small uploads), the selections are one launch each - no torch kernel in the step
+    mask_h = np.asarray(mask_lab.cpu() if torch.is_tensor(mask_lab) else mask_lab, dtype=bool)
+    iu = torch.from_numpy(np.flatnonzero(~mask_h)).to(feats.device)
+    il = torch.from_numpy(np.flatnonzero(mask_h)).to(feats.device)
+    fu, u_feats, nidx_u = ops.select_rows(feats, iu, name_idx)
+    _, l_feats, _ = ops.select_rows(feats, il, None, want16=False)
+    if cluster == "KM":
+        # the shipped default of scripts/evaluate_unsupervised.sh: `KMeans(n_clusters, random_state=0).fit(u_feats).labels_` (:362)
+        from .cluster import KMeans
+        assert group is None, "--cluster KM is a single-process fit (as in the reference)"
+        km = KMeans(n_clusters=n_cluster, random_state=seed).fit(u_feats)
+        mark("kmeans")
+        u_preds = torch.from_numpy(km.labels_).to(feats.device)
+        cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote, num_common_linear, max_iter=50)
+        mark("vote")
+        return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace), kmeans=km)
     km = SemiSupKMeans(k=n_cluster, tolerance=1e-4, max_iterations=kmeans_iters, init='k-means++', n_init=n_init,
                        random_state=seed, n_jobs=None, pairwise_batch_size=1024, mode=None, group=group)
     km.fit_mix(u_feats, l_feats, torch.as_tensor(l_targets, device=feats.device))
     mark("kmeans")
     u_preds = km.labels_[l_feats.shape[0]:]
-    nidx_u = name_idx[~mask]
-    fu = feats[~mask]
     if group is None:
         cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote,
                                                     num_common_linear, max_iter=50)
