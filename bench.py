@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--batch", type=int, default=3990)
     p.add_argument("--vocab", type=int, default=VOCAB)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-only", action="store_true", help="print the cpu_baseline object and exit (no GPU work; how the main run obtains it)")
     p.add_argument("--cluster", choices=["SSKM", "KM"], default="SSKM",
                    help="clustering stage: SSKM (semi-supervised K-Means, the north-star path; default) or KM = the flag of the shipped "
                         "scripts/evaluate_unsupervised.sh, `KMeans(n_clusters, random_state=0).fit(u_feats)` (main_unsup.py:362)")
@@ -383,8 +384,25 @@ def secondary_rooflines(out, wt, dev):
     return res
 
 
+def cpu_baseline_child():
+    """cpu_baseline() in a child process of its own: the C restatement is a host library built elsewhere, and whatever goes wrong in
+    it (an illegal instruction, a crash in OpenMP) must not take the measured line with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True, timeout=900)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"error": "cpu baseline child exited with code %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+    except Exception as e:          # noqa: BLE001 - the baseline is reported beside the metric, never instead of it
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -483,7 +501,7 @@ def main():
             "roofline": roof,
         }
         line["secondary_rooflines"] = secondary_rooflines(out, wt, dev)
-        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_child()
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -225,6 +225,14 @@ size_t scd_kpp_seed_ws_bytes(int64_t n, int d, int R);
 int scd_kpp_seed_lockstep(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
                           const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws, size_t ws_bytes,
                           void* stream);
+/* One round's distance update of the lock-step seeding through that filter, as a call of its own: d2[r] = min(d2[r], ||x - c_new[r]||^2),
+ * r < R <= 16, c_new [R][d] float32 (rows of the global X), X16 = the exact fp16 copy of this rank's rows.  Same float32 results as
+ * scd_kmeans_min_update_multi.  For callers whose rounds cannot run behind scd_kpp_seed_lockstep: under a process group three
+ * all-gathers sit between a round's draw and its update.  ws keeps the rows' norm table between calls:
+ * first_call != 0 (re)builds it - pass it on the first update of a seeding. */
+size_t scd_kpp_update_ws_bytes(int64_t n, int d);
+int scd_kpp_update_filter(scd_handle h, const void* X16, int64_t n, int d, int R, const float* c_new, float* d2, int64_t ld,
+                          int first_call, void* ws, size_t ws_bytes, void* stream);
 /* deterministic float64 sum of a float32 vector (inertia, d2.sum()) */
 int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out, void* stream);
 

@@ -81,6 +81,9 @@ SIGNATURES = {
     # final_C, result_host, ws_e, nb_e, ws_m, nb_m, stream
     "scd_kmeans_lloyd_run_sk": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double, _vp, _vp, _vp,
                                      _vp, _sz, _vp, _sz, _vp]),
+    "scd_kpp_update_ws_bytes": (_sz, [_i64, _i]),
+    # h, X16, n, d, R, c_new, d2, ld, first_call, ws, nb, stream
+    "scd_kpp_update_filter": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "scd_sum_f32_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp]),
     "scd_sum_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "scd_vote_hist_ws_bytes": (_sz, [_i64, _i]),

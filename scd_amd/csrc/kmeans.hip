@@ -1850,6 +1850,7 @@ extern "C" int scd_sum_f32(scd_handle h, const float* x, int64_t n, double* out,
 //   kpp_pick       prefix over psum (+ *prefix_in) locates the first tile whose running sum reaches r; that tile is
 //                  scanned in index order for the first i with float32(running) >= r.
 #define KPP_TILE 4096
+#define KPP_STAGE 1024            /* per-tile sums a pick / search block stages in LDS (n <= 4.2 M rows; beyond: read from L2) */
 extern "C" size_t scd_kpp_draw_ws_bytes(int64_t n) { return scd_align(16 * (size_t)scd_cdiv(n, KPP_TILE) + 64) + 256; }
 
 __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
@@ -2223,6 +2224,15 @@ __global__ void __launch_bounds__(1024) kpp_pick_multi_kernel(const float* __res
     const float* v = d2 + (size_t)y * ld;
     const double* bsum = bsum_all + (size_t)y * nb;
     const double* psum = psum_all + (size_t)y * nb;
+    // the restart's per-tile sums into LDS first: thread 0's serial walks over them below were a chain of ~30 dependent L2 reads
+    // (11.5 us per launch at 95,000 rows, the longest of the draw's three kernels)
+    __shared__ double s_bs[KPP_STAGE], s_ps[KPP_STAGE];
+    if (nb <= KPP_STAGE) {
+        for (int b = threadIdx.x; b < nb; b += 1024) { s_bs[b] = bsum[b]; s_ps[b] = psum[b]; }
+        __syncthreads();
+        bsum = s_bs;
+        psum = s_ps;
+    }
     const float r = rarr[y];
     const float totf = kpp_total(bsum, nb, total_in ? total_in + y : nullptr);
     if (threadIdx.x == 0) {

@@ -26,6 +26,12 @@ __global__ void __launch_bounds__(1024) kg_search_kernel(const float* __restrict
     const int r = blockIdx.y, slot = r * L + blockIdx.x;
     const float* d2 = d2_all + (size_t)r * ld;
     const double* bsum = bsum_all + (size_t)r * nb;
+    __shared__ double s_bs[KPP_STAGE];                             // thread 0 walks the tile sums twice: from LDS, not as dependent L2 reads
+    if (nb <= KPP_STAGE) {
+        for (int b = threadIdx.x; b < nb; b += 1024) s_bs[b] = bsum[b];
+        __syncthreads();
+        bsum = s_bs;
+    }
     if (threadIdx.x == 0) {
         double pot = 0.0;
         for (int b = 0; b < nb; ++b) pot += bsum[b];
@@ -343,6 +349,74 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
             kg_select_kernel<<<dim3(64, R), 256, 0, st>>>(tmp, n, y.ld, potd, R, L, d2, cand, Cn, d, slot, ldc, picks_t);
         }
     }
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one filtered distance update
+// scd_kpp_update_filter: d2[r] = min(d2[r], ||x - c_new[r]||^2) for R restarts through the MFMA lower-bound filter of
+// scd_kpp_seed_lockstep (muf_filter_kernel + muf_exact_kernel) as a call of its own - the lock-step seeding under a process group
+// (scd_amd/kmeans.py kpp_lockstep: three all-gathers sit between a round's draw and its update, so the rounds cannot run behind one
+// call) gets the same update as the single-process loop instead of the float32 tile kernel.  c_new [R][d] float32: rows of the GLOBAL
+// X (any rank's shard), hence exact in fp16 like the local rows; the bound covers centres that are not.
+// block r < 16: c16[r] = fp16(c_new[r]) (zero rows beyond R), info[r] = {||c16_r||^2, ||c_r - c16_r||}
+__global__ void __launch_bounds__(256) muf_prep_rows_kernel(const float* __restrict__ Cn, int R, int d, int dp, half_t* __restrict__ c16,
+                                                            double* __restrict__ info) {
+    __shared__ double red[4][2];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s2 = 0.0, e2 = 0.0;
+    for (int j = threadIdx.x; j < dp; j += 256) {
+        const float c = (r < R && j < d) ? Cn[(size_t)r * d + j] : 0.f;
+        const half_t hc = (half_t)c;
+        c16[(size_t)r * dp + j] = hc;
+        const double hv = (double)(float)hc, e = (double)c - hv;
+        s2 = fma(hv, hv, s2);
+        e2 = fma(e, e, e2);
+    }
+    s2 = wave_sum_f64(s2);
+    e2 = wave_sum_f64(e2);
+    if (lane == 0) { red[wave][0] = s2; red[wave][1] = e2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[r * 2] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        info[r * 2 + 1] = sqrt((red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+    }
+}
+static bool muf_shape_ok(int64_t n, int d, int R) {
+    const int dp = muf_dp(d);
+    return R >= 1 && R <= 16 && d % 32 == 0 && (dp == 128 || dp == 256 || dp == 384 || dp == 512 || dp == 768) && n < (1ll << 40);
+}
+extern "C" size_t scd_kpp_update_ws_bytes(int64_t n, int d) {
+    const int g = muf_grid(muf_dp(d));
+    return scd_align(4 * (size_t)n) + scd_align(2 * 16 * (size_t)muf_dp(d)) + 256 + scd_align(4 * 1024) + scd_align(8 * (size_t)muf_cap(n, g) * g) + 256;
+}
+extern "C" int scd_kpp_update_filter(scd_handle h, const void* X16, int64_t n, int d, int R, const float* c_new, float* d2, int64_t ld,
+                                     int first_call, void* ws, size_t ws_bytes, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_update_filter");
+    SCD_REQUIRE(X16 && c_new && d2 && ws && n > 0 && ld >= n, "scd_kpp_update_filter: bad arguments");
+    SCD_REQUIRE(muf_shape_ok(n, d, R), "scd_kpp_update_filter: shape not served by the filter (R=%d d=%d): use scd_kmeans_min_update_multi", R, d);
+    SCD_REQUIRE(ws_bytes >= scd_kpp_update_ws_bytes(n, d), "scd_kpp_update_filter: workspace too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const int dp = muf_dp(d), g = muf_grid(dp);
+    const long long cap = muf_cap(n, g);
+    char* w = (char*)ws;
+    float* rn2 = (float*)w;
+    half_t* c16 = (half_t*)(w + scd_align(4 * (size_t)n));
+    double* info = (double*)((char*)c16 + scd_align(2 * 16 * (size_t)dp));
+    unsigned* counts = (unsigned*)((char*)info + 256);
+    unsigned long long* list = (unsigned long long*)((char*)counts + scd_align(4 * 1024));
+    if (first_call) muf_rown2_kernel<<<(unsigned)scd_cdiv(n, 4), 256, 0, st>>>((const half_t*)X16, n, d, rn2);   // the table lives in ws between calls
+    muf_prep_rows_kernel<<<16, 256, 0, st>>>(c_new, R, d, dp, c16, info);
+#define MUF_GO(NKS) muf_filter_kernel<NKS><<<g, 256, 0, st>>>((const half_t*)X16, rn2, c16, info, n, d, R, d2, ld, counts, list, cap)
+    switch (dp / 32) {
+        case 4: MUF_GO(4); break;
+        case 8: MUF_GO(8); break;
+        case 12: MUF_GO(12); break;
+        case 16: MUF_GO(16); break;
+        default: MUF_GO(24); break;
+    }
+#undef MUF_GO
+    muf_exact_kernel<<<g, 256, 0, st>>>((const half_t*)X16, c_new, d, d, counts, list, cap, d2, ld);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

@@ -81,6 +81,12 @@ class HipBackend:
     def kpp_seed_lockstep(self, data, x16, d2, rv, buf, m0):
         return self.ops.kpp_seed_lockstep(data.x, x16, d2, rv, buf, m0)
 
+    def update_filter(self, data, x16, restarts):
+        """The filtered distance update for Python-driven seeding rounds (process groups), or None when the shape is not served."""
+        if x16 is None or not self.ops.UpdateFilter.serves(data.n, data.d, restarts):
+            return None
+        return self.ops.UpdateFilter(x16)
+
     def transport(self, cost, size_min, size_max):
         return self.ops.transport_solve(cost, size_min, size_max)
 
@@ -260,6 +266,10 @@ class KMeansEngine:
             if pk.numel() and bool((pk < 0).any()):
                 raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
             return buf
+        # Python-driven rounds (a process group: three all-gathers sit between a round's draw and its update): with an exact fp16 copy
+        # the update still goes through the MFMA filter of the C loop (same float32 results, half the bytes, a fraction of the float64
+        # work) once a new centre wins few rows
+        filt = be.update_filter(data, x16, restarts) if (hasattr(be, "update_filter") and os.environ.get("SCD_KPP_FILTER", "1") != "0") else None
         for t in range(k - m):
             r = rv[t]
             if dd is None:
@@ -281,7 +291,10 @@ class KMeansEngine:
             rows = rows.to(torch.float32).contiguous()
             buf[:, m + t] = rows
             if t + 1 < k - m:
-                be.min_update_multi(data, rows, d2)
+                if filt is not None and m + t >= 8:
+                    filt.update(rows, d2)
+                else:
+                    be.min_update_multi(data, rows, d2)
         if picks and bool((torch.stack(picks) < 0).any()):
             raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
         return buf

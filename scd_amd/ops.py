@@ -482,6 +482,31 @@ def kpp_seed_lockstep(x, x16, d2, rv, buf, m0):
     return picks
 
 
+class UpdateFilter:
+    """The distance update of one lock-step seeding round through the MFMA filter (scd_kpp_update_filter), for seedings whose rounds
+    are driven from Python (process groups).  One object per seeding: it owns the workspace with the rows' norm table."""
+
+    def __init__(self, x16):
+        _need_cuda(x16)
+        self.x16 = x16
+        self.n, self.d = x16.shape
+        self.nb = _L().scd_kpp_update_ws_bytes(self.n, self.d)
+        self.ws = _ws(self.nb, x16.device)
+        self.first = True
+
+    @staticmethod
+    def serves(n, d, restarts):
+        dp = (d + 31) // 32 * 32
+        return 1 <= restarts <= 16 and d % 32 == 0 and dp in (128, 256, 384, 512, 768)
+
+    def update(self, c_new, d2):
+        """d2 [R, ld] = min(d2, ||x - c_new[r]||^2); c_new float32 [R, d] contiguous."""
+        assert c_new.dtype == torch.float32 and c_new.is_contiguous() and c_new.shape[1] == self.d and d2.shape[0] == c_new.shape[0]
+        check(_L().scd_kpp_update_filter(handle(), ptr(self.x16), self.n, self.d, c_new.shape[0], ptr(c_new), ptr(d2), d2.stride(0),
+                                         1 if self.first else 0, ptr(self.ws), self.nb, stream_ptr()))
+        self.first = False
+
+
 def sum_f32_multi(x):
     """float64 row sums of a float32 matrix [R, n] (deterministic order)."""
     _need_cuda(x)

@@ -361,6 +361,40 @@ def test_kpp_seed_lockstep_rounds_in_c(ops, monkeypatch, n, d, k, R, exact):
         assert int((picks < 0).sum()) == 0
 
 
+@pytest.mark.parametrize("n,d,R", [(5000, 512, 10), (3001, 768, 4), (2600, 128, 16), (4096, 256, 1)])
+def test_kpp_update_filter_equals_tile_kernel(ops, monkeypatch, n, d, R):
+    """scd_kpp_update_filter (one seeding round's distance update through the MFMA filter, the call the Python-driven rounds of a
+    process group use) leaves the float32 bits of scd_kmeans_min_update_multi, round after round, also for a centre that is NOT a
+    row of X (not exact in fp16); and KMeansEngine.kpp_lockstep driven from Python (SCD_KPP_SEED_RUN=0, filter updates from the
+    eighth centre on) returns the centres of the C loop (sskm_constrained.py:28-44 per restart)."""
+    x, _, _ = synth.clustered_features(n, d, 12, seed=n + d, noise=0.7)
+    xt = dev(x.astype(np.float16).astype(np.float32))
+    x16 = ops.f16_exact(xt)
+    assert ops.UpdateFilter.serves(n, d, R)
+    uf = ops.UpdateFilter(x16)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    d2a = torch.full((R, n), float("inf"), dtype=torch.float32, device="cuda")
+    ops.min_update_multi(xt, xt[torch.randint(0, n, (R,), device="cuda", generator=g)].contiguous(), d2a)
+    d2b = d2a.clone()
+    for t in range(12):
+        rows = xt[torch.randint(0, n, (R,), device="cuda", generator=g)].contiguous()
+        if t == 5:
+            rows = (rows + 1e-3 * torch.randn(rows.shape, device="cuda", generator=g)).contiguous()
+        ops.min_update_multi(xt, rows, d2a)
+        uf.update(rows, d2b)
+        assert torch.equal(d2a, d2b), t
+    if R != 10:
+        return
+    from scd_amd.kmeans import KMeansEngine
+    res = []
+    for run in ("1", "0"):
+        monkeypatch.setenv("SCD_KPP_SEED_RUN", run)
+        eng = KMeansEngine(k=24, n_init=R, random_state=0)
+        data = eng._be().prepare(xt)
+        res.append(eng.kpp_lockstep(data, None, 24, np.random.RandomState(3), R, x16=x16))
+    assert torch.equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("mixed", [False, True])
 def test_kpp_lockstep_equals_sequential_restarts_gpu(ops, monkeypatch, mixed):
     """KMeansEngine on the device: seedings of the n_init restarts drawn in lock-step == one kpp per restart (sskm.py:190-204)."""
