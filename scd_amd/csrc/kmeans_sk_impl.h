@@ -9,8 +9,8 @@
 //
 // Greedy seeding, one round (centre t of every start r < R): L = 2 + int(ln k) candidates per start by searchsorted on the cumulative
 // closest distances; the candidate with the smallest new potential sum_i min(d2[r][i], ||x_i - x_cand||^2) is kept.  With the exact fp16
-// copy of X the M = R * L candidates of a round go through the MFMA lower-bound filter of the lock-step seeding (muf_filter_kernel, 16
-// candidates per pass over X): for most rows the bound proves min(d2, dist) = d2, the (row, candidate) pairs it cannot rule out get the
+// copy of X the M = R * L candidates of a round go through the MFMA lower-bound filter of the lock-step seeding (muf_filter_kernel, 64
+// candidates per pass over X: four blocks of one XCD hold 16 candidates each and walk the same row tiles together): for most rows the bound proves min(d2, dist) = d2, the (row, candidate) pairs it cannot rule out get the
 // exact float32(float64 sum) distance, and a candidate's potential is sum(d2) + sum over its listed pairs of (min(d2, dist) - d2): the
 // same float32 values summed in float64 as a dense evaluation would.  The winner's listed values are then written into d2.  Without the
 // copy (float32 features that do not survive the fp16 round trip) and in the first rounds (a candidate improves most rows) the
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(1024) kg_search_kernel(const float* __restrict
     if (threadIdx.x == 0) idx_out[slot] = (best == 0x7fffffffffffffffll) ? n - 1 : best;
 }
 
-// block m < Mp (Mp = M rounded up to 16): Cn[m] = X[cand[m]] (float32), c16[m] = its fp16 image (zero rows beyond M, zero columns
+// block m < Mp (Mp = M rounded up to 64): Cn[m] = X[cand[m]] (float32), c16[m] = its fp16 image (zero rows beyond M, zero columns
 // beyond d), info[m] = {||c16||^2, ||c - c16||}; block 0 also clears the potentials of the round
 __global__ void __launch_bounds__(256) kg_prep_kernel(const float* __restrict__ X, const long long* __restrict__ cand, int M, int d, int dp,
                                                       float* __restrict__ Cn, half_t* __restrict__ c16, double* __restrict__ info,
@@ -227,17 +227,13 @@ __global__ void __launch_bounds__(256) kg_select_kernel(const float* __restrict_
         for (int j = threadIdx.x; j < d; j += 256) C_slot[(size_t)r * ldc + j] = Cn[(size_t)m * d + j];
     }
 }
-// out[blockIdx.x * stride] = float64 sum of row blockIdx.x of x (the arithmetic of sum_multi_kernel)
-__global__ void __launch_bounds__(1024) kg_potential_kernel(const float* __restrict__ x, long long n, long long ld, double* __restrict__ out, int stride) {
-    __shared__ double sh[32];
-    const float* v = x + (size_t)blockIdx.x * ld;
-    const long long seg = scd_cdiv_dev(n, 1024);
-    const long long a = threadIdx.x * seg, b = (a + seg < n) ? a + seg : n;
-    double s = 0.0;
-    for (long long i = a; i < b; ++i) s += (double)v[i];
-    double tot;
-    block_scan_excl_1024(s, sh, &tot);
-    if (threadIdx.x == 0) out[(size_t)blockIdx.x * stride] = tot;
+// out[r * stride] = sum_b bsum[r][b], tiles in index order (thread r < R)
+__global__ void kg_tiles_pot_kernel(const double* __restrict__ bsum, int nb, int R, double* __restrict__ out, int stride) {
+    const int r = threadIdx.x;
+    if (r >= R) return;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += bsum[(size_t)r * nb + b];
+    out[(size_t)r * stride] = t;
 }
 __global__ void __launch_bounds__(256) kg_fill_kernel(float* __restrict__ p, long long n_elems, float v) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (long long)gridDim.x * 256) p[i] = v;
@@ -254,9 +250,9 @@ static KgLayout kg_layout(int64_t n, int d, int R, int L, bool filt) {
     y.ld = (n + 63) / 64 * 64;
     y.dp = muf_dp(d);
     y.g = muf_grid(y.dp);
-    y.cap = muf_cap(n, y.g);
-    y.nbat = (M + 15) / 16;
-    y.Mp = y.nbat * 16;
+    y.cap = scd_cdiv(scd_cdiv(n, 16), y.g) * 1024;       // a block's row tiles (its four waves': ceil(tiles / g) each) x 16 rows x 16 candidates
+    y.nbat = (M + 63) / 64;                               // passes over X: 64 candidates each (four groups of 16, one per wave)
+    y.Mp = y.nbat * 64;
     y.nb = (int)scd_cdiv(n, KPP_TILE);
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += scd_align(bytes); return at; };
@@ -324,8 +320,8 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
         if (use_filter) {
             for (int b = 0; b < y.nbat; ++b) {
 #define KG_GO(NKS)                                                                                                        \
-    muf_filter_kernel<NKS><<<y.g, 256, 0, st>>>((const half_t*)X16, rn2, c16 + (size_t)b * 16 * y.dp, info + b * 32, n, d, M, d2, y.ld, \
-                                                counts + (size_t)b * y.g, list + (size_t)b * y.g * y.cap, y.cap, b * 16, L)
+    muf_filter_kernel<NKS, 4><<<dim3(y.g / 4, 4), 256, 0, st>>>((const half_t*)X16, rn2, c16 + (size_t)b * 64 * y.dp, info + b * 128, n, d, M, d2, y.ld, \
+                                                   counts + (size_t)b * y.g, list + (size_t)b * y.g * y.cap, y.cap, b * 64, L)
                 switch (y.dp / 32) {
                     case 4: KG_GO(4); break;
                     case 8: KG_GO(8); break;
@@ -344,8 +340,12 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
                 float* tl = tmp + (size_t)l * R * y.ld;
                 minupd_all(X, Cn + (size_t)l * d, n, d, R, tl, y.ld, (long long)L * d, st);
             }
-            // potentials: potd[r * L + l] = float64 sum of tmp[l][r] - one launch per trial, written with stride L
-            for (int l = 0; l < L; ++l) kg_potential_kernel<<<R, 1024, 0, st>>>(tmp + (size_t)l * R * y.ld, n, y.ld, potd + l, L);
+            // potentials: potd[r * L + l] = float64 sum of tmp[l][r]: per-tile sums over the whole chip, then the tiles in order
+            // (one 1024-thread block per row took 108 us per trial at 95,000 rows)
+            for (int l = 0; l < L; ++l) {
+                kpp_tile_sum_multi_kernel<<<dim3(y.nb, R), 1024, 0, st>>>(tmp + (size_t)l * R * y.ld, n, y.ld, bsum, y.nb);
+                kg_tiles_pot_kernel<<<1, 64, 0, st>>>(bsum, y.nb, R, potd + l, L);
+            }
             kg_select_kernel<<<dim3(64, R), 256, 0, st>>>(tmp, n, y.ld, potd, R, L, d2, cand, Cn, d, slot, ldc, picks_t);
         }
     }

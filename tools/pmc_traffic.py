@@ -3,7 +3,8 @@
 usage: python tools/pmc_traffic.py FETCH_DIR WRITE_DIR M N K OUT.json
 Full-size launches are those within 10% of the largest counter value of the kernel (the last, partial batch is dropped).
 FETCH_SIZE is doubled (gfx950: 128-byte requests tallied at 64 B, MI355X guide); the doubling is checked in the same run on
-row_stats_kernel, whose read is exactly rows*width*2 bytes (it writes 8 bytes per row).
+im2col_kernel, a pure copy: it reads batch*3*224*224*2 bytes of fp16 pixels and writes M*768*2 bytes of patch rows (round 2 / 3
+calibrated on row_stats_kernel, which round 4 folded into the kernel that writes x).
 """
 import csv, glob, json, sys
 
@@ -23,18 +24,20 @@ def full(vals):
 fd, wd, M, N, K, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 fc1 = [k for k in fetch if "gemm_w4_kernel" in k and "Li1ELb1ELb0ELi1" in k]   # QuickGELU, bias, no residual, LN-folded
-ln = [k for k in fetch if "row_stats_kernel" in k]   # calibration kernel: reads rows*width*2 bytes exactly, writes 8 bytes per row
+ln = [k for k in fetch if "im2col_kernel" in k]      # calibration kernel: a copy of known size
 assert fc1 and ln, (list(fetch)[:5])
 nf, f_kb = full(fetch[fc1[0]]); nw, w_kb = full(write[fc1[0]])
 nlf, lf_kb = full(fetch[ln[0]]); nlw, lw_kb = full(write[ln[0]])
-ln_bytes = M * 768 * 2
+BATCH = int(sys.argv[7]) if len(sys.argv) > 7 else M // 197          # images per launch
+ln_bytes = BATCH * 3 * 224 * 224 * 2
+ln_wbytes = (M // 197 * 196 + 255) // 256 * 256 * 768 * 2
 res = {
     "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded> (ViT fc1) m=%d n=%d k=%d" % (M, N, K),
-    "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 1 --warmup 0 --images 2660 --no-cpu-baseline (two separate passes)",
+    "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 1 --warmup 0 --images 7980 --no-cpu-baseline (two separate passes)",
     "raw": {"FETCH_SIZE": {"full_launches": nf, "avg_kb": f_kb}, "WRITE_SIZE": {"full_launches": nw, "avg_kb": w_kb},
-            "row_stats_FETCH_SIZE": {"full_launches": nlf, "avg_kb": lf_kb}, "row_stats_WRITE_SIZE": {"full_launches": nlw, "avg_kb": lw_kb}},
-    "correction": "FETCH_SIZE x2; same-run calibration on row_stats_kernel: raw fetch %.1f MB for a %.1f MB streaming read (ratio %.3f); WRITE_SIZE %.2f MB for its %.2f MB of row sums"
-                  % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, M * 8 / 1e6),
+            "im2col_FETCH_SIZE": {"full_launches": nlf, "avg_kb": lf_kb}, "im2col_WRITE_SIZE": {"full_launches": nlw, "avg_kb": lw_kb}},
+    "correction": "FETCH_SIZE x2; same-run calibration on im2col_kernel (a copy): raw fetch %.1f MB for a %.1f MB streaming read (ratio %.3f); WRITE_SIZE %.1f MB for its %.1f MB of patch rows"
+                  % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, ln_wbytes / 1e6),
     "fetch_bytes_per_launch": 2 * f_kb * 1024,
     "write_bytes_per_launch": w_kb * 1024,
     "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
