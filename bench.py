@@ -234,12 +234,12 @@ def dominant_kernel_roofline(ms, launches, flop):
     2*M*N*K per launch (M = 197 * batch padded to 256 images)."""
     sec = ms / 1e3
     tf = flop / max(sec, 1e-12) / 1e12
-    # HBM-side traffic per launch cannot be read without the profiler: it is taken from the committed PMC passes
-    # (profiles/r02_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script)
+    # HBM-side traffic per launch cannot be read without the profiler: it is taken from this round's committed PMC passes
+    # (profiles/r04_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/gpu_r04_profiles.sh)
     # at the default launch size (3,990 images = 786,432 rows); another --batch scales it by its rows per launch
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_fc1.json")) as f:
             pm = json.load(f)
         rows_per_launch = flop / max(launches, 1) / (2.0 * 3072 * 768)
         traffic = round(pm["traffic_bytes_per_launch"] * rows_per_launch / pm["rows"])

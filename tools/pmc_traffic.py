@@ -24,20 +24,28 @@ def full(vals):
 fd, wd, M, N, K, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 fc1 = [k for k in fetch if "gemm_w4_kernel" in k and "Li1ELb1ELb0ELi1" in k]   # QuickGELU, bias, no residual, LN-folded
-ln = [k for k in fetch if "im2col_kernel" in k]      # calibration kernel: a copy of known size
+ln = [k for k in fetch if "im2col_kernel" in k]      # a copy of known size, but its reads are 32-byte pieces of image rows (<= 64-B requests)
+av = [k for k in fetch if "assemble_visual_kernel" in k]   # reads the patch rows as whole 512-B wave loads (128-B requests), writes x
 assert fc1 and ln, (list(fetch)[:5])
 nf, f_kb = full(fetch[fc1[0]]); nw, w_kb = full(write[fc1[0]])
 nlf, lf_kb = full(fetch[ln[0]]); nlw, lw_kb = full(write[ln[0]])
 BATCH = int(sys.argv[7]) if len(sys.argv) > 7 else M // 197          # images per launch
 ln_bytes = BATCH * 3 * 224 * 224 * 2
 ln_wbytes = (M // 197 * 196 + 255) // 256 * 256 * 768 * 2
+cal128 = None
+if av:
+    naf, af_kb = full(fetch[av[0]]); naw, aw_kb = full(write[av[0]])
+    rows_p = BATCH * 196
+    cal128 = {"kernel": "assemble_visual_kernel", "raw_fetch_mb": af_kb * 1024 / 1e6, "expected_read_mb": rows_p * 768 * 2 / 1e6,
+              "ratio_raw_over_expected": af_kb * 1024 / (rows_p * 768 * 2), "write_mb": aw_kb * 1024 / 1e6, "expected_write_mb": M * 768 * 2 / 1e6}
 res = {
     "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded> (ViT fc1) m=%d n=%d k=%d" % (M, N, K),
     "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 1 --warmup 0 --images 7980 --no-cpu-baseline (two separate passes)",
     "raw": {"FETCH_SIZE": {"full_launches": nf, "avg_kb": f_kb}, "WRITE_SIZE": {"full_launches": nw, "avg_kb": w_kb},
             "im2col_FETCH_SIZE": {"full_launches": nlf, "avg_kb": lf_kb}, "im2col_WRITE_SIZE": {"full_launches": nlw, "avg_kb": lw_kb}},
-    "correction": "FETCH_SIZE x2; same-run calibration on im2col_kernel (a copy): raw fetch %.1f MB for a %.1f MB streaming read (ratio %.3f); WRITE_SIZE %.1f MB for its %.1f MB of patch rows"
+    "correction": "FETCH_SIZE x2 for kernels whose loads are 128-byte requests (gfx950 tallies them at 64 B: the guide's correction; same-run check on assemble_visual_kernel below: ratio ~0.5) - the GEMM's LDS-DMA ring fills are whole 128-byte lines; im2col_kernel in the same run, whose reads are 32-byte pieces (<= 64-B requests), is tallied at face value: raw fetch %.1f MB for a %.1f MB read (ratio %.3f); WRITE_SIZE needs no correction: %.1f MB for its %.1f MB of patch rows"
                   % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, ln_wbytes / 1e6),
+    "calibration_128B_requests": cal128,
     "fetch_bytes_per_launch": 2 * f_kb * 1024,
     "write_bytes_per_launch": w_kb * 1024,
     "traffic_bytes_per_launch": 2 * f_kb * 1024 + w_kb * 1024,
