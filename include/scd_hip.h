@@ -117,6 +117,10 @@ int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const 
  * as features that left an fp16 encoder are - the float64 sums are then bit-identical.  scd_f16_exact writes the copy
  * (n_elems % 4 == 0) and counts the waves that saw a value that does not survive the round trip (*inexact_out == 0: exact). */
 int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream);
+/* The same, also returning max |x| (device float; +inf when a value is infinite).  The incremental M-step's "exact sums" argument
+ * (scd_kmeans_lloyd_step_delta) needs rows * max|x| * 2^24 < 2^53 on top of the exact copy: unit-scale features satisfy it by orders
+ * of magnitude, fp16 values near 65504 in clusters of 2^13 rows do not - the caller checks n * max|x| < 2^29. */
+int scd_f16_exact_max(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, float* absmax_out, void* stream);
 int scd_kmeans_mstep_f16(scd_handle h, const void* X16, const int32_t* labels, const float* C_old, int64_t n, int d, int k,
                          int64_t split, double* sums, int64_t* counts, double* inertia, void* ws, size_t ws_bytes,
                          void* stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "scd_kmeans_mstep_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kmeans_mstep": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scd_f16_exact": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "scd_f16_exact_max": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "scd_kmeans_mstep_f16": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "scd_kmeans_finalize": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i64, _vp]),
     "scd_labels_changed": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -201,13 +201,15 @@ extern "C" int scd_vote_table(scd_handle h, const int64_t* name_idx, int64_t n, 
                               const int32_t* slot_of, int n_slots, int64_t row_offset, int64_t v, int n_clusters, int32_t* counts,
                               int64_t* first, void* stream_) {
     SCD_DEVICE_ENTRY(h, "scd_vote_table");
-    SCD_REQUIRE(name_idx && preds && slot_of && counts && first, "scd_vote_table: null argument");
-    SCD_REQUIRE(n > 0 && top_k > 0 && top_k <= ld && v > 0 && n_clusters > 0 && n_slots > 0, "scd_vote_table: bad shape");
+    // n == 0 (a rank whose shard holds no unlabelled row): empty tables - the caller's all-reduce must still find this rank
+    SCD_REQUIRE(counts && first && slot_of && (n == 0 || (name_idx && preds)), "scd_vote_table: null argument");
+    SCD_REQUIRE(n >= 0 && top_k > 0 && top_k <= ld && v > 0 && n_clusters > 0 && n_slots > 0, "scd_vote_table: bad shape");
     SCD_REQUIRE((row_offset + n) * top_k < (1ll << 40), "scd_vote_table: global rows x top_k must be < 2^40");
     hipStream_t st = (hipStream_t)stream_;
     SCD_HIP(hipMemsetAsync(counts, 0, (size_t)n_clusters * v * 4, st));
     SCD_HIP(hipMemsetAsync(first, 0x7F, (size_t)n_clusters * v * 8, st));          // "never seen" = 0x7f7f...: above every position, also as a SIGNED int64 (MIN all-reduce)
-    vote_table_kernel<<<(unsigned)scd_cdiv(n * top_k, 256), 256, 0, st>>>((const long long*)name_idx, n, ld, top_k, (const long long*)preds, slot_of,
+    if (n > 0)
+        vote_table_kernel<<<(unsigned)scd_cdiv(n * top_k, 256), 256, 0, st>>>((const long long*)name_idx, n, ld, top_k, (const long long*)preds, slot_of,
                                                                            n_slots, row_offset, v, counts, (unsigned long long*)first);
     SCD_LAUNCH_CHECK();
     return SCD_OK;

@@ -220,9 +220,15 @@ def f16_exact(x):
     if x.numel() % 4 or x.shape[-1] % 2:
         return None
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    bad = torch.empty(1, dtype=torch.int32, device=x.device)
-    check(_L().scd_f16_exact(handle(), ptr(x), x.numel(), ptr(out), ptr(bad), stream_ptr()))
-    return out if int(bad.item()) == 0 else None
+    res = torch.empty(2, dtype=torch.int32, device=x.device)                  # [inexact waves | max |x| as float bits]
+    check(_L().scd_f16_exact_max(handle(), ptr(x), x.numel(), ptr(out), ptr(res), res.data_ptr() + 4, stream_ptr()))
+    host = res.cpu()
+    if int(host[0]) != 0:
+        return None
+    # max |x| rides along on the copy: the incremental M-step's exact-sums argument needs rows * max|x| < 2^29 as well
+    # (LloydBuffers.inc); a plain attribute of the tensor object, not of its storage
+    out.scd_absmax = float(host[1:].view(torch.float32)[0])
+    return out
 
 
 def kmeans_mstep(x, labels32, c_old, k, split=0, x16=None):
@@ -266,7 +272,10 @@ class LloydBuffers:
         self.ws_e = data_u.ws(("e", k), self.nb_e)
         self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)
         self.ws_m = _ws(self.nb_m, dev)
-        self.inc = cat16 is not None and k <= 8192 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0"
+        # incremental exact M-step: every float64 cluster sum must be exact, i.e. rows * max|x| * 2^24 < 2^53 on top of the exact fp16
+        # copy (unit-scale features: 1e5 * 1 against 5e8; fp16 values near 65504 in big clusters, or infinities, take the fresh M-step)
+        amax = getattr(cat16, "scd_absmax", float("inf")) if cat16 is not None else float("inf")
+        self.inc = (cat16 is not None and k <= 8192 and n_cat * amax < 2.0 ** 29 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0")
         if self.inc:
             self.lab_prev = torch.full((n_cat,), -1, dtype=torch.int32, device=dev)
             self.sumsq = torch.empty(4, dtype=torch.float64, device=dev)
@@ -556,8 +565,8 @@ def vote_table(name_idx, top_k, preds, clusters, n_slots, row_offset, v):
     slot = slot.to(dev)
     counts = torch.empty((nc, v), dtype=torch.int32, device=dev)
     first = torch.empty((nc, v), dtype=torch.int64, device=dev)
-    n, ld = name_idx.shape
-    check(_L().scd_vote_table(handle(), ptr(name_idx), n, ld, top_k, ptr(preds), ptr(slot), n_slots, int(row_offset), int(v), nc,
+    n, ld = name_idx.shape                  # n == 0 (a shard without unlabelled rows) gives empty tables
+    check(_L().scd_vote_table(handle(), ptr(name_idx), n, max(ld, top_k), top_k, ptr(preds), ptr(slot), n_slots, int(row_offset), int(v), nc,
                               ptr(counts), ptr(first), stream_ptr()))
     return counts, first
 

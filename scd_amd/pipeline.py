@@ -109,10 +109,11 @@ def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, n
         counts, firsts = be.vote_table(name_idx, top_k, u_preds, clusters, n_slots, row_offset, v)
         dist.all_reduce(counts, group=group)
         dist.all_reduce(firsts, op=dist.ReduceOp.MIN, group=group)
-        keys, cnts = be.vote_table_topm(counts, firsts, m)
-        # rank 0: names voted on, assignment (Munkres); broadcast [n_voted | voted | ind (pairs)]
+        # rank 0: most_common(m) per cluster off the reduced tables, names voted on, assignment (Munkres); broadcast
+        # [n_voted | voted | ind (pairs)].  (Only rank 0 consumes the top-m lists, so only rank 0 extracts them.)
         nc = len(clusters)
         if rank == 0:
+            keys, cnts = be.vote_table_topm(counts, firsts, m)
             keys_h, cnts_h = keys.cpu().numpy(), cnts.cpu().numpy()
             c2c = {c: naming.TopCounter(keys_h[i], cnts_h[i]) for i, c in enumerate(clusters)}
             voted = []

@@ -361,6 +361,32 @@ def test_kpp_seed_lockstep_rounds_in_c(ops, monkeypatch, n, d, k, R, exact):
         assert int((picks < 0).sum()) == 0
 
 
+def test_incremental_mstep_needs_exact_sums(ops):
+    """The incremental M-step (scd_kmeans_lloyd_step_delta) is offered only where every float64 cluster sum is exact: an exact fp16
+    copy AND rows * max|x| < 2^29 (scd_f16_exact_max).  Unit-scale features qualify; fp16-exact values of magnitude 32,768 over
+    20,000 rows, or an infinity, take the fresh M-step - and the fit still equals the oracle's."""
+    from scd_amd.kmeans import KMeansEngine
+    x, _, _ = synth.clustered_features(20000, 64, 6, seed=3, noise=0.8)
+    xh = dev(x.astype(np.float16).astype(np.float32))
+    x16 = ops.f16_exact(xh)
+    assert x16 is not None and 0.0 < x16.scd_absmax <= 1.0
+    assert ops.LloydBuffers(ops.KMeansData(xh), xh, x16, 6).inc
+    big = np.round(x * 3.0) * 16384.0                                   # multiples of 2^14 up to 32,768 (49,152): exact in fp16
+    xb = dev(big.astype(np.float32))
+    b16 = ops.f16_exact(xb)
+    assert b16 is not None and b16.scd_absmax * 20000 >= 2.0 ** 29
+    assert not ops.LloydBuffers(ops.KMeansData(xb), xb, b16, 6).inc
+    xi = xb.clone()
+    xi[5, 7] = float("inf")
+    i16 = ops.f16_exact(xi)
+    assert i16 is not None and i16.scd_absmax == float("inf") and not ops.LloydBuffers(ops.KMeansData(xi), xi, i16, 6).inc
+    eng = KMeansEngine(k=6, max_iterations=10, n_init=2, random_state=0)
+    eng.fit(xb)
+    okm = ko.K_Means(k=6, max_iterations=10, n_init=2, random_state=0)
+    okm.fit(big.astype(np.float32))
+    assert np.array_equal(eng.labels_.cpu().numpy(), okm.labels_) and np.array_equal(eng.cluster_centers_.cpu().numpy(), okm.cluster_centers_)
+
+
 @pytest.mark.parametrize("n,d,R", [(5000, 512, 10), (3001, 768, 4), (2600, 128, 16), (4096, 256, 1)])
 def test_kpp_update_filter_equals_tile_kernel(ops, monkeypatch, n, d, R):
     """scd_kpp_update_filter (one seeding round's distance update through the MFMA filter, the call the Python-driven rounds of a
