@@ -1219,7 +1219,8 @@ def test_zero_shot_bounds_and_cidx_names(ops):
     assert np.array_equal(preds, lg.argmax(1))
 
 
-def _write_cache_tree(root, n=1600, k=8, v=500, seed=51, dataset="cifar10", corpus="wordnet", d_feat=512, noise=0.9, layers=1):
+def _write_cache_tree(root, n=1600, k=8, v=500, seed=51, dataset="cifar10", corpus="wordnet", d_feat=512, noise=0.9, layers=1,
+                      feat_model="dino_vit"):
     """The reference's on-disk boundary: feature dicts (main_unsup.py:141-146), the [512, V] classifier
     (:389-394), the vocabulary file get_nouns reads (clip_lang_util.py:139-149), a class-name table and a CLIP checkpoint."""
     import json
@@ -1234,13 +1235,14 @@ def _write_cache_tree(root, n=1600, k=8, v=500, seed=51, dataset="cifar10", corp
         xf = xf[perm]
     w = synth.vocabulary(v, 512, cent, seed=seed + 3, jitter=0.4)
     nouns = ["noun-%03d" % i for i in range(v)]                   # get_nouns output is lower-cased and '-' -> '_' by the mains
-    zname, vfile = {"wordnet": ("nouns", "wordnet_all_noun.txt"), "wikibird": ("wikibird", "wiki_birdclass_names.txt")}[corpus]
+    zname, vfile = {"wordnet": ("nouns", "wordnet_all_noun.txt"), "wikibird": ("wikibird", "wiki_birdclass_names.txt"),
+                    "wikidog": ("wikidog", "wiki_dogclass_names.txt")}[corpus]
     os.makedirs(os.path.join(root, "extracted_features"))
     os.makedirs(os.path.join(root, "zeroshot_weights"))
     os.makedirs(os.path.join(root, "data"))
     os.makedirs(os.path.join(root, "clip"))
     feats = dict(all_feats=xf.astype(np.float32), mask_lab=mask_lab, mask_cls=(y < k // 2), targets=y.astype(np.float64))
-    torch.save(feats, os.path.join(root, "extracted_features", "dino_vit_%s_all.pt" % dataset))
+    torch.save(feats, os.path.join(root, "extracted_features", "%s_%s_all.pt" % (feat_model, dataset)))
     torch.save(dict(feats, all_feats=x.astype(np.float16)), os.path.join(root, "extracted_features", "clip_%s_all.pt" % dataset))
     torch.save(torch.from_numpy(w), os.path.join(root, "zeroshot_weights", "zeroshot_weights_all_%s_vit_b_16.pt" % zname))
     with open(os.path.join(root, "data", vfile), "w") as f:
@@ -1310,6 +1312,54 @@ def test_c1_shape_end_to_end(ops, tmp_path, monkeypatch, capsys):
     assert np.array_equal(saved["all_preds"], okm.labels_)
     ocand, opreds, _ = oracle_names(okm.labels_[len(yl):])
     assert list(cand) == ocand and np.array_equal(np.asarray(u_preds), opreds)
+
+
+def test_c3_shape_ptsup_end_to_end(ops, tmp_path, monkeypatch, capsys):
+    """BASELINE configs[2] at its own shape, through main_ptsup.main() on the reference's cache files: Stanford Dogs partially
+    supervised - 12,000 images of which ~3,000 labelled (classes < 60, half of their rows), cached 768-wide float32 GCD features, K =
+    120, the flags main_unsup.py:222-224 name for sdogs (--topk 2 --num_common_vote 5 --num_common_linear 2), the dog-name corpus.
+    `--cluster SSKM`: all_preds, the top-5 indices, every iteration of the partially supervised vote (names of the labelled classes
+    kept, the rest voted) and the final names / u_preds equal the oracle chain on the same files (main_ptsup.py:526-545, 588-676);
+    the class name the vocabulary lacks goes through the greedy top-5 matching of the sdogs branch (:459-469)."""
+    import importlib
+    import scd_amd.clip as clip
+    from scd_amd import naming
+    root = str(tmp_path)
+    n, k, v = 12000, 120, 1000
+    x, y, mask_lab, w, xf = _write_cache_tree(root, n=n, k=k, v=v, seed=71, dataset="sdogs", corpus="wikidog", d_feat=768, feat_model="gcd")
+    monkeypatch.setenv("SCD_ROOT", root)
+    monkeypatch.setenv("SCD_DATA", os.path.join(root, "data"))
+    monkeypatch.setattr(clip, "_tokenizer", None)
+    monkeypatch.setenv("SCD_SYNTHETIC", "1")
+    mp_ = importlib.import_module("main_ptsup")
+    assert 2700 <= int(mask_lab.sum()) <= 3300 and mask_lab[: int(mask_lab.sum())].all()          # labelled rows first
+    np.random.seed(11)                                  # random_state=None at the call site (main_ptsup.py:369): numpy's global stream
+    cand, u_preds = mp_.main(["--root_dir", root, "--dataset_name", "sdogs", "--corpus", "wikidog", "--feat_model", "gcd", "--n_cluster", str(k),
+                              "--cluster", "SSKM", "--topk", "2", "--num_common_vote", "5", "--num_common_linear", "2", "--run_cluster", "true",
+                              "--save_cluster", "true", "--class_names", os.path.join(root, "class_names.json")])
+    out = capsys.readouterr().out
+    assert "sACC lower bound" in out and "sACC upper bound" in out and "Missed 1 names" in out
+    saved = torch.load(os.path.join(root, "cluster", "SSKM_gcd_sdogs.pt"), weights_only=False)
+    np.random.seed(11)
+    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=10, random_state=None)
+    okm.fit_mix(xf[~mask_lab], xf[mask_lab], y[mask_lab])
+    assert np.array_equal(saved["all_preds"], okm.labels_)
+    nouns = ["noun_%03d" % i for i in range(v)]
+    f16, w16 = x.astype(np.float16), w.astype(np.float16)
+    oidx, _ = no.sim_topk(f16, w16, 5, "raw")
+    # the labelled classes' names as main_ptsup derives them (class k - 1 carries a name outside the vocabulary: matched by the text tower)
+    model, _ = clip.load("ViT-B/16")
+    import json
+    with open(os.path.join(root, "class_names.json")) as fh:
+        class_to_idx = {kk: int(vv) for kk, vv in json.load(fh).items()}
+    wt = ops.transpose_f16(dev(w16))
+    cname = naming.resolve_class_names("sdogs", "wikidog", class_to_idx, nouns, wt, model.cuda().eval())
+    lab_names = [cname[c] for c in range(k // 2)]
+    assert lab_names == ["noun_%03d" % c for c in range(k // 2)]
+    otr = no.vote_loop_ptsup(oidx[~mask_lab], okm.labels_, mask_lab, f16[~mask_lab], w16, nouns, lab_names, k, 2, 5, 2)
+    assert "voting converged after %d iterations" % len(otr) in out
+    assert list(cand) == [nouns[c] for c in otr[-1]["cand"].tolist()] and np.array_equal(np.asarray(u_preds), otr[-1]["u_preds"])
+    assert set(lab_names) <= set(cand) and len(cand) == k
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "e", "c", "c1"])
