@@ -635,20 +635,29 @@ __device__ __forceinline__ float rb_swap32(float v, int lane) {         // the v
 }
 #define RB8_EMARGIN 4.2f                   /* sim_refine_kernel certifies against (other half's entry KS) - 3.9 E: keep it below this */
 template <bool SOFTMAX, int TM, int KS, int XM = 0>
-__global__ void __launch_bounds__(512) sim_topk_rb8_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt, long long n,
-                                                           long long v, float scale, float* __restrict__ cand_val,
+__global__ void __launch_bounds__(512) sim_topk_rb8_kernel(const half_t* __restrict__ F, const half_t* __restrict__ Wt_all, long long n,
+                                                           long long v_all, float scale, float* __restrict__ cand_val,
                                                            int* __restrict__ cand_idx, float* __restrict__ stats,
-                                                           const unsigned* __restrict__ wmax2_bits) {
+                                                           const unsigned* __restrict__ wmax2_bits, int rb0 = 0, int nparts = 1,
+                                                           long long vsplit = 0, long long out_row0 = 0, long long part_rows = 0) {
+    // rb0 / nparts / vsplit (round 4): the launch's row blocks are rb0 + blockIdx.x / nparts; with nparts == 2 a row block is served
+    // by TWO blocks, names [0, vsplit) and [vsplit, v), whose lists go to side arrays (row (part * part_rows + img - out_row0)) and are
+    // merged by sim_split_merge_kernel - the partial last round of row blocks (626 blocks on 256 CUs at the C4 shard: 256 + 256 + 114)
+    // then costs half a round instead of a whole one.
     constexpr int D = 512, UB = 32768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int r = lane & 31, hh = lane >> 5;
     const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int rbi = (int)blockIdx.x / nparts, part = (int)blockIdx.x - rbi * nparts;
+    const long long v_lo = part ? vsplit : 0, v_hi = (nparts == 2 && part == 0) ? vsplit : v_all;
+    const long long v = v_hi - v_lo;                           // this block's vocabulary: names v_lo .. v_hi - 1, local indices below
+    const half_t* Wt = Wt_all + (size_t)v_lo * D;
 
     half8 bf[32];
     float f2 = 0.f;
-    const long long img = (long long)blockIdx.x * 256 + wave * 32 + r;
+    const long long img = (long long)(rb0 + rbi) * 256 + wave * 32 + r;
     {
         // eight fragments at a time (the "memory" clobber keeps the next batch's loads behind the pins): loaded all at once the
         // 32 fragments need 128 VGPRs on their way to the AGPRs, and the kernel has 128 in all
@@ -897,24 +906,57 @@ __global__ void __launch_bounds__(512) sim_topk_rb8_kernel(const half_t* __restr
         smz += acc16[0][0] + acc16[1][0] + acc16[2][0] + acc16[3][0];
     }
     if (img < n) {
-        float* cv = cand_val + (img * 2 + hh) * TM;
-        int* ci = cand_idx + (img * 2 + hh) * TM;
+        const long long orow = (long long)part * part_rows + (img - out_row0);
+        float* cv = cand_val + (orow * 2 + hh) * TM;
+        int* ci = cand_idx + (orow * 2 + hh) * TM;
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int idx = __double2loint(L[j]);
             const bool ok = L[j] > -INFINITY && (long long)idx < v;
             cv[j] = ok ? (float)L[j] * scale : -INFINITY;
-            ci[j] = ok ? idx : -1;
+            ci[j] = ok ? idx + (int)v_lo : -1;
         }
         if (SOFTMAX) {
-            stats[(img * 2 + hh) * 2] = smm * scale;
-            stats[(img * 2 + hh) * 2 + 1] = smz;
+            stats[(orow * 2 + hh) * 2] = smm * scale;
+            stats[(orow * 2 + hh) * 2 + 1] = smz;
         }
     }
 #undef RB_RD
 #undef RB_WAIT
 #undef RB_MFMA
 #undef RB_MFMA0
+}
+// The two vocabulary parts of a split row block into the image's two half lists: list h = the TM best of (part 0's list h, part 1's
+// list h), (value desc, index asc).  Everything a part dropped is bounded by ITS lists' entries, and the merged list dominates both
+// parts' lists entry by entry, so sim_refine4_kernel's certificate (list_h[TM-1], max(list_A[KS], list_B[KS]) - 3.9 E) holds for the
+// merged lists as it does for a block that saw the whole vocabulary.  Softmax (max, sum) pairs are combined per half.
+__global__ void __launch_bounds__(256) sim_split_merge_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                              const float* __restrict__ pstats, long long row0, long long n, long long part_rows,
+                                                              int tm, int softmax, float* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                              float* __restrict__ stats) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long img = row0 + (t >> 1);
+    const int hh = (int)(t & 1);
+    if (img >= n) return;
+    const long long o0 = ((img - row0) * 2 + hh), o1 = ((part_rows + img - row0) * 2 + hh);
+    const float* a = pval + o0 * tm; const int* ai = pidx + o0 * tm;
+    const float* b = pval + o1 * tm; const int* bi = pidx + o1 * tm;
+    float* cv = cand_val + (img * 2 + hh) * tm;
+    int* ci = cand_idx + (img * 2 + hh) * tm;
+    int x = 0, y = 0;
+    for (int j = 0; j < tm; ++j) {
+        const bool ha = x < tm && ai[x] >= 0, hb = y < tm && bi[y] >= 0;
+        const bool take_a = ha && (!hb || a[x] > b[y] || (a[x] == b[y] && ai[x] < bi[y]));
+        if (take_a) { cv[j] = a[x]; ci[j] = ai[x]; ++x; }
+        else if (hb) { cv[j] = b[y]; ci[j] = bi[y]; ++y; }
+        else { cv[j] = -INFINITY; ci[j] = -1; }
+    }
+    if (softmax) {
+        const float m0 = pstats[o0 * 2], z0 = pstats[o0 * 2 + 1], m1 = pstats[o1 * 2], z1 = pstats[o1 * 2 + 1];
+        const float mm = fmaxf(m0, m1);
+        stats[(img * 2 + hh) * 2] = mm;
+        stats[(img * 2 + hh) * 2 + 1] = (m0 > -INFINITY ? z0 * __expf(m0 - mm) : 0.f) + (m1 > -INFINITY ? z1 * __expf(m1 - mm) : 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1852,10 +1894,13 @@ static int sim_exact_launch(const half_t* f, const half_t* wt, int d, long long 
     return SCD_OK;
 }
 
+// side arrays of the split last round (two vocabulary parts of up to 128 row blocks): values, indices, softmax pairs
+static const size_t SIM_SPLIT_ROWS = 2 * 128 * 256;
+static const size_t SIM_SPLIT_BYTES = 2 * ((SIM_SPLIT_ROWS * 2 * TOPM * 4 + 255) / 256 * 256) + (SIM_SPLIT_ROWS * 2 * 2 * 4 + 255) / 256 * 256;
 extern "C" size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k) {
     (void)d; (void)v; (void)k;
     return 64 + scd_align((size_t)n * 2 * TOPM * 4) * 2 + scd_align((size_t)n * 32) + scd_align((size_t)n * 4) * 2 + 256 +
-           scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v));
+           scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v)) + SIM_SPLIT_BYTES;
 }
 
 extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
@@ -1915,10 +1960,29 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
         sim_refine4_kernel<SM, 8><<<(unsigned)scd_cdiv(n, 16), 256, 0, st>>>(f, wt, n, v, scale, k, cval, cidx, stats, hdr, fb, (long long*)idx_out, val_out, -1, bnd, 4); \
         { const int rc_ = sim_exact_launch<SM>(f, wt, d, v, scale, k, hdr, fb, expart, (long long*)idx_out, val_out, st); if (rc_) return rc_; } \
     }
+        // the partial last round of row blocks (g1 mod 256 of them), when it fills at most half of the chip and the vocabulary is long
+        // enough to halve: two blocks per row block, one per vocabulary half, merged before the refine pass
+        static const int split_env = getenv("SCD_SIM_SPLIT") ? atoi(getenv("SCD_SIM_SPLIT")) : 1;
+        const unsigned rem = g1 % 256u;
+        const long long nun = (v + 31) / 32;
+        const bool split = split_env && rem > 0 && rem <= 128 && nun >= 32;
+        const long long vsplit = (nun / 2) * 32;
+        char* sp = (char*)expart + scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v));
+        float* sp_val = (float*)sp;
+        int* sp_idx = (int*)(sp + scd_align(SIM_SPLIT_ROWS * 2 * TOPM * 4));
+        float* sp_st = (float*)(sp + 2 * scd_align(SIM_SPLIT_ROWS * 2 * TOPM * 4));
 #define RB8_GO(SM, TMV, KSV)                                                                                                    \
     {                                                                                                                           \
         { const int rc_ = scd_set_max_lds((const void*)sim_topk_rb8_kernel<SM, TMV, KSV, 0>, 131072); if (rc_) return rc_; }        \
-        sim_topk_rb8_kernel<SM, TMV, KSV><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits);     \
+        if (!split) sim_topk_rb8_kernel<SM, TMV, KSV><<<g1, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); \
+        else {                                                                                                                  \
+            const long long row0 = (long long)(g1 - rem) * 256, prow = (long long)rem * 256;                                   \
+            if (g1 > rem) sim_topk_rb8_kernel<SM, TMV, KSV><<<g1 - rem, 512, 131072, st>>>(f, wt, n, v, scale, cval, cidx, stats, &hdr->wmax2_bits); \
+            sim_topk_rb8_kernel<SM, TMV, KSV><<<2 * rem, 512, 131072, st>>>(f, wt, n, v, scale, sp_val, sp_idx, sp_st, &hdr->wmax2_bits, \
+                                                                            (int)(g1 - rem), 2, vsplit, row0, prow);           \
+            sim_split_merge_kernel<<<(unsigned)scd_cdiv((n - row0) * 2, 256), 256, 0, st>>>(sp_val, sp_idx, sp_st, row0, n, prow, TMV, SM ? 1 : 0, \
+                                                                                            cval, cidx, stats);                \
+        }                                                                                                                       \
         RB_TAIL(SM, TMV, KSV)                                                                                                   \
     }
 #ifdef SCD_ABLATE

@@ -644,8 +644,13 @@ def test_sim_topk_golden_and_oracle(ops, golden):
     assert (idx[:, 0].cpu().numpy() == g["tk_idx_ptsup"][:, 0]).mean() > 0.99
 
 
-@pytest.mark.parametrize("n,v,d,k", [(300, 21000, 512, 5), (129, 1000, 512, 3), (1000, 100, 512, 1), (64, 37, 64, 8)])
+@pytest.mark.parametrize("n,v,d,k", [(300, 21000, 512, 5), (129, 1000, 512, 3), (1000, 100, 512, 1), (64, 37, 64, 8),
+                                     (33100, 1100, 512, 3), (66000, 1031, 512, 3), (300, 1031, 512, 2)])
 def test_sim_topk_shapes(ops, n, v, d, k):
+    """Ragged N and V, every list size, d < 512 (tile kernel), and both launch forms of the row-block kernel: up to 128 row blocks
+    in the (partial) last round are served by two blocks each, one per vocabulary half, merged before the refine pass
+    (sim_split_merge_kernel: n = 300 and 129 with V >= 1024 names; n = 66,000 = 256 whole-vocabulary blocks + 2 split ones); n = 1000 x
+    100 names and n = 33,100 (130 row blocks: more than half a round) take the whole vocabulary in every block."""
     rs = np.random.RandomState(n + v)
     f = (rs.randn(n, d) / np.sqrt(d)).astype(np.float16)
     w = (rs.randn(d, v) / np.sqrt(d)).astype(np.float16)
