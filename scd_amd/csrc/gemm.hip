@@ -1436,7 +1436,10 @@ static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
         const int cand = (tiles_n + groups - 1) / groups;
         const double wg = cand * panel;
         const double rounds = (double)total / resident;
-        const double w_traffic = wg <= 2.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
+        // W panels of a group stay in an XCD's 4-MB L2 up to ~3.6 MB: round 4's sweep at the default launch size (786,432 rows,
+        // profiles/r04_gemm_ng_sweep.txt) - QKV's nine tile columns (3.54 MB) as ONE group: -5.9 % (one pass over A instead of two),
+        // -3.2 % at 393,216 rows, neutral at 131,072; fc1's twelve (4.7 MB) as one group: +3 %, two groups of six stay best
+        const double w_traffic = wg <= 3.6e6 ? 8.0 * tiles_n * panel : 8.0 * rounds * wg;
         const double cost = groups * a_bytes + w_traffic;
         if (cost < best) { best = cost; ng = cand; }
     }
