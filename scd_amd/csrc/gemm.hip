@@ -689,9 +689,18 @@ template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-               int xmode, int ng, const long long* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, long long* __restrict__ ln_out, int stagger, long long* __restrict__ ln_zero) {
+               int xmode_in, int ng, const long long* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
+               float ln_eps, long long* __restrict__ ln_out, int stagger_in, long long* __restrict__ ln_zero) {
     static_assert(NT == 8, "wave tile is 128 x 128");
+#ifdef SCD_ABLATE
+    const int xmode = xmode_in, stagger = stagger_in;
+#else
+    // the shipped build keeps the one switch it uses (512: non-temporal C stores): the timing ablations, the cycle counters and the
+    // start-up stagger exist in the -DSCD_ABLATE build only.  With them a runtime possibility, their state (seven 64-bit counters, the
+    // probe registers) stayed live through the kernel and the residual variant spilled 11 VGPRs / 66 SGPRs (round 4)
+    const int xmode = xmode_in & 512, stagger = 0;
+    (void)stagger_in;
+#endif
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
     constexpr bool DEFER_ST = HAS_RES && W4_DEFER_STORES;   // residual variants: all stores after the last residual load
     constexpr bool LATE_BAR = W4_LATE_BAR;     // the chunk's barrier after the odd sub-step's first L0 MFMAs instead of before them
@@ -702,6 +711,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, q16 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lane_el = HAS_RES ? (unsigned)(q16 * N + c16 * 8) : 0u;   // (residual variants) element offset of this lane's row / 16-byte piece inside a 4-row group
     const int nkc = K >> 6;                       // 64-deep chunks per tile
     const int tiles_m = total_tiles / tiles_n;
     const int per_group = tiles_m * ng;
@@ -812,7 +822,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         for (int p = 0; p < W4_TNW; ++p) issue_w(p, 1);
     }
     issue_advance();
-    constexpr int RD = LN == 2 ? 2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
+#ifndef W4_RD_LN2
+#define W4_RD_LN2 2
+#endif
+    constexpr int RD = LN == 2 ? W4_RD_LN2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
     half8 rq[RD][4];
 #pragma unroll
     for (int e = 0; e < RD; ++e)
@@ -928,6 +941,12 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     for (int ti = 0; ti < my_tiles; ++ti) {
         const int bm = cit.bm, bn = cit.n0 + cit.bnl;
         const int nb0 = bn * BN + wn * 128;
+        // C / R addresses of the epilogue = a wave-uniform tile base (SGPRs) + ONE 32-bit per-lane element offset (row q16 of the
+        // wave's rows, column piece c16): as 64-bit per-lane pointers the loop-invariant parts were hoisted into VGPR pairs that
+        // lived through the kernel, and the residual variant spilled ten of them (round 4)
+        const size_t tile_el = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128) * N + ((xmode & 1024) ? wn * 128 : nb0);
+        const half_t* const Rt = HAS_RES ? R + tile_el : nullptr;
+        half_t* const Ct = C + tile_el;
         const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
         f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
         f32x4v bq[8], sq[8];
@@ -939,7 +958,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     {                                                                                                            \
         if (HAS_RES) {                                                                                           \
             _Pragma("unroll") for (int e = 0; e < RD - 1; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
-                *(const half8*)(R + ((size_t)bm * BM + wm * 128 + e * 16 + p * 4 + q16) * N + nb0 + c16 * 8);    \
+                *(const half8*)(Rt + (size_t)((e * 16 + p * 4) * N) + lane_el);                                  \
         }                                                                                                        \
         if (HAS_BIAS) {                                                                                          \
             _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
@@ -1036,6 +1055,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                     for (int p = 0; p < 4; ++p) {
                         const int rr = p * 4 + q16;
                         half8 hv = hvb[p];
+                        half_t* const crow = Ct + (size_t)((ts * 16 + p * 4) * N);          // wave-uniform (residual variants)
                         const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + ts * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
                         if (HAS_RES) hv = hv + rq[ts % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
                         if (LN == 2) {
@@ -1074,6 +1094,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 2]) : "v"(w4.z));
                             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 3]) : "v"(w4.w));
                         } else if (xmode & 2) { /* ablation: no stores */
+                        } else if (HAS_RES) {
+                            if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
+                            else *(half8*)(crow + lane_el) = hv;
                         } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
                         else *(half8*)(C + off) = hv;
                     }
@@ -1081,7 +1104,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 if (HAS_RES && tm < 8 && tm + RD - 1 < 8) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        rq[(tm + RD - 1) % RD][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + RD - 1) * 16 + p * 4 + q16) * N + nb0 + c16 * 8);
+                        rq[(tm + RD - 1) % RD][p] = *(const half8*)(Rt + (size_t)(((tm + RD - 1) * 16 + p * 4) * N) + lane_el);
                 }
                 if (tm < 8) {
 #pragma unroll
@@ -1102,10 +1125,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.z) : "a"(stash[ts][p * 4 + 2]));
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(w4.w) : "a"(stash[ts][p * 4 + 3]));
                         const half8 hv = __builtin_bit_cast(half8, w4);
-                        const size_t off = ((size_t)bm * BM + wm * 128 + ts * 16 + p * 4 + q16) * N + nb0 + c16 * 8;
+                        half_t* const crow = Ct + (size_t)((ts * 16 + p * 4) * N);
                         if (xmode & 2) { /* ablation: no stores */
-                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
-                        else *(half8*)(C + off) = hv;
+                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
+                        else *(half8*)(crow + lane_el) = hv;
                     }
             }
         }
@@ -1113,7 +1136,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // fixed point so that the six partial sums of a row (3 tile columns x 2 waves) add up deterministically
-                unsigned long long* dst = (unsigned long long*)(ln_out + 2 * ((size_t)bm * BM + wm * 128 + 4 * c16 + 64 * j + q16));
+                unsigned long long* dst = (unsigned long long*)(ln_out + 2 * ((size_t)bm * BM + wm * 128)) + (unsigned)(2 * (4 * c16 + 64 * j + q16));
                 atomicAdd(dst, (unsigned long long)__float2ll_rn(keep1[j] * 16777216.f));
                 atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(keep2[j] * 1048576.f));
             }
