@@ -685,7 +685,7 @@ __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block
 // LN = 2: this GEMM produces the rows the NEXT LayerNorm normalises: the epilogue adds each row's {sum, sum of squares} of
 //         the fp16 values it stores into ln_out[m] (64-bit integer atomics - order-independent, so the encoder stays
 //         bit-reproducible - one 64-row instruction per 64 rows).
-template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN>
+template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN, bool NTS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
@@ -698,7 +698,11 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // the shipped build keeps the one switch it uses (512: non-temporal C stores): the timing ablations, the cycle counters and the
     // start-up stagger exist in the -DSCD_ABLATE build only.  With them a runtime possibility, their state (seven 64-bit counters, the
     // probe registers) stayed live through the kernel and the residual variant spilled 11 VGPRs / 66 SGPRs (round 4)
-    const int xmode = xmode_in & 512, stagger = 0;
+    // Non-temporal C stores: for the residual variants (proj, fc2) a template parameter (NTS) - as a runtime test in front of each of
+    // the tile's 32 store instructions they cost 61 branches with their exec-mask bookkeeping per tile, and with the test gone the
+    // variant needs 196 VGPRs and spills nothing; the LayerNorm-folded variants (QKV, fc1) keep the runtime test: without it the
+    // register allocator ends at 256 VGPRs with spills reloaded once per tile (hipcc 7.2, -Rpass-analysis=kernel-resource-usage)
+    const int xmode = HAS_RES ? (NTS ? 512 : 0) : (xmode_in & 512), stagger = 0;
     (void)stagger_in;
 #endif
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
@@ -1095,9 +1099,13 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 3]) : "v"(w4.w));
                         } else if (xmode & 2) { /* ablation: no stores */
                         } else if (HAS_RES) {
-                            if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
+                            // (s_nop 1 behind every asm store: a VMEM store of more than 64 bits must not be followed within two wait
+                            // states by a write of its data registers, and hipcc's hazard recognizer cannot see a store inside inline asm -
+                            // the deferred-store loop below refills the same four registers for the next store right away.  Round 4: with
+                            // the per-store branches gone the big launches wrote corrupted rows until the nops went in)
+                            if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
                             else *(half8*)(crow + lane_el) = hv;
-                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(C + off), "v"(hv) : "memory");
                         else *(half8*)(C + off) = hv;
                     }
                 }
@@ -1127,7 +1135,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         const half8 hv = __builtin_bit_cast(half8, w4);
                         half_t* const crow = Ct + (size_t)((ts * 16 + p * 4) * N);
                         if (xmode & 2) { /* ablation: no stores */
-                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
+                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
                         else *(half8*)(crow + lane_el) = hv;
                     }
             }
@@ -1427,7 +1435,7 @@ gemm_w8_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         keep2[tm >> 2] = mine ? s2 : keep2[tm >> 2];
                     }
                     if (xmode & 2) {
-                    } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(C + off), "v"(hv) : "memory");
+                    } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(C + off), "v"(hv) : "memory");
                     else *(half8*)(C + off) = hv;
                 }
             }
@@ -1497,7 +1505,8 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
                      const scd_gemm_ln* ln, hipStream_t st) {
     constexpr int LDS = 2 * 65536 + 16384;
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
-    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN, false>, LDS); if (rc_) return rc_; }
+    if (RR) { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN, RR>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
     static const int xenv = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;   // -1: by size
@@ -1507,10 +1516,13 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
     static const int stagger_env = SCD_ABLATE_ENV("SCD_GEMM_STAGGER", 0);   // ticks per phase, experiment
     const int stagger = stagger_env;
-    gemm_w4_kernel<NT, ACT, B, RR, LN><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
-                                                               LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
-                                                               LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,
-                                                               LN == 2 ? ln->stats_out : nullptr, stagger, LN == 1 ? ln->zero_out : nullptr);
+#define W4_GO(NTSV)                                                                                                            \
+    gemm_w4_kernel<NT, ACT, B, RR, LN, NTSV><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,         \
+                                                                     LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr, \
+                                                                     LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,             \
+                                                                     LN == 2 ? ln->stats_out : nullptr, stagger, LN == 1 ? ln->zero_out : nullptr)
+    if (RR && nt) W4_GO(RR); else W4_GO(false);      // (NTS is only instantiated for the residual variants)
+#undef W4_GO
     if (xmode & 64) {
         static unsigned long long h[256 * 4];
         SCD_HIP(hipDeviceSynchronize());

@@ -816,6 +816,29 @@ def test_encoder_batch_invariance(ops):
     assert torch.equal(five, all13[4:9])
 
 
+@pytest.mark.parametrize("kind", ["clip", "dino"])
+def test_encoder_large_launch_equals_small_batches(ops, kind):
+    """The launch sizes the bench runs at - several rounds of tiles per GEMM, non-temporal C stores (2 M N > 64 MB: from 53 images on
+    for fc1), QKV as one n-group - against small batches of the same images, bit for bit: 1,400 images in one call (two 665-image row
+    groups + a ragged rest) = the same images 13 at a time.  The small-batch tests never reach those kernels' big-launch paths (round 4:
+    a store-data hazard inside inline asm corrupted rows of the large launches only, and only the bench noticed)."""
+    from scd_amd.clip import weights as W
+    from scd_amd.clip.model import CLIP, DinoViT
+    if kind == "clip":
+        model = CLIP(W.synthetic_clip_state_dict(seed=3, cfg=dict(v_layers=2, t_layers=1))).cuda().eval()
+        enc = lambda x: model.encode_image(x)
+    else:
+        model = DinoViT(W.synthetic_dino_state_dict(seed=1, layers=2)).cuda()
+        enc = lambda x: model(x)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    img = torch.randn(1400, 3, 224, 224, generator=g, device="cuda", dtype=torch.float16)
+    big = enc(img).float()
+    assert bool(torch.isfinite(big).all())
+    for s0 in (0, 652, 665, 1317, 1387):
+        small = enc(img[s0:s0 + 13]).float()
+        assert torch.equal(small, big[s0:s0 + 13]), s0
+
+
 @pytest.mark.parametrize("longest", [9, 32, 33, 64, 65, 76])
 def test_text_tower_trimmed_context_is_bit_identical(ops, longest):
     """encode_text reads only the EOT position of a causal tower (clip model.py encode_text): computing the first
