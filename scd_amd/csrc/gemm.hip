@@ -702,7 +702,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // the tile's 32 store instructions they cost 61 branches with their exec-mask bookkeeping per tile, and with the test gone the
     // variant needs 196 VGPRs and spills nothing; the LayerNorm-folded variants (QKV, fc1) keep the runtime test: without it the
     // register allocator ends at 256 VGPRs with spills reloaded once per tile (hipcc 7.2, -Rpass-analysis=kernel-resource-usage)
-    const int xmode = HAS_RES ? (NTS ? 512 : 0) : (xmode_in & 512), stagger = 0;
+    const int xmode = NTS ? 512 : 0, stagger = 0; (void)xmode_in;
     (void)stagger_in;
 #endif
     constexpr bool DMA_SPLIT = W4_DMA_SPLIT;
@@ -1003,17 +1003,23 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             // and its rows are stored after that (one wave per SIMD: nothing else would cover the LDS round trip)
             half8 hvb[4];
             unsigned stash[8][16];
+            float rstd_a[8], nmr_a[8];
+            if (LN == 1) {
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm) {
+                    // row sums are 64-bit fixed point (2^-24 / 2^-20 units): integer atomics add in any order to the same bits
+                    const float mu = __ll2float_rn(lst[tm][0]) * (5.9604644775390625e-8f * ln_invk);
+                    const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(lst[tm][1]) * (9.5367431640625e-7f * ln_invk)), 0.f);
+                    rstd_a[tm] = __builtin_amdgcn_rsqf(var + ln_eps);
+                    nmr_a[tm] = -mu * rstd_a[tm];
+                }
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int tm = 0; tm <= 8; ++tm) {
                 if (tm < 8) {
                     float rstd = 1.f, nmr = 0.f;
-                    if (LN == 1) {
-                        // row sums are 64-bit fixed point (2^-24 / 2^-20 units): integer atomics add in any order to the same bits
-                        const float mu = __ll2float_rn(lst[tm][0]) * (5.9604644775390625e-8f * ln_invk);
-                        const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(lst[tm][1]) * (9.5367431640625e-7f * ln_invk)), 0.f);
-                        rstd = __builtin_amdgcn_rsqf(var + ln_eps);
-                        nmr = -mu * rstd;
-                    }
+                    if (LN == 1) { rstd = rstd_a[tm]; nmr = nmr_a[tm]; }
 #pragma unroll
                     for (int tn = 0; tn < 8; ++tn) {
                         // four values as two register pairs, so that bias / LayerNorm terms are packed-fp32 operations and the
@@ -1506,7 +1512,7 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     constexpr int LDS = 2 * 65536 + 16384;
     if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
     { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN, false>, LDS); if (rc_) return rc_; }
-    if (RR) { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN, RR>, LDS); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<NT, ACT, B, RR, LN, true>, LDS); if (rc_) return rc_; }
     const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
     static const int xenv = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
     static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;   // -1: by size
@@ -1521,7 +1527,7 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
                                                                      LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr, \
                                                                      LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,             \
                                                                      LN == 2 ? ln->stats_out : nullptr, stagger, LN == 1 ? ln->zero_out : nullptr)
-    if (RR && nt) W4_GO(RR); else W4_GO(false);      // (NTS is only instantiated for the residual variants)
+    if (nt) W4_GO(true); else W4_GO(false);
 #undef W4_GO
     if (xmode & 64) {
         static unsigned long long h[256 * 4];
