@@ -715,7 +715,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c16 = lane & 15, q16 = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const unsigned lane_el = HAS_RES ? (unsigned)(q16 * N + c16 * 8) : 0u;   // (residual variants) element offset of this lane's row / 16-byte piece inside a 4-row group
+    const unsigned lane_el = (unsigned)(q16 * N + c16 * 8);   // element offset of this lane's row / 16-byte piece inside a 4-row group
     const int nkc = K >> 6;                       // 64-deep chunks per tile
     const int tiles_m = total_tiles / tiles_n;
     const int per_group = tiles_m * ng;
@@ -1066,7 +1066,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         const int rr = p * 4 + q16;
                         half8 hv = hvb[p];
                         half_t* const crow = Ct + (size_t)((ts * 16 + p * 4) * N);          // wave-uniform (residual variants)
-                        const size_t off = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128 + ts * 16 + rr) * N + ((xmode & 1024) ? wn * 128 : nb0) + c16 * 8;
+                        (void)rr;
                         if (HAS_RES) hv = hv + rq[ts % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
                         if (LN == 2) {
                             // row sums of the stored fp16 values over this wave's 128 columns: 8 values in-lane, then the 16 lanes
@@ -1104,15 +1104,13 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 2]) : "v"(w4.z));
                             asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(stash[ts][p * 4 + 3]) : "v"(w4.w));
                         } else if (xmode & 2) { /* ablation: no stores */
-                        } else if (HAS_RES) {
+                        } else if (xmode & 512) {
                             // (s_nop 1 behind every asm store: a VMEM store of more than 64 bits must not be followed within two wait
                             // states by a write of its data registers, and hipcc's hazard recognizer cannot see a store inside inline asm -
                             // the deferred-store loop below refills the same four registers for the next store right away.  Round 4: with
                             // the per-store branches gone the big launches wrote corrupted rows until the nops went in)
-                            if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
-                            else *(half8*)(crow + lane_el) = hv;
-                        } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(C + off), "v"(hv) : "memory");
-                        else *(half8*)(C + off) = hv;
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_el * 2u), "v"(hv), "s"(crow) : "memory");
+                        } else *(half8*)(crow + lane_el) = hv;
                     }
                 }
                 if (HAS_RES && tm < 8 && tm + RD - 1 < 8) {
