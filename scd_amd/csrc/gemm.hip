@@ -810,10 +810,20 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     cit.r = tstride - cit.q * cit.w;
     nit = cit;
     int nkt = 0, ntiles = 0;              // ntiles: tiles completely issued
+    // panel bases of the tile being issued (nit): recomputed when that tile changes, so that a chunk's pointers are base + 128 kc bytes
+    // (the closed form per chunk - two 64-bit multiply-adds - sat in the lone wave's instruction stream between two MFMA groups)
+    const half_t *ga_t = A, *gw_t = W;
+    auto tile_ptrs = [&]() {
+        int bm = nit.bm, bn = nit.n0 + nit.bnl;
+        if (xmode & 4) { bm = 0; bn = 0; }
+        ga_t = A + (size_t)bm * BM * K;
+        gw_t = W + (size_t)bn * BN * K;
+    };
+    tile_ptrs();
     auto issue_advance = [&]() {
         if (++nkt == nkc) {
             nkt = 0;
-            if (++ntiles < my_tiles) it_step(nit);
+            if (++ntiles < my_tiles) { it_step(nit); tile_ptrs(); }
         }
     };
     issue(nit, nkt, 0);
@@ -934,7 +944,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_bar += t - t_sub; t_sub = t; } \
         /* past this block's last chunk the refill re-reads the current tile's first chunk into the free slot: no branch  \
            around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
-        if (g + 2 < chunks) chunk_ptrs(nit, nkt); else chunk_ptrs(cit, 0);                                       \
+        if (g + 2 < chunks) { ga = ga_t + nkt * 64; gw = gw_t + nkt * 64; } else chunk_ptrs(cit, 0);             \
         issue_advance();                                                                                         \
         if (LATE_BAR) { W4_SUB_RANGE(fwB, faB, 0, W4_H_ODD, W4_LATE_TM, 8) } else { W4_SUB(fwB, faB, 0, W4_H_ODD) }  \
         cslot ^= 1;                                                                                              \
