@@ -784,11 +784,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned dma_lds = sbase + wave * 8192;
     const unsigned voff0 = (unsigned)g_off[0] * 2, voff1 = (unsigned)g_off[1] * 2;
-#define W4_DMA(BASE, P, LDSOFF)                                                                                  \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                                \
-                 ::"s"(dma_lds + (LDSOFF) + (P) * 1024), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16) : "memory")
-    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, slot * SLOT); };
-    auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, slot * SLOT + WPART); };
+    // M0 = the slot's LDS base (one SGPR per slot, formed once) + an immediate: one SALU instruction per fill.  (As "s"(base + slot
+    // offset + 1024 p) hipcc rebuilt the address with xor / add / mov + its own s_nop in front of every fill: five scalar
+    // instructions in the lone wave's stream per fill, sixteen fills per chunk.)
+#define W4_DMA(BASE, P, SLOTLDS, PART)                                                                           \
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                            \
+                 ::"s"(SLOTLDS), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16), "n"((PART) + (P) * 1024) : "memory", "scc")
+    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0); };
+    auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, dma_lds + slot * SLOT, WPART); };
     auto issue = [&](const TileIt& it, int kc, int slot) {
         chunk_ptrs(it, kc);
 #pragma unroll
