@@ -169,6 +169,22 @@ int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int
                          float* C_ring, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,
                          const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* best_labels, float* best_C,
                          double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream);
+/* The same loop over a ROW SHARD, one process per GPU (the reference is single-process): X_u / X16_cat / labels are this
+ * rank's rows, sums_lab / counts_lab / sumsq4 the GLOBAL ones (reduced by the caller once per fit).  Every iteration packs the rank's
+ * [k*d sums | k counts as float64] into xbuf (device, k*d + 2k doubles) and calls exchange(exchange_ctx, xbuf, k*d + k, stream), which
+ * must leave the element-wise sum over all ranks in xbuf in stream order (an all-reduce; scd_allreduce_centroids has this signature
+ * with ctx = the handle, a torch.distributed caller passes a callback around dist.all_reduce) and return 0.  Centres, centre shift
+ * and inertia are then formed from the global sums, so every rank takes the same stop / keep decisions and issues the same number of
+ * exchanges; with exact sums (scd_f16_exact_max: GLOBAL rows x max|x| < 2^29) the result is bit-identical to the single-process
+ * loop whatever the sharding.  The fresh-or-incremental M-step choice and the E-step hints are per rank.  Needs n_u > 0 on every
+ * rank.  A non-zero return of the callback ends the loop with SCD_ERCCL. */
+typedef int (*scd_exchange_fn)(void* ctx, double* buf, int64_t n_doubles, void* stream);
+int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
+                                 int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev, const float* C_start,
+                                 float* C_ring, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,
+                                 const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* best_labels, float* best_C,
+                                 double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream,
+                                 double* xbuf, scd_exchange_fn exchange, void* exchange_ctx);
 /* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
  * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
  * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips

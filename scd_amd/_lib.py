@@ -28,6 +28,8 @@ class EncoderDesc(C.Structure):
 
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+# scd_exchange_fn (include/scd_hip.h): int (*)(void* ctx, double* buf, int64_t n_doubles, void* stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/scd_hip.h
 SIGNATURES = {
@@ -69,6 +71,9 @@ SIGNATURES = {
     # stats_ring, max_iter, tol, best_labels, best_C, result_host, ws_e, nb_e, ws_m, nb_m, stream
     "scd_kmeans_lloyd_run": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_double,
                                   _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    # ... the same, then xbuf, exchange (EXCHANGE_FN), exchange_ctx
+    "scd_kmeans_lloyd_run_sharded": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                          C.c_double, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, EXCHANGE_FN, _vp]),
     "scd_kmeans_lloyd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
     "scd_kmeans_min_update_multi": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp]),
     "scd_kpp_draw_multi": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

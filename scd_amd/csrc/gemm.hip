@@ -787,11 +787,17 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // M0 = the slot's LDS base (one SGPR per slot, formed once) + an immediate: one SALU instruction per fill.  (As "s"(base + slot
     // offset + 1024 p) hipcc rebuilt the address with xor / add / mov + its own s_nop in front of every fill: five scalar
     // instructions in the lone wave's stream per fill, sixteen fills per chunk.)
-#define W4_DMA(BASE, P, SLOTLDS, PART)                                                                           \
-    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                            \
+#ifndef W4_A_MOD
+#define W4_A_MOD ""      // cache-policy bits of the activation fills (" nt", " sc1", ...): experiment hook
+#endif
+#ifndef W4_W_MOD
+#define W4_W_MOD ""
+#endif
+#define W4_DMA(BASE, P, SLOTLDS, PART, MOD)                                                                      \
+    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD                        \
                  ::"s"(SLOTLDS), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16), "n"((PART) + (P) * 1024) : "memory", "scc")
-    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0); };
-    auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, dma_lds + slot * SLOT, WPART); };
+    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, W4_A_MOD); };
+    auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, dma_lds + slot * SLOT, WPART, W4_W_MOD); };
     auto issue = [&](const TileIt& it, int kc, int slot) {
         chunk_ptrs(it, kc);
 #pragma unroll

@@ -2739,12 +2739,26 @@ __global__ void __launch_bounds__(256) inertia_dd_kernel(const float* __restrict
     }
 }
 
+// Exchange hook of the sharded Lloyd loop (scd_kmeans_lloyd_run_sharded): every rank's [k*d sums | k counts as float64] are summed in
+// place by `fn` (an all-reduce the caller owns); the k int64 counts the finalize launch reads are rebuilt behind them.  The rank's
+// own sums / counts stay untouched - the incremental M-step keeps updating them.
+struct LloydXch { double* buf; scd_exchange_fn fn; void* ctx; };
+__global__ void __launch_bounds__(256) xch_pack_kernel(const double* sums, const long long* counts, size_t kd, int k, double* buf) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < kd) buf[i] = sums[i];
+    else if (i < kd + (size_t)k) buf[i] = (double)counts[i - kd];
+}
+__global__ void __launch_bounds__(256) xch_unpack_kernel(double* buf, size_t kd, int k) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < k) ((long long*)(buf + kd + k))[i] = llrint(buf[kd + i]);
+}
+
 static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
                                  int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
                                  float* C_out, double* sums, int64_t* counts, const double* sums_lab,
                                  const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
                                  size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq,
-                                 int shift_mode = 0) {
+                                 int shift_mode = 0, const LloydXch* xch = nullptr) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
     SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
                 "scd_kmeans_lloyd_step_delta: null argument");
@@ -2757,6 +2771,9 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
     // rows whose label changed: accumulated in the handle's scratch (zero between iterations), handed to stats[4] by finalize_kernel
     double* changed_acc = (double*)((char*)h->scratch + 262144 + 40);
     bool fused_inertia = false;
+    // sharded: the inertia always comes from the (global) sums - a rank's row-wise partial of a fresh M-step could not be mixed with
+    // the sums-based form another rank's incremental step needs, and each rank picks fresh / incremental from its own change count
+    const bool sums_inertia = xch || !(flags & SCD_LLOYD_FULL);
     if (flags & SCD_LLOYD_FULL) {
         // a fresh M-step (sums, counts, inertia from the rows), then labels_prev = labels for the incremental steps that follow
         rc = scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
@@ -2765,15 +2782,32 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
     } else {
         mstep_delta_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>((const half_t*)X16_cat, labels_cat, labels_prev, l_num, n_cat, d, k, sums,
                                                                           (unsigned long long*)counts, changed_acc);
+    }
+    const double* fsums = sums;
+    const int64_t* fcounts = counts;
+    if (xch) {
+        const size_t kd = (size_t)k * d;
+        xch_pack_kernel<<<(unsigned)scd_cdiv((int64_t)(kd + k), 256), 256, 0, st>>>(sums, (const long long*)counts, kd, k, xch->buf);
+        SCD_LAUNCH_CHECK();
+        rc = xch->fn(xch->ctx, xch->buf, (int64_t)(kd + k), stream);
+        if (rc) {
+            scd_set_error("scd_kmeans_lloyd_run_sharded: the exchange callback failed (%d)", rc);
+            return SCD_ERCCL;
+        }
+        xch_unpack_kernel<<<(unsigned)scd_cdiv(k, 256), 256, 0, st>>>(xch->buf, kd, k);
+        fsums = xch->buf;
+        fcounts = (const int64_t*)(xch->buf + kd + k);
+    }
+    if (sums_inertia) {
         // the inertia from the sums: inside finalize_kernel when its 4 k partials fit behind the k shift partials in the handle's scratch
         // (32,768 doubles), else in a launch of its own (partials at the start of the scratch, free between two finalize launches)
         fused_inertia = 5 * (long long)k <= 32768;
         if (!fused_inertia)
-            inertia_dd_kernel<<<k, 256, 0, st>>>(C_in, sums, (const long long*)counts, sums_lab, (const long long*)counts_lab, sumsq4, k, d,
+            inertia_dd_kernel<<<k, 256, 0, st>>>(C_in, fsums, (const long long*)fcounts, sums_lab, (const long long*)counts_lab, sumsq4, k, d,
                                                  (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144 + 32), stats);
     }
     SCD_LAUNCH_CHECK();
-    return finalize_impl(h, sums, counts, k, d, C_in, C_out, stats + 2, shift_mode, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3, stats + 4,
+    return finalize_impl(h, fsums, fcounts, k, d, C_in, C_out, stats + 2, shift_mode, prep_u, ws_e, ws_e_bytes, n_u, stream, stats + 3, stats + 4,
                          stats, mirror, seq, sums_lab, counts_lab, sumsq4, fused_inertia ? stats : nullptr);
 }
 
@@ -2795,12 +2829,12 @@ extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const
 //  * labels and centres of iteration i live in slot i % 3 of caller-owned rings, so the least-inertia iteration's (the reference's
 //    bookkeeping; nearly always one of the last two) are still there when the loop ends - a slot is copied out only when an OLDER best
 //    iteration's slot is about to be re-used.
-extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
-                                    int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
-                                    const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
-                                    const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
-                                    int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
-                                    size_t ws_m_bytes, void* stream) {
+static int lloyd_run_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
+                          int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
+                          const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
+                          const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                          int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
+                          size_t ws_m_bytes, void* stream, const LloydXch* xch) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_run");
     SCD_REQUIRE(C_start && C_ring && stats_ring && lab_ring && best_labels && best_C && result_host, "scd_kmeans_lloyd_run: null argument");
     SCD_REQUIRE(max_iter >= 1 && n_u > 0 && n_cat >= n_u && (n_cat == n_u || labels_lab), "scd_kmeans_lloyd_run: bad arguments");
@@ -2881,7 +2915,7 @@ extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* 
         seq_of[it & 1] = h->run_seq;
         const int rc = lloyd_step_delta_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, lab_ring + (size_t)(it % 3) * n_cat, labels_prev, c_in,
                                              c_out, sums, counts, sums_lab, counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m,
-                                             ws_m_bytes, stream, h->run_dev + (it & 1) * 8, h->run_seq);
+                                             ws_m_bytes, stream, h->run_dev + (it & 1) * 8, h->run_seq, 0, xch);
         if (rc) return rc;
         ++launched;
         delta_steps += full ? 0 : 1;
@@ -2906,6 +2940,35 @@ extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* 
     result_host[2] = (double)delta_steps;
     result_host[3] = (double)launched;
     return SCD_OK;
+}
+
+extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
+                                    int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
+                                    const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
+                                    const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                                    int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
+                                    size_t ws_m_bytes, void* stream) {
+    return lloyd_run_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, lab_ring, labels_prev, C_start, C_ring, sums, counts, sums_lab,
+                          counts_lab, sumsq4, stats_ring, max_iter, tol, best_labels, best_C, result_host, ws_e, ws_e_bytes, ws_m, ws_m_bytes,
+                          stream, nullptr);
+}
+
+// The same loop over a row shard (one process per GPU): sums / counts / sums_lab / counts_lab / sumsq4 semantics as above, but
+// sums_lab / counts_lab / sumsq4 are the GLOBAL ones (the caller reduces them once per fit) and every iteration's [sums | counts] go
+// through `exchange` before the centres are formed, so every rank forms the same centres, shift and inertia and takes the same
+// stop / keep decisions; fresh-or-incremental M-step and the E-step hints stay per-rank choices (same bits either way).
+extern "C" int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                            int64_t n_cat, int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
+                                            const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
+                                            const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                                            int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes,
+                                            void* ws_m, size_t ws_m_bytes, void* stream, double* xbuf, scd_exchange_fn exchange,
+                                            void* exchange_ctx) {
+    SCD_REQUIRE(xbuf && exchange, "scd_kmeans_lloyd_run_sharded: null exchange buffer / callback");
+    const LloydXch x = {xbuf, exchange, exchange_ctx};
+    return lloyd_run_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, lab_ring, labels_prev, C_start, C_ring, sums, counts, sums_lab,
+                          counts_lab, sumsq4, stats_ring, max_iter, tol, best_labels, best_C, result_host, ws_e, ws_e_bytes, ws_m, ws_m_bytes,
+                          stream, &x);
 }
 
 extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,

@@ -60,8 +60,8 @@ class HipBackend:
     def finalize(self, sums, counts, c_old, data=None):
         return self.ops.kmeans_finalize(sums, counts, c_old, data=data)
 
-    def lloyd_buffers(self, data_u, cat, cat16, k):
-        return self.ops.LloydBuffers(data_u, cat, cat16, k)
+    def lloyd_buffers(self, data_u, cat, cat16, k, dd=None):
+        return self.ops.LloydBuffers(data_u, cat, cat16, k, dd)
 
     def sum_f32(self, x):
         return self.ops.sum_f32(x)
@@ -101,8 +101,8 @@ class _Dist:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    def allreduce_(self, t):
-        self.d.all_reduce(t, op=self.d.ReduceOp.SUM, group=self.group)
+    def allreduce_(self, t, op="sum"):
+        self.d.all_reduce(t, op={"sum": self.d.ReduceOp.SUM, "max": self.d.ReduceOp.MAX, "min": self.d.ReduceOp.MIN}[op], group=self.group)
         return t
 
     def allgather(self, t):
@@ -337,8 +337,10 @@ class KMeansEngine:
         be = self._be()
         cat16 = be.exact_f16(cat) if hasattr(be, "exact_f16") else None
         bufs = None
-        if (not self.constrained and cat.is_cuda and self._dist() is None and hasattr(be, "lloyd_buffers")):
-            bufs = be.lloyd_buffers(data_u, cat, cat16, self.k)
+        if (not self.constrained and cat.is_cuda and hasattr(be, "lloyd_buffers")):
+            # (under a process group too: the buffers then carry the group's exchange, and every rank learns whether ALL shards qualify
+            # for the C-side loop - collectives inside, so every rank must get here)
+            bufs = be.lloyd_buffers(data_u, cat, cat16, self.k, self._dist())
         return dict(cat16=cat16, bufs=bufs)
 
     def _lloyd(self, data_u, cat, labels, l_num, centers, cat16=None, bufs=None):
@@ -390,6 +392,17 @@ class KMeansEngine:
         # without a process group the three calls of an iteration go out as ONE (scd_kmeans_lloyd_step): the Python call overhead
         # of an iteration (185 us) otherwise exceeds its device time (105 us)
         fused = None
+        if (dd is not None and bufs is not None and getattr(bufs, "inc", False) and getattr(bufs, "dd", None) is not None
+                and os.environ.get("SCD_LLOYD_RUN", "1") != "0"):
+            # a row shard whose ranks ALL qualify for the exact incremental M-step: the loop below behind one C call per restart
+            # (scd_kmeans_lloyd_run_sharded), the packed all-reduce of an iteration handed in as a callback; same decisions on every rank
+            bufs.lab32[:l_num] = labels[:l_num]
+            bufs.c0.copy_(centers)
+            lab, inertia, cen, n_done, n_delta, n_launched = bufs.run(self.max_iterations, self.tolerance)
+            self.stats["estep_calls"] += n_launched
+            self.stats["delta_steps"] = self.stats.get("delta_steps", 0) + n_delta
+            self.stats["sharded_runs"] = self.stats.get("sharded_runs", 0) + 1
+            return lab.to(labels.dtype), inertia, cen, n_done
         if dd is None and hasattr(be, "lloyd_buffers"):
             fused = bufs if bufs is not None else be.lloyd_buffers(data_u, cat, cat16, self.k)
             fused.lab32[:l_num] = labels[:l_num]

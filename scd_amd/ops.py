@@ -250,15 +250,27 @@ def kmeans_mstep(x, labels32, c_old, k, split=0, x16=None):
     return sums, counts, inertia
 
 
+def _dd_add(a, b):
+    """(hi, lo) + (hi, lo) in double-double (Knuth's two-sum on the high parts); host floats."""
+    s_ = a[0] + b[0]
+    bb = s_ - a[0]
+    e = (a[0] - (s_ - bb)) + (b[0] - bb)
+    e += a[1] + b[1]
+    hi = s_ + e
+    return hi, e - (hi - s_)
+
+
 class LloydBuffers:
     """Device buffers of KMeansEngine's Lloyd loop through scd_kmeans_lloyd_step[_delta]: two sets (the host reads set i while the
     device fills set i + 1), allocated once per fit.  With an exact fp16 copy of the rows (`cat16`) the M-step can run
     incrementally (`step_delta`: sums / counts updated with the rows whose label changed, inertia from the sums)."""
 
-    def __init__(self, data_u, cat, cat16, k):
+    def __init__(self, data_u, cat, cat16, k, dd=None):
+        """dd: the process group's exchange object (scd_amd.kmeans._Dist: allreduce_(t, op), allgather(t)) when `cat` is one rank's row
+        shard - only `run` is shard-aware (scd_kmeans_lloyd_run_sharded), and only when EVERY rank's rows qualify (self.inc)."""
         dev = cat.device
         n_cat, d = cat.shape
-        self.data, self.cat, self.cat16, self.k = data_u, cat, cat16, k
+        self.data, self.cat, self.cat16, self.k, self.dd = data_u, cat, cat16, k, dd
         self.lab32 = torch.empty(n_cat, dtype=torch.int32, device=dev)
         self.c = [torch.empty((k, d), dtype=torch.float32, device=dev) for _ in range(2)]
         # a run's initial centres get a buffer of their own: the hand-over of scd_kmeans_finalize is keyed on the centre POINTER, and
@@ -275,8 +287,32 @@ class LloydBuffers:
         # incremental exact M-step: every float64 cluster sum must be exact, i.e. rows * max|x| * 2^24 < 2^53 on top of the exact fp16
         # copy (unit-scale features: 1e5 * 1 against 5e8; fp16 values near 65504 in big clusters, or infinities, take the fresh M-step)
         amax = getattr(cat16, "scd_absmax", float("inf")) if cat16 is not None else float("inf")
-        self.inc = (cat16 is not None and k <= 8192 and n_cat * amax < 2.0 ** 29 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0")
+        n_glob = n_cat
+        if dd is not None:
+            # the bound is on the GLOBAL cluster sums, and all ranks must take the same path (its collectives differ from the other's):
+            # [rows] summed, [max|x|, "my rows do not qualify"] maximised
+            tot = dd.allreduce_(torch.tensor([float(n_cat)], dtype=torch.float64, device=dev))
+            bad = cat16 is None or not np.isfinite(amax) or data_u.n <= 0
+            mx = dd.allreduce_(torch.tensor([0.0 if bad else float(amax), 1.0 if bad else 0.0], dtype=torch.float64, device=dev), op="max")
+            tot_h, mx_h = tot.cpu().numpy(), mx.cpu().numpy()
+            n_glob, amax = float(tot_h[0]), (float("inf") if mx_h[1] > 0 else float(mx_h[0]))
+        self.inc = (cat16 is not None and k <= 8192 and n_glob * amax < 2.0 ** 29 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0")
         if self.inc:
+            if dd is not None:
+                self.xbuf = torch.empty(k * d + 2 * k, dtype=torch.float64, device=dev)     # [sums | counts as float64 | int64 counts]
+                self._xch_err = None
+                view = self.xbuf[: k * d + k]
+
+                def _cb(ctx, buf, n_doubles, stream):
+                    # called by scd_kmeans_lloyd_run_sharded between an iteration's M-step and its finalize launch, on the stream the
+                    # kernels are enqueued on (torch's current stream, which is what dist.all_reduce orders itself against)
+                    try:
+                        dd.allreduce_(view)
+                        return 0
+                    except BaseException as e:          # never let an exception unwind through the C frames
+                        self._xch_err = e
+                        return 1
+                self._xch_cb = _lib.EXCHANGE_FN(_cb)
             self.lab_prev = torch.full((n_cat,), -1, dtype=torch.int32, device=dev)
             self.sumsq = torch.empty(4, dtype=torch.float64, device=dev)
             self.sums_lab = self.counts_lab = None
@@ -303,8 +339,26 @@ class LloydBuffers:
         n_cat, d = self.cat.shape
         l_num = n_cat - self.data.n
         check(_L().scd_kmeans_sumsq(handle(), ptr(self.cat16), None, n_cat, d, l_num, ptr(self.sumsq), stream_ptr()))
-        if l_num > 0:
-            s, c, _ = kmeans_mstep(self.cat[:l_num], self.lab32[:l_num].contiguous(), None, self.k, 0, x16=self.cat16[:l_num])
+        dd = self.dd
+        any_lab = l_num > 0
+        if dd is not None:
+            # global sums of squares: the ranks' double-double pairs added in rank order on the host (once per fit); global sums /
+            # counts of the labelled rows (exact sums: any order)
+            parts = dd.allgather(self.sumsq).cpu().numpy()
+            acc = [(0.0, 0.0), (0.0, 0.0)]
+            for r in range(parts.shape[0]):
+                acc = [_dd_add(acc[0], (float(parts[r, 0]), float(parts[r, 1]))), _dd_add(acc[1], (float(parts[r, 2]), float(parts[r, 3])))]
+            self.sumsq.copy_(torch.tensor([acc[0][0], acc[0][1], acc[1][0], acc[1][1]], dtype=torch.float64))
+            any_lab = bool(dd.allreduce_(torch.tensor([float(l_num)], dtype=torch.float64, device=self.cat.device)).item() > 0)
+        if any_lab:
+            if l_num > 0:
+                s, c, _ = kmeans_mstep(self.cat[:l_num], self.lab32[:l_num].contiguous(), None, self.k, 0, x16=self.cat16[:l_num])
+            else:
+                s = torch.zeros((self.k, d), dtype=torch.float64, device=self.cat.device)
+                c = torch.zeros(self.k, dtype=torch.int64, device=self.cat.device)
+            if dd is not None:
+                dd.allreduce_(s)
+                dd.allreduce_(c)
             self.sums_lab, self.counts_lab = s.contiguous(), c.contiguous()
         self._fit_ready = True
 
@@ -331,11 +385,20 @@ class LloydBuffers:
         n_cat = self.cat.shape[0]
         best_lab = torch.empty(n_cat, dtype=torch.int32, device=self.cat.device)
         best_c = torch.empty((self.k, d.d), dtype=torch.float32, device=self.cat.device)
-        check(_L().scd_kmeans_lloyd_run(handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), n_cat, d.d, self.k,
-                                        ptr(self.lab32) if n_cat > d.n else None, ptr(self.lab_ring), ptr(self.lab_prev), ptr(self.c0),
-                                        ptr(self.c_ring), ptr(self.sums), ptr(self.counts), ptr(self.sums_lab), ptr(self.counts_lab),
-                                        ptr(self.sumsq), ptr(self.stats_ring), int(max_iter), float(tol), ptr(best_lab), ptr(best_c),
-                                        self.result.ctypes.data, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr()))
+        args = (handle(), ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), n_cat, d.d, self.k,
+                ptr(self.lab32) if n_cat > d.n else None, ptr(self.lab_ring), ptr(self.lab_prev), ptr(self.c0),
+                ptr(self.c_ring), ptr(self.sums), ptr(self.counts), ptr(self.sums_lab), ptr(self.counts_lab),
+                ptr(self.sumsq), ptr(self.stats_ring), int(max_iter), float(tol), ptr(best_lab), ptr(best_c),
+                self.result.ctypes.data, ptr(self.ws_e), self.nb_e, ptr(self.ws_m), self.nb_m, stream_ptr())
+        if self.dd is None:
+            check(_L().scd_kmeans_lloyd_run(*args))
+        else:
+            # a row shard: every iteration's [sums | counts] go through the group's all-reduce (the callback) before the centres are formed
+            self._xch_err = None
+            rc = _L().scd_kmeans_lloyd_run_sharded(*args, ptr(self.xbuf), self._xch_cb, None)
+            if self._xch_err is not None:
+                raise self._xch_err
+            check(rc)
         r = self.result
         return best_lab, np.float32(r[0]), best_c, int(r[1]), int(r[2]), int(r[3])
 

@@ -27,7 +27,8 @@ def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device("cuda", local % torch.cuda.device_count())
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    backend = os.environ.get("SCD_TEST_BACKEND", "nccl")       # "gloo": several ranks sharing ONE GPU (RCCL refuses a duplicate device)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from oracle import synth, naming_oracle as no
     from scd_amd import ops, naming, pipeline
     from scd_amd.kmeans import KMeansEngine
@@ -53,6 +54,28 @@ def main():
     ref = cen.clone()
     dist.broadcast(ref, 0)
     assert torch.equal(cen, ref), "centres must be bit-identical on every rank"
+    # ---- (1b) fp16-exact rows (what the encoders deliver): the sharded fit runs its Lloyd loops behind scd_kmeans_lloyd_run_sharded (the
+    # packed all-reduce handed in as a callback) and is BIT-identical to the single-rank fit - exact sums do not depend on the sharding
+    x16 = x.astype(np.float16).astype(np.float32)
+    u, l = x16[~mask_lab], x16[mask_lab]
+    one = KMeansEngine(k=k, max_iterations=8, n_init=3, random_state=5)
+    one.fit_mix(T(u), T(l), T(lt))
+    shd = KMeansEngine(k=k, max_iterations=8, n_init=3, random_state=5, group=grp)
+    shd.fit_mix(T(u[su]), T(l[sl]), T(lt[sl]))
+    assert shd.stats.get("sharded_runs", 0) == 3, "the sharded C loop did not run: %r" % (shd.stats,)
+    full, mine = one.labels_.cpu().numpy(), shd.labels_.cpu().numpy()
+    assert np.array_equal(mine[:n_ls], full[:n_l][sl]) and np.array_equal(mine[n_ls:], full[n_l:][su]), "exact rows: sharded labels differ"
+    assert torch.equal(shd.cluster_centers_, one.cluster_centers_), "exact rows: centres must be bit-identical to the single-rank fit"
+    # (n_iter_ of fit_mix is the reference's stale labelled-row index, sskm_constrained.py:104,139 - a per-shard number by construction)
+    assert float(shd.inertia_) == float(one.inertia_), (float(shd.inertia_), float(one.inertia_))
+    # the unsupervised fit (no labelled rows) through the same loop
+    one = KMeansEngine(k=k, max_iterations=8, n_init=2, random_state=6)
+    one.fit(T(u))
+    shd = KMeansEngine(k=k, max_iterations=8, n_init=2, random_state=6, group=grp)
+    shd.fit(T(u[su]))
+    assert shd.stats.get("sharded_runs", 0) == 2
+    assert np.array_equal(shd.labels_.cpu().numpy(), one.labels_.cpu().numpy()[su]) and torch.equal(shd.cluster_centers_, one.cluster_centers_)
+    assert float(shd.inertia_) == float(one.inertia_) and shd.n_iter_ == one.n_iter_, (float(shd.inertia_), float(one.inertia_), shd.n_iter_, one.n_iter_)
     # ---- (2) sharded vote loop == single-rank vote loop
     nv, dv, kv, vv = 4800, 512, 12, 2100
     xv, yv, cv = synth.clustered_features(nv, dv, kv, seed=31, center_seed=32, noise=0.9)
@@ -68,6 +91,12 @@ def main():
     cand2, up2, tr2 = pipeline.vote_loop_unsup_sharded(idx[sv], preds0[sv], f[sv], wt, nouns, kv, 10, 2, grp, max_iter=50)
     assert cand1 == cand2 and len(tr1) == len(tr2), "sharded vote loop: candidate names differ"
     assert np.array_equal(np.asarray(up1)[sv], np.asarray(up2)), "sharded vote loop: re-classified rows differ"
+    if backend != "nccl":
+        torch.cuda.synchronize()
+        dist.barrier()
+        print("rank %d ok" % rank, flush=True)
+        dist.destroy_process_group()
+        return
     # ---- (3) the C entry points over RCCL
     uid = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:

@@ -1558,6 +1558,26 @@ def test_multi_rank_rccl(ops):
         assert "rank %d ok" % rank in r.stdout
 
 
+def test_two_ranks_one_gpu_sharded_kmeans(ops):
+    """The same worker as two ranks SHARING this box's one GPU (gloo collectives on device tensors; RCCL refuses a duplicate device):
+    the sharded SSKM / K-Means fits - lock-step seeding over the three all-gathers, Lloyd loops behind scd_kmeans_lloyd_run_sharded
+    with the group's all-reduce as the exchange callback - equal the single-rank fits bit for bit on fp16-exact rows, and the sharded
+    vote loop reproduces the single-rank trace.  Two child processes (never an exec of this one)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", SCD_TEST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_rccl_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    for rank in range(2):
+        assert "rank %d ok" % rank in r.stdout
+
+
 def test_c4_shape_sskm_k1000(ops):
     """BASELINE configs[3] per-GPU shard (main_unsup.py:350 with --n_cluster 1000): N = 160,146 CLIP-width rows, K = 1000.
     Full-size properties of the single-pass E-step and of one fused Lloyd step - labels = the stand-alone E-step's, exact

@@ -6,6 +6,6 @@ SCD_DIST_BACKEND=gloo timeout -k 10 900 python bench.py --gpus 2 --steps 1 --war
 echo "rc=$rc"; tail -n 5 $O/rehearsal.err
 python - <<PY
 import json
-d=json.load(open("$O/bench_gpus2_gloo_rehearsal.json"))
+d=json.loads([l for l in open("$O/bench_gpus2_gloo_rehearsal.json") if l.startswith("{")][-1])   # gloo prints its own lines to stdout
 print(d["n_gpus"], d["value"], d["stage_ms_per_step"], d["synthetic_name_accuracy"])
 PY
