@@ -5,8 +5,13 @@ the default of scripts/evaluate_unsupervised.sh), on the HIP k-means kernels ins
 Which scikit-learn: /root/reference/requirements.txt pins scikit-learn 1.0.2; this image has 1.7.2.  The two differ in what the
 reference's call means, so the class takes `sklearn_compat` (default: the reference's pin; env SCD_SKLEARN_COMPAT overrides):
   * "1.0.2" (default): n_init defaults to 10 starts on ONE RandomState, the first k-means++ centre is `random_state.randint(n)`,
-    a start replaces the best when `inertia < best * (1 - 1e-6)`.  Restated from the public source; that version is not
-    installed here, so this mode is checked against the oracle's restatement only ("parity unpinned" for the seeding stream);
+    a start replaces the best when `inertia < best * (1 - 1e-6)`.  That version is not installed here, but the reference vendors
+    its seeding routine: `_k_init` of /root/reference/local_utils/k_means_constrained/sklearn_import/cluster/k_means_.py:33-132 (the
+    0.19 source, same algorithm and stream consumption as 1.0.2's `_kmeans_plusplus`).  oracle/gen_golden.py runs THAT function on
+    seeded inputs (ten starts per case, BASELINE configs[0]'s 4,500 x 768, K = 200 among them) and the picks are committed in
+    tests/golden/kmeans_sklearn.npz: the oracle (tests/test_oracle_golden.py) and the HIP lock-step seeding
+    (test_sklearn_102_seeding_matches_reference_k_init) reproduce them pick for pick.  The Lloyd rules of the mode are restated
+    from the public 1.0.2 source;
   * "1.7.2": n_init 'auto' -> 1 start for k-means++, first centre `random_state.choice(n, p=uniform)`, a start replaces the
     best when its inertia is smaller and its clustering differs (`_is_same_clustering`).  Pinned against scikit-learn 1.7.2
     itself: `kmeans_plusplus` picks, the default call's labels and the n_init=10 call's labels (tests/golden/kmeans_sklearn.npz).
