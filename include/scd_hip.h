@@ -49,6 +49,10 @@ size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k);
 int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
                  int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws, size_t ws_bytes,
                  void* stream);
+/* argmax re-classification over the K candidate names (main_unsup.py:601-614, main_ptsup.py:668-676, get_clip_preds_fast
+ * main_ptsup.py:78-99): idx_out int64 [n], val_out float32 [n] = scd_sim_topk with k = 1 on the raw logits (ws: scd_sim_topk_ws_bytes(n, d, v, 1)). */
+int scd_sim_argmax(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int64_t* idx_out,
+                   float* val_out, void* ws, size_t ws_bytes, void* stream);
 /* W [r,c] fp16 -> Wt [c,r]  (zeroshot_weights [512,V] -> name-major) */
 int scd_transpose_f16(scd_handle h, const void* in, int64_t r, int64_t c, void* out, void* stream);
 /* out[i,:] = Wt[idx[i],:]  (the `zeroshot_weights[:, nouns.index(n)]` gather, main_unsup.py:601-602) */

@@ -2240,3 +2240,11 @@ extern "C" int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
+
+// SURVEY.md 8b names the re-classification `argmax(scale * F @ Wt^T, -1)` (main_unsup.py:601-614, main_ptsup.py:668-676) as an entry
+// point of its own: it is scd_sim_topk with k = 1 on the raw logits (same kernels, same tie rule: the lowest index wins).
+extern "C" int scd_sim_argmax(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int64_t* idx_out,
+                              float* val_out, void* ws, size_t ws_bytes, void* stream) {
+    return scd_sim_topk(h, F, Wt, n, d, v, scale, 1, SCD_SIM_RAW, idx_out, val_out, nullptr, ws, ws_bytes, stream);
+}
+

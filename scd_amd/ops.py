@@ -125,9 +125,18 @@ def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
 
 
 def sim_argmax(f, wsel_t, scale=100.0):
-    """argmax(scale * f @ wsel_t.T, -1) (main_unsup.py:603-614)."""
-    idx, val = sim_topk(f, wsel_t, 1, "raw", scale)
-    return idx[:, 0], val[:, 0]
+    """argmax(scale * f @ wsel_t.T, -1) (main_unsup.py:603-614): scd_sim_argmax.  Returns (idx int64 [n], val float32 [n])."""
+    _need_cuda(f, wsel_t)
+    f = f.to(torch.float16).contiguous()
+    wt = wsel_t.to(torch.float16).contiguous()
+    n, d = f.shape
+    v = wt.shape[0]
+    idx = torch.empty(n, dtype=torch.int64, device=f.device)
+    val = torch.empty(n, dtype=torch.float32, device=f.device)
+    nb = _L().scd_sim_topk_ws_bytes(n, d, v, 1)
+    ws = _ws(nb, f.device)
+    check(_L().scd_sim_argmax(handle(), ptr(f), ptr(wt), n, d, v, float(scale), ptr(idx), ptr(val), ptr(ws), nb, stream_ptr()))
+    return idx, val
 
 
 def prompt_pool(emb, n_names, t_per, out, col0):
