@@ -384,6 +384,61 @@ def secondary_rooflines(out, wt, dev):
     return res
 
 
+class PowerSampler:
+    """Board power / shader clock of THIS rank's GPU while the timed steps run, read from the amdgpu hwmon files (read-only sysfs: power1_input
+    in microwatts, power1_cap, freq1_input = sclk in Hz) by a host thread every 0.25 s.  Context for the roofline fraction, not part of the
+    metric: the MI355X holds the encoder at its board power cap and lowers the clock to do so (docs/design/encoder_time_budget.md).
+    Returns None when the device's PCI address or its hwmon directory cannot be found."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.dir = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            cand = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            if cand and os.path.exists(os.path.join(cand[0], "power1_input")):
+                self.dir, self.bdf = cand[0], bdf
+        except Exception:
+            self.dir = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            w, hz = self._read("power1_input"), self._read("freq1_input")
+            if w is not None:
+                self.samples.append((w / 1e6, (hz or 0.0) / 1e6))
+            self._stop.wait(0.25)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        if not self.samples:
+            return None
+        w = sorted(x[0] for x in self.samples)
+        f = [x[1] for x in self.samples if x[1] > 0]
+        cap = self._read("power1_cap")
+        return {"source": "amdgpu hwmon power1_input / freq1_input of %s, every 0.25 s over the timed steps" % self.bdf, "samples": len(w),
+                "median_w": round(w[len(w) // 2], 1), "max_w": round(w[-1], 1), "cap_w": None if cap is None else round(cap / 1e6, 1),
+                "sclk_mhz_median": round(sorted(f)[len(f) // 2], 0) if f else None}
+
+
 def cpu_baseline_child():
     """cpu_baseline() in a child process of its own: the C restatement is a host library built elsewhere, and whatever goes wrong in
     it (an illegal instruction, a crash in OpenMP) must not take the measured line with it."""
@@ -464,11 +519,15 @@ def main():
         out = step(i, False)
     barrier()
     model.visual.enc.timing(True)
+    power = PowerSampler(local_rank) if rank == 0 else None       # a host thread reading sysfs: nothing enters the stream
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(100 + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    power = power.stop() if power else None
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
@@ -499,6 +558,7 @@ def main():
             "encode_tflops": round(args.images * FLOP_PER_IMAGE / max(enc_s, 1e-9) / 1e12, 1),
             "vote_iters": out["vote_iters"], "synthetic_name_accuracy": round(name_hits, 4),
             "roofline": roof,
+            "board_power": power,
         }
         line["secondary_rooflines"] = secondary_rooflines(out, wt, dev)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_child()
