@@ -4,9 +4,10 @@ __graft_entry__.smoke() and main_unsup.py --synthetic.  Everything numeric insid
 included: scd_select_rows); torch allocates, uploads the row numbers and carries the collectives.
 
 Multi-GPU: images (and their features) are sharded over ranks; W is replicated; K-Means exchanges one packed
-all-reduce per Lloyd iteration; the vote histograms each rank's own rows into a dense [clusters, V] table, all-reduces it
-(counts: sum, first-seen positions: min), rank 0 solves the assignment and broadcasts the K candidate names, and every rank
-re-classifies its own shard (SURVEY.md 8e).
+all-reduce per Lloyd iteration; the vote either histograms each rank's own rows into a dense [clusters, V] table and all-reduces it
+(counts: sum, first-seen positions: min) or - cheaper at every BASELINE size - gathers the rows' name lists once and their
+cluster ids per iteration to rank 0's histogram; rank 0 solves the assignment and broadcasts the K candidate names, and every rank
+re-classifies its own shard.
 """
 import numpy as np
 import torch
@@ -72,14 +73,20 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
                 kmeans=km)
 
 
-def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50, be=None):
+def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50, be=None, exchange="auto"):
     """main_unsup.py:568-614 over row shards, with the exchange of SURVEY.md 8e.  Per iteration every rank histograms ITS rows into
     a dense [clusters, V] table (counts, first-seen position in global row order), the tables are all-reduced (sum / min), and
     most_common(m) of every cluster is read off the reduced table - what Counter.most_common gives on the concatenated rows.  Rank 0
     solves the assignment (Munkres, host) and broadcasts the voted names, the assignment and the K candidate columns; every rank
     re-classifies only its own rows.  O(N / world) device work per rank and iteration; the collectives carry 12 bytes per
     (cluster, name) pair, whatever N is.  `be` = the op set (default scd_amd.ops; tests/test_dist_gloo.py passes an oracle-backed
-    stand-in)."""
+    stand-in).
+
+    exchange = "table" is the form above; "rows" exchanges the ROWS instead: the top-k name rows never change during the loop, so
+    they are all-gathered once (8 k bytes per row), every iteration all-gathers only the rows' current cluster ids (8 bytes per
+    row) and rank 0 histograms all rows itself - the same counts and first-seen positions by construction.  "auto" takes "rows"
+    while an iteration's ids are fewer bytes than its tables (N_global * 8 <= clusters * V * 12: every BASELINE config - C2: 6 MB
+    against 25 MB per iteration at 8 x 95k rows, C4 (K = 1000): 10 MB against 252 MB) and "table" beyond (N in the tens of millions)."""
     import copy
     import torch.distributed as dist
     from .local_utils.clip_lang_util import assign_name
@@ -101,15 +108,40 @@ def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, n
     ns = torch.tensor([n_slots], dtype=torch.int64, device=dev)
     dist.all_reduce(ns, op=dist.ReduceOp.MAX, group=group)
     n_slots = int(ns.item())
+    n_rows = [int(x) for x in lens]
+    n_glob = sum(n_rows)
+    if exchange == "auto":
+        exchange = "rows" if n_glob * 8 <= n_slots * v * 12 else "table"
+    assert exchange in ("rows", "table")
+    if exchange == "rows":
+        # the rows' top-k names, gathered ONCE in rank order (padded to the longest shard; a rank may own no row)
+        mx = max(max(n_rows), 1)
+        pad = torch.zeros((mx, name_idx.shape[1]), dtype=torch.int64, device=dev)
+        pad[: name_idx.shape[0]] = name_idx
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        name_idx_all = torch.cat([parts[r][: n_rows[r]] for r in range(world)]).contiguous()
+        ppad = torch.zeros(mx, dtype=torch.int64, device=dev)
+        pparts = [torch.empty_like(ppad) for _ in range(world)]
     while set(cur) != set(prev) and len(trace) < max_iter:
-        # the clusters present anywhere (python-set order of the ids, main_unsup.py:573)
-        present = torch.bincount(u_preds, minlength=n_slots).to(torch.int64)
-        dist.all_reduce(present, group=group)
-        clusters = list(set(torch.nonzero(present).reshape(-1).cpu().numpy().tolist()))
-        counts, firsts = be.vote_table(name_idx, top_k, u_preds, clusters, n_slots, row_offset, v)
-        dist.all_reduce(counts, group=group)
-        dist.all_reduce(firsts, op=dist.ReduceOp.MIN, group=group)
-        # rank 0: most_common(m) per cluster off the reduced tables, names voted on, assignment (Munkres); broadcast
+        if exchange == "rows":
+            ppad[: u_preds.shape[0]] = u_preds
+            dist.all_gather(pparts, ppad, group=group)
+            preds_all = torch.cat([pparts[r][: n_rows[r]] for r in range(world)]).contiguous()
+            # the clusters present anywhere (python-set order of the ids, main_unsup.py:573): every rank has all ids
+            present = torch.bincount(preds_all, minlength=n_slots)
+            clusters = list(set(torch.nonzero(present).reshape(-1).cpu().numpy().tolist()))
+            if rank == 0:
+                counts, firsts = be.vote_table(name_idx_all, top_k, preds_all, clusters, n_slots, 0, v)
+        else:
+            # the clusters present anywhere
+            present = torch.bincount(u_preds, minlength=n_slots).to(torch.int64)
+            dist.all_reduce(present, group=group)
+            clusters = list(set(torch.nonzero(present).reshape(-1).cpu().numpy().tolist()))
+            counts, firsts = be.vote_table(name_idx, top_k, u_preds, clusters, n_slots, row_offset, v)
+            dist.all_reduce(counts, group=group)
+            dist.all_reduce(firsts, op=dist.ReduceOp.MIN, group=group)
+        # rank 0: most_common(m) per cluster off the (reduced) tables, names voted on, assignment (Munkres); broadcast
         # [n_voted | voted | ind (pairs)].  (Only rank 0 consumes the top-m lists, so only rank 0 extracts them.)
         nc = len(clusters)
         if rank == 0:

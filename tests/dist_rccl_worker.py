@@ -88,9 +88,12 @@ def main():
     preds0 = T(np.where(rs.rand(nv) < 0.8, (yv * 7 + 2) % kv, rs.randint(0, kv, size=nv)).astype(np.int64))
     cand1, up1, tr1 = naming.vote_loop_unsup(idx, preds0, f, wt, nouns, kv, 10, 2, max_iter=50)
     sv = shard(nv, rank, world)
-    cand2, up2, tr2 = pipeline.vote_loop_unsup_sharded(idx[sv], preds0[sv], f[sv], wt, nouns, kv, 10, 2, grp, max_iter=50)
-    assert cand1 == cand2 and len(tr1) == len(tr2), "sharded vote loop: candidate names differ"
-    assert np.array_equal(np.asarray(up1)[sv], np.asarray(up2)), "sharded vote loop: re-classified rows differ"
+    for exchange in ("table", "rows"):          # the dense-table exchange of SURVEY 8e and the rows exchange "auto" picks at these sizes
+        cand2, up2, tr2 = pipeline.vote_loop_unsup_sharded(idx[sv], preds0[sv], f[sv], wt, nouns, kv, 10, 2, grp, max_iter=50, exchange=exchange)
+        assert cand1 == cand2 and len(tr1) == len(tr2), "sharded vote loop (%s): candidate names differ" % exchange
+        assert np.array_equal(np.asarray(up1)[sv], np.asarray(up2)), "sharded vote loop (%s): re-classified rows differ" % exchange
+        for a, b in zip(tr1, tr2):
+            assert np.array_equal(a["voted"], b["voted"]) and np.array_equal(np.asarray(a["ind"]), np.asarray(b["ind"])), exchange
     if backend != "nccl":
         torch.cuda.synchronize()
         dist.barrier()

@@ -146,7 +146,7 @@ def test_sharded_vocabulary_allgather_keeps_name_order():
     assert res[0].shape == (8, 37) and np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
 
 
-def _vote_worker(rank, world, port, q):
+def _vote_worker(rank, world, port, q, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -158,7 +158,7 @@ def _vote_worker(rank, world, port, q):
         sl = slice(0, cut) if rank == 0 else slice(cut, None)
         cand, up, tr = pipeline.vote_loop_unsup_sharded(torch.from_numpy(idx[sl]), torch.from_numpy(preds0[sl]), torch.from_numpy(f[sl]),
                                                         torch.from_numpy(np.ascontiguousarray(w.T)), nouns, k, 10, 2, dist.group.WORLD,
-                                                        be=OracleNamingOps())
+                                                        be=OracleNamingOps(), exchange=exchange)
         q.put((rank, cand, up, [(t["voted"], t["ind"], t["cand"]) for t in tr]))
     finally:
         dist.destroy_process_group()
@@ -176,15 +176,17 @@ def _vote_case():
     return f, w, synth.nouns_list(v), idx, preds0, k
 
 
-def test_sharded_vote_loop_equals_single_process():
+@pytest.mark.parametrize("exchange", ["table", "rows", "auto"])
+def test_sharded_vote_loop_equals_single_process(exchange):
     """pipeline.vote_loop_unsup_sharded over two row shards = the single-process oracle loop (main_unsup.py:568-614): same voted
     lists, assignments and candidate names on every iteration, and each rank's re-classified rows are its slice of the global
-    predictions."""
+    predictions - with the dense [clusters, V] table exchange and with the rows exchange (names gathered once, cluster ids
+    per iteration) that "auto" picks at these sizes."""
     from oracle import naming_oracle as no
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_vote_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + os.getpid() % 2000 + {"table": 0, "rows": 2000, "auto": 4000}[exchange]
+    procs = [ctx.Process(target=_vote_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

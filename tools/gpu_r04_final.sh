@@ -21,3 +21,5 @@ pass() { # ctr
 }
 pass FETCH_SIZE && pass WRITE_SIZE && python3 $R/tools/pmc_traffic.py $out/pmc_fc1_FETCH_SIZE $out/pmc_fc1_WRITE_SIZE 786432 3072 768 $out/r04_pmc_fc1.json 3990 | tail -n 30
 rm -rf $out/pmc_fc1_FETCH_SIZE $out/pmc_fc1_WRITE_SIZE
+cd $R
+bash tools/gpu_power_trace.sh > $out/power_trace.log 2>&1; tail -n 3 $out/power_trace.log

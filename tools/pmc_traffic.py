@@ -43,8 +43,8 @@ res = {
     "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 1 --warmup 0 --images 7980 --no-cpu-baseline (two separate passes)",
     "raw": {"FETCH_SIZE": {"full_launches": nf, "avg_kb": f_kb}, "WRITE_SIZE": {"full_launches": nw, "avg_kb": w_kb},
             "im2col_FETCH_SIZE": {"full_launches": nlf, "avg_kb": lf_kb}, "im2col_WRITE_SIZE": {"full_launches": nlw, "avg_kb": lw_kb}},
-    "correction": "FETCH_SIZE x2 for kernels whose loads are 128-byte requests (gfx950 tallies them at 64 B: the guide's correction; same-run check on assemble_visual_kernel below: ratio ~0.5) - the GEMM's LDS-DMA ring fills are whole 128-byte lines; im2col_kernel in the same run, whose reads are 32-byte pieces (<= 64-B requests), is tallied at face value: raw fetch %.1f MB for a %.1f MB read (ratio %.3f); WRITE_SIZE needs no correction: %.1f MB for its %.1f MB of patch rows"
-                  % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, ln_wbytes / 1e6),
+    "correction": "FETCH_SIZE x2: gfx950 tallies every request pattern this library uses at half the bytes read (tools/micro/fetch_calib.hip, profiles/r04_fetch_calib.txt: 1,024-byte wave loads, global_load_lds_dwordx4 fills with 128- and 64-byte row segments, 32-byte pieces: 0.500-0.504); same-run checks below: assemble_visual_kernel raw ratio ~0.5 (= 1.0 x its input after the correction); im2col_kernel raw fetch %.1f MB for a %.1f MB read (raw ratio %.3f, i.e. it fetches %.2f x its input: neighbouring patches re-request the same 128-byte lines); WRITE_SIZE needs no correction: %.1f MB for im2col's %.1f MB of patch rows.  The counter is on the L2's fabric side: Infinity-Cache hits are included"
+                  % (lf_kb * 1024 / 1e6, ln_bytes / 1e6, lf_kb * 1024 / ln_bytes, 2 * lf_kb * 1024 / ln_bytes, lw_kb * 1024 / 1e6, ln_wbytes / 1e6),
     "calibration_128B_requests": cal128,
     "fetch_bytes_per_launch": 2 * f_kb * 1024,
     "write_bytes_per_launch": w_kb * 1024,
