@@ -407,3 +407,49 @@ def test_host_solvers_under_sanitizers(tmp_path):
     subprocess.run(cmd, check=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
+
+
+def test_double_double_add_of_the_sharded_sumsq():
+    """ops._dd_add (the host-side sum of the ranks' double-double sums of squares, once per sharded fit): hi + lo reproduces the exact
+    rational sum of the four parts to ~2^-100 where a plain float64 sum of the high parts loses the low ones."""
+    from fractions import Fraction
+    from scd_amd.ops import _dd_add
+    rs = np.random.RandomState(4)
+    acc, exact = (0.0, 0.0), Fraction(0)
+    for _ in range(64):
+        hi = float(rs.rand() * 10.0 ** rs.randint(-3, 9))
+        lo = float((rs.rand() - 0.5) * hi * 2.0 ** -53)
+        acc = _dd_add(acc, (hi, lo))
+        exact += Fraction(hi) + Fraction(lo)
+    got = Fraction(acc[0]) + Fraction(acc[1])
+    assert abs(got - exact) <= abs(exact) * Fraction(1, 2 ** 96)
+    assert abs(acc[1]) <= abs(acc[0]) * 2.0 ** -52
+
+
+def test_bench_power_sampler_reads_hwmon(tmp_path, monkeypatch):
+    """bench.PowerSampler: the rank's GPU is found through its PCI address, watts / cap / shader clock come from the hwmon files, and a
+    box without them yields None (the bench line then carries "board_power": null)."""
+    import importlib.util
+    import time
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hw = tmp_path / "hwmon3"
+    hw.mkdir()
+    (hw / "power1_input").write_text("1388000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    (hw / "freq1_input").write_text("1837000000\n")
+    import glob as globmod
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x5a, pci_device_id=0))
+    real_glob = globmod.glob
+    monkeypatch.setattr(globmod, "glob", lambda pat, **kw: [str(hw)] if pat.startswith("/sys/bus/pci/devices/0000:5a:00.0/hwmon") else real_glob(pat, **kw))
+    ps = bench.PowerSampler(0)
+    ps.start()
+    time.sleep(0.6)
+    out = ps.stop()
+    assert out and out["median_w"] == 1388.0 and out["cap_w"] == 1400.0 and out["sclk_mhz_median"] == 1837.0 and out["samples"] >= 2
+    monkeypatch.setattr(globmod, "glob", lambda pat, **kw: [])
+    ps = bench.PowerSampler(0)
+    ps.start()
+    assert ps.stop() is None
