@@ -1288,6 +1288,8 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     SCD_REQUIRE(h && X && prep && C && labels_out && ws, "scd_kmeans_estep: null argument");
     { const int rc_ = scd_check_device(h, "scd_kmeans_estep"); if (rc_) return rc_; }
     SCD_REQUIRE(n > 0 && d > 0 && k > 0 && k < 32768 && n < (1ll << 31), "scd_kmeans_estep: bad shape n=%lld d=%d k=%d", (long long)n, d, k);
+    // (the exact re-evaluation stages four rows as float64 in LDS: 32 d + 64 bytes of the 64 KB a launch gets without opting in)
+    SCD_REQUIRE(d <= 2032, "scd_kmeans_estep: d=%d > 2032 is not supported", d);
     SCD_REQUIRE(ws_bytes >= scd_kmeans_estep_ws_bytes(n, d, k), "scd_kmeans_estep: workspace too small");
     hipStream_t st = (hipStream_t)stream_;
     // one-shot hints and the finalize hand-over are consumed by THIS call whichever path it takes (left set by a call that took the
