@@ -189,6 +189,20 @@ int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, const void* pre
                                  const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* best_labels, float* best_C,
                                  double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream,
                                  double* xbuf, scd_exchange_fn exchange, void* exchange_ctx);
+/* The lock-step k-means++ rounds of scd_kpp_seed_lockstep over a ROW SHARD (one process per GPU; sskm_constrained.py:28-44 is
+ * single-process): per round three exchanges - shard sums, shard probability masses, candidate rows - each an all-gather of a few bytes
+ * per restart through `gather(gather_ctx, send, recv, bytes_per_rank, stream)`: rank w's `bytes_per_rank` bytes at `send` must arrive at
+ * recv + w * bytes_per_rank on every rank, in stream order; send / recv lie inside xbuf (device, scd_kpp_seed_sharded_xbuf_bytes).  The
+ * new centres are the rows of their first owner in rank order (float32 values of the global X), written to C_buf[r][m0 + t]; picks_out
+ * int64 [T][R] = 0, or -1 where no shard reported a hit (the reference indexes an empty nonzero() there).  d2 float [R][ld]: this
+ * shard's closest squared distances, updated in place; r_dev float [T][R]: the restarts' uniforms; ws: scd_kpp_seed_sharded_ws_bytes.
+ * X16 (may be NULL): this shard's exact fp16 copy - the update then goes through the MFMA filter as in scd_kpp_seed_lockstep. */
+typedef int (*scd_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+size_t scd_kpp_seed_sharded_ws_bytes(int64_t n, int d, int R);
+size_t scd_kpp_seed_sharded_xbuf_bytes(int d, int R, int world);
+int scd_kpp_seed_lockstep_sharded(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
+                                  const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws, size_t ws_bytes,
+                                  void* stream, void* xbuf, size_t xbuf_bytes, scd_gather_fn gather, void* gather_ctx, int rank, int world);
 /* prep / estep_ws (both may be NULL): the data set's scd_kmeans_prepare buffer and the workspace the NEXT scd_kmeans_estep
  * of these centres will be given (n = its row count).  The blocks that produce the centres then also write their E-step
  * operands into it, and that E-step - same handle, same C_out pointer, same workspace, C_out unmodified in between - skips

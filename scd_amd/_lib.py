@@ -30,6 +30,8 @@ class EncoderDesc(C.Structure):
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 # scd_exchange_fn (include/scd_hip.h): int (*)(void* ctx, double* buf, int64_t n_doubles, void* stream)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+# scd_gather_fn: int (*)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/scd_hip.h
 SIGNATURES = {
@@ -81,6 +83,11 @@ SIGNATURES = {
     "scd_kpp_seed_ws_bytes": (_sz, [_i64, _i, _i]),
     # h, X, X16, n, d, R, d2, ld, r_dev, T, C_buf, k, m0, picks_out, ws, nb, stream
     "scd_kpp_seed_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "scd_kpp_seed_sharded_ws_bytes": (_sz, [_i64, _i, _i]),
+    "scd_kpp_seed_sharded_xbuf_bytes": (_sz, [_i, _i, _i]),
+    # h, X, X16, n, d, R, d2, ld, r_dev, T, C_buf, k, m0, picks_out, ws, nb, stream, xbuf, xbuf_bytes, gather (GATHER_FN), ctx, rank, world
+    "scd_kpp_seed_lockstep_sharded": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz,
+                                           GATHER_FN, _vp, _i, _i]),
     "scd_kpp_greedy_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     # h, X, X16, n, d, R, L, k, first, u, C_buf, picks_out, ws, nb, stream
     "scd_kpp_greedy_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -510,3 +510,128 @@ extern "C" int scd_kmeans_lloyd_run_sk(scd_handle h, const float* X, const void*
     result_host[3] = (double)launched;
     return SCD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// scd_kpp_seed_lockstep_sharded: the rounds of KMeansEngine.kpp_lockstep over a ROW SHARD behind one call (one process per GPU, SURVEY
+// 8e; the reference is single-process: sskm_constrained.py:28-44).  A round needs three exchanges - the shards' sums (-> the float32
+// total that `prob = d2 / d2.sum()` divides by), the shards' probability masses (-> this shard's prefix), the candidate rows (-> the
+// first owner's row) - each an all-gather of a few bytes per restart that the caller supplies as a callback, as the Lloyd loop's
+// all-reduce (scd_kmeans_lloyd_run_sharded).  Same arithmetic, in the same order, as the Python-driven rounds it replaces
+// (scd_amd/kmeans.py: kpp_lockstep), which remain as the A/B and for callers without a callback.
+__global__ void __launch_bounds__(64) kss_total_kernel(const double* __restrict__ recv, int world, int R, double* __restrict__ tot) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    double s = 0.0;
+    for (int w = 0; w < world; ++w) s += recv[(size_t)w * R + r];          // rank order: the same bits on every rank
+    tot[r] = s;
+}
+__global__ void __launch_bounds__(64) kss_prefix_kernel(const double* __restrict__ recv, int rank, int R, double* __restrict__ pre) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    double s = 0.0;
+    for (int w = 0; w < rank; ++w) s += recv[(size_t)w * R + r];
+    pre[r] = s;
+}
+// block r: send[r] = [hit flag | the drawn row] (float32, 1 + d values; a shard without the hit sends row 0 with flag 0, as the mirror does)
+__global__ void __launch_bounds__(256) kss_pack_kernel(const float* __restrict__ X, const long long* __restrict__ idx, int d,
+                                                       float* __restrict__ send) {
+    const int r = blockIdx.x;
+    const long long i = idx[r];
+    const float* row = X + (size_t)(i < 0 ? 0 : i) * d;
+    float* out = send + (size_t)r * (1 + d);
+    if (threadIdx.x == 0) out[0] = i >= 0 ? 1.f : 0.f;
+    for (int j = threadIdx.x; j < d; j += 256) out[1 + j] = row[j];
+}
+// block r: the first rank (in rank order) that reports a hit owns restart r's new centre; none: rank 0's row and picks = -1
+__global__ void __launch_bounds__(256) kss_select_kernel(const float* __restrict__ recv, int world, int R, int d, float* __restrict__ rows,
+                                                         float* __restrict__ slot, long long ldc, long long* __restrict__ pick) {
+    const int r = blockIdx.x;
+    int owner = -1;
+    for (int w = 0; w < world; ++w)
+        if (recv[((size_t)w * R + r) * (1 + d)] > 0.f) { owner = w; break; }
+    const float* src = recv + ((size_t)(owner < 0 ? 0 : owner) * R + r) * (1 + d) + 1;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float v = src[j];
+        rows[(size_t)r * d + j] = v;
+        slot[(size_t)r * ldc + j] = v;
+    }
+    if (threadIdx.x == 0) pick[r] = owner < 0 ? -1 : 0;
+}
+static size_t kss_small_bytes(int d, int R) { return scd_align(8 * (size_t)R) * 3 + scd_align(8 * (size_t)R) + scd_align(4 * (size_t)R * d); }
+extern "C" size_t scd_kpp_seed_sharded_ws_bytes(int64_t n, int d, int R) {
+    return (size_t)R * scd_kpp_draw_ws_bytes(n) + scd_kpp_update_ws_bytes(n, d) + kss_small_bytes(d, R) + 256;
+}
+extern "C" size_t scd_kpp_seed_sharded_xbuf_bytes(int d, int R, int world) {
+    const size_t unit = scd_align(4 * (size_t)R * (1 + d) > 8 * (size_t)R ? 4 * (size_t)R * (1 + d) : 8 * (size_t)R);
+    return unit * (size_t)(1 + world);
+}
+extern "C" int scd_kpp_seed_lockstep_sharded(scd_handle h, const float* X, const void* X16, int64_t n, int d, int R, float* d2, int64_t ld,
+                                             const float* r_dev, int T, float* C_buf, int k, int m0, int64_t* picks_out, void* ws,
+                                             size_t ws_bytes, void* stream_, void* xbuf, size_t xbuf_bytes, scd_gather_fn gather,
+                                             void* gather_ctx, int rank, int world) {
+    SCD_DEVICE_ENTRY(h, "scd_kpp_seed_lockstep_sharded");
+    SCD_REQUIRE(X && d2 && r_dev && C_buf && picks_out && ws && xbuf && gather && n > 0 && d > 0 && R > 0 && ld >= n && T >= 0 && m0 >= 1 &&
+                    m0 + T <= k && world >= 1 && rank >= 0 && rank < world,
+                "scd_kpp_seed_lockstep_sharded: bad arguments");
+    SCD_REQUIRE(ws_bytes >= scd_kpp_seed_sharded_ws_bytes(n, d, R) && xbuf_bytes >= scd_kpp_seed_sharded_xbuf_bytes(d, R, world),
+                "scd_kpp_seed_lockstep_sharded: workspace / exchange buffer too small");
+    hipStream_t st = (hipStream_t)stream_;
+    const size_t draw_nb = (size_t)R * scd_kpp_draw_ws_bytes(n), upd_nb = scd_kpp_update_ws_bytes(n, d);
+    char* w = (char*)ws;
+    void* draw_ws = w;
+    void* upd_ws = w + draw_nb;
+    double* tot = (double*)(w + draw_nb + upd_nb);
+    double* pre = (double*)((char*)tot + scd_align(8 * (size_t)R));
+    double* ps = (double*)((char*)pre + scd_align(8 * (size_t)R));
+    long long* idx = (long long*)((char*)ps + scd_align(8 * (size_t)R));
+    float* rows = (float*)((char*)idx + scd_align(8 * (size_t)R));
+    const size_t unit = scd_kpp_seed_sharded_xbuf_bytes(d, R, world) / (size_t)(1 + world);
+    char* send = (char*)xbuf;
+    char* recv = send + unit;
+    const long long ldc = (long long)k * d;
+    static const int filt_env = getenv("SCD_KPP_FILTER") ? atoi(getenv("SCD_KPP_FILTER")) : 1;
+    const bool filt = X16 && filt_env && muf_shape_ok(n, d, R);
+    bool first_filter = true;
+#define KSS_GATHER(BYTES)                                                                                        \
+    {                                                                                                            \
+        const int rc_ = gather(gather_ctx, send, recv, (int64_t)(BYTES), stream_);                               \
+        if (rc_) {                                                                                               \
+            scd_set_error("scd_kpp_seed_lockstep_sharded: the gather callback failed (%d)", rc_);                \
+            return SCD_ERCCL;                                                                                    \
+        }                                                                                                        \
+    }
+    for (int t = 0; t < T; ++t) {
+        const float* r_t = r_dev + (size_t)t * R;
+        // (1) shard sums -> total (float64 sums added in rank order; the draw rounds it to float32 as the reference's d2.sum())
+        int rc = scd_sum_f32_multi(h, d2, n, ld, R, (double*)send, stream_);
+        if (rc) return rc;
+        KSS_GATHER(8 * (size_t)R)
+        kss_total_kernel<<<(unsigned)scd_cdiv(R, 64), 64, 0, st>>>((const double*)recv, world, R, tot);
+        // (2) shard probability masses -> this shard's prefix
+        rc = scd_kpp_draw_multi(h, d2, n, ld, R, r_t, tot, nullptr, nullptr, (double*)send, draw_ws, draw_nb, stream_);
+        if (rc) return rc;
+        KSS_GATHER(8 * (size_t)R)
+        kss_prefix_kernel<<<(unsigned)scd_cdiv(R, 64), 64, 0, st>>>((const double*)recv, rank, R, pre);
+        // (3) the draw on this shard, its candidate rows -> the first owner's rows
+        rc = scd_kpp_draw_multi(h, d2, n, ld, R, r_t, tot, pre, (int64_t*)idx, nullptr, draw_ws, draw_nb, stream_);
+        if (rc) return rc;
+        kss_pack_kernel<<<R, 256, 0, st>>>(X, idx, d, (float*)send);
+        SCD_LAUNCH_CHECK();
+        KSS_GATHER(4 * (size_t)R * (1 + d))
+        kss_select_kernel<<<R, 256, 0, st>>>((const float*)recv, world, R, d, rows, C_buf + (size_t)(m0 + t) * d, ldc,
+                                             (long long*)(picks_out + (size_t)t * R));
+        SCD_LAUNCH_CHECK();
+        if (t + 1 == T) break;
+        // (4) d2 = min(d2, ||x - new centre||^2): through the MFMA filter once a new centre wins few rows, as the single-process loop
+        if (filt && m0 + t >= 8) {
+            rc = scd_kpp_update_filter(h, X16, n, d, R, rows, d2, ld, first_filter ? 1 : 0, upd_ws, upd_nb, stream_);
+            first_filter = false;
+        } else {
+            rc = scd_kmeans_min_update_multi(h, X, rows, n, d, R, d2, ld, stream_);
+        }
+        if (rc) return rc;
+    }
+#undef KSS_GATHER
+    return SCD_OK;
+}
+

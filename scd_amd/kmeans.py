@@ -81,6 +81,9 @@ class HipBackend:
     def kpp_seed_lockstep(self, data, x16, d2, rv, buf, m0):
         return self.ops.kpp_seed_lockstep(data.x, x16, d2, rv, buf, m0)
 
+    def kpp_seed_lockstep_sharded(self, data, x16, d2, rv, buf, m0, dd):
+        return self.ops.kpp_seed_lockstep_sharded(data.x, x16, d2, rv, buf, m0, dd)
+
     def update_filter(self, data, x16, restarts):
         """The filtered distance update for Python-driven seeding rounds (process groups), or None when the shape is not served."""
         if x16 is None or not self.ops.UpdateFilter.serves(data.n, data.d, restarts):
@@ -118,6 +121,14 @@ class _Dist:
         pad[: t.shape[0]] = t
         allp = self.allgather(pad)
         return torch.cat([allp[r, : lens[r]] for r in range(self.world)]), lens
+
+    def allgather_into(self, out, inp):
+        """rank w's `inp` (flat, equal sizes) -> out[w * len(inp): (w + 1) * len(inp)] on every rank."""
+        try:
+            self.d.all_gather_into_tensor(out, inp, group=self.group)
+        except (RuntimeError, NotImplementedError, AttributeError):       # a backend without the flat form
+            parts = list(out.view(self.world, -1).unbind(0))
+            self.d.all_gather(parts, inp, group=self.group)
 
     def broadcast_(self, t, src):
         self.d.broadcast(t, src=self.d.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
@@ -263,6 +274,13 @@ class KMeansEngine:
         rv = torch.from_numpy(np.ascontiguousarray(rv.T.astype(np.float32))).to(dev)       # [k - m, restarts], one upload
         if dd is None and hasattr(be, "kpp_seed_lockstep") and os.environ.get("SCD_KPP_SEED_RUN", "1") != "0":
             pk = be.kpp_seed_lockstep(data, x16, d2, rv, buf, m)
+            if pk.numel() and bool((pk < 0).any()):
+                raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+            return buf
+        if (dd is not None and hasattr(be, "kpp_seed_lockstep_sharded") and x.is_cuda and os.environ.get("SCD_KPP_SEED_RUN", "1") != "0"):
+            # a row shard: the rounds behind one call as well, the three all-gathers of a round handed in as a callback
+            pk = be.kpp_seed_lockstep_sharded(data, x16, d2, rv, buf, m, dd)
+            self.stats["sharded_seedings"] = self.stats.get("sharded_seedings", 0) + 1
             if pk.numel() and bool((pk < 0).any()):
                 raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
             return buf

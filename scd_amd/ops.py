@@ -563,6 +563,43 @@ def kpp_seed_lockstep(x, x16, d2, rv, buf, m0):
     return picks
 
 
+def kpp_seed_lockstep_sharded(x, x16, d2, rv, buf, m0, dd):
+    """The same rounds over a ROW SHARD behind one call (scd_kpp_seed_lockstep_sharded): the three all-gathers of a round - shard sums,
+    shard probability masses, candidate rows - go out through a callback that runs the process group's all-gather on views of one
+    exchange buffer.  dd: scd_amd.kmeans._Dist (rank, world, allgather_bytes).  Returns the picks, int64 [T, R] (0, or -1 where no
+    shard drew a row)."""
+    _need_cuda(x, d2, rv, buf)
+    t_rounds, rr = rv.shape
+    n, d = x.shape
+    assert d2.shape[0] == rr and buf.shape[0] == rr and buf.shape[2] == d and buf.is_contiguous() and rv.is_contiguous()
+    dev = x.device
+    picks = torch.empty((t_rounds, rr), dtype=torch.int64, device=dev)
+    nb = _L().scd_kpp_seed_sharded_ws_bytes(n, d, rr)
+    ws = _ws(nb, dev)
+    xb = _L().scd_kpp_seed_sharded_xbuf_bytes(d, rr, dd.world)
+    xbuf = torch.empty(int(xb), dtype=torch.uint8, device=dev)
+    base = xbuf.data_ptr()
+    err = []
+
+    def _cb(ctx, send, recv, nbytes, stream):
+        # rank w's nbytes at `send` -> recv + w * nbytes on every rank, in stream order (torch's current stream = the kernels' stream)
+        try:
+            so, ro = send - base, recv - base
+            dd.allgather_into(xbuf[ro: ro + dd.world * nbytes], xbuf[so: so + nbytes])
+            return 0
+        except BaseException as e:            # never unwind through the C frames
+            err.append(e)
+            return 1
+    cb = _lib.GATHER_FN(_cb)
+    rc = _L().scd_kpp_seed_lockstep_sharded(handle(), ptr(x), ptr(x16), n, d, rr, ptr(d2), d2.stride(0), ptr(rv), t_rounds, ptr(buf),
+                                            buf.shape[1], int(m0), ptr(picks), ptr(ws), nb, stream_ptr(), ptr(xbuf), int(xb), cb, None,
+                                            dd.rank, dd.world)
+    if err:
+        raise err[0]
+    check(rc)
+    return picks
+
+
 class UpdateFilter:
     """The distance update of one lock-step seeding round through the MFMA filter (scd_kpp_update_filter), for seedings whose rounds
     are driven from Python (process groups).  One object per seeding: it owns the workspace with the rows' norm table."""

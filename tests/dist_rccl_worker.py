@@ -1,7 +1,8 @@
 """One rank of the multi-GPU check (tests/test_gpu_parity.py::test_multi_rank_rccl): started N times by torch.distributed.run,
 one process per GPU, "nccl" (= RCCL) backend, every kernel through libscd_hip.so.  Each rank holds a contiguous, uneven row shard;
 the sharded results must equal what the same rank computes alone from the full data:
-  * sharded SSKM fit_mix (lock-step seeding over three all-gathers per round, one packed all-reduce per Lloyd iteration),
+  * sharded SSKM fit_mix (lock-step seeding over three all-gathers per round, one packed all-reduce per Lloyd iteration; both loops in
+    C with the collectives as callbacks: scd_kpp_seed_lockstep_sharded, scd_kmeans_lloyd_run_sharded),
   * the sharded vote loop,
   * the C entry points scd_comm_init / scd_allreduce_centroids / scd_allgather_text over RCCL.
 Prints "rank R ok" and exits 0."""
@@ -63,6 +64,7 @@ def main():
     shd = KMeansEngine(k=k, max_iterations=8, n_init=3, random_state=5, group=grp)
     shd.fit_mix(T(u[su]), T(l[sl]), T(lt[sl]))
     assert shd.stats.get("sharded_runs", 0) == 3, "the sharded C loop did not run: %r" % (shd.stats,)
+    assert shd.stats.get("sharded_seedings", 0) == 1, "the sharded seeding rounds did not run behind scd_kpp_seed_lockstep_sharded: %r" % (shd.stats,)
     full, mine = one.labels_.cpu().numpy(), shd.labels_.cpu().numpy()
     assert np.array_equal(mine[:n_ls], full[:n_l][sl]) and np.array_equal(mine[n_ls:], full[n_l:][su]), "exact rows: sharded labels differ"
     assert torch.equal(shd.cluster_centers_, one.cluster_centers_), "exact rows: centres must be bit-identical to the single-rank fit"
