@@ -24,7 +24,7 @@ def main():
     lab = (y < k // 2) & (torch.rand(n, device=dev, generator=g2) < 0.5)
     u, l, lt = x[~lab].contiguous(), x[lab].contiguous(), y[lab].contiguous()
     stat = {"n": 0, "t": 0.0, "sync": False}
-    for name in ("all_reduce", "all_gather", "broadcast"):
+    for name in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast"):
         orig = getattr(dist, name)
 
         def wrapped(*a, _o=orig, **kw):
