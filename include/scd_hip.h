@@ -196,7 +196,9 @@ int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, const void* pre
  * new centres are the rows of their first owner in rank order (float32 values of the global X), written to C_buf[r][m0 + t]; picks_out
  * int64 [T][R] = 0, or -1 where no shard reported a hit (the reference indexes an empty nonzero() there).  d2 float [R][ld]: this
  * shard's closest squared distances, updated in place; r_dev float [T][R]: the restarts' uniforms; ws: scd_kpp_seed_sharded_ws_bytes.
- * X16 (may be NULL): this shard's exact fp16 copy - the update then goes through the MFMA filter as in scd_kpp_seed_lockstep. */
+ * X16 (may be NULL): this shard's exact fp16 copy - the update then goes through the MFMA filter as in scd_kpp_seed_lockstep.
+ * Every rank needs at least one row (n > 0) and must make the call (three gathers per round, T rounds).  A non-zero return of the
+ * callback ends the loop with SCD_ERCCL. */
 typedef int (*scd_gather_fn)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
 size_t scd_kpp_seed_sharded_ws_bytes(int64_t n, int d, int R);
 size_t scd_kpp_seed_sharded_xbuf_bytes(int d, int R, int world);
