@@ -4,7 +4,8 @@
 // 139-141) on random data and checks both against plain float64 loops on the host; then a restart's Lloyd loop
 // (faster_mix_k_means_pytorch.py:187-214) twice - once over all rows (scd_kmeans_lloyd_run) and once over two ROW SHARDS driven by two
 // host threads, two handles and two streams (scd_kmeans_lloyd_run_sharded), whose exchange callback adds the two shards' packed sums on
-// the host - and checks that the sharded run reproduces the single one bit for bit.  Exit code 0 = equal.
+// the host - and checks that the sharded run reproduces the single one bit for bit; the k-means++ rounds of two restarts get the same treatment (scd_kpp_seed_lockstep against
+// scd_kpp_seed_lockstep_sharded with a host-side all-gather).  Exit code 0 = equal.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -74,6 +75,41 @@ static int two_way_exchange(void* ctx, double* buf, int64_t n, void* stream) {
         total = t->acc;
     }
     return hipMemcpyAsync(buf, total.data(), (size_t)n * 8, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess &&
+                   hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
+}
+
+// ---- the all-gather of the sharded seeding rounds for two shards in one process: shard w's bytes land at recv + w * bytes on both
+struct TwoWayGather {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> stage;
+    int arrived = 0;
+    long generation = 0;
+    int rank_of_thread[2] = {0, 1};
+};
+struct GatherCtx { TwoWayGather* g; int rank; };
+static int two_way_gather(void* ctx, const void* send, void* recv, int64_t bytes, void* stream) {
+    GatherCtx* c = (GatherCtx*)ctx;
+    TwoWayGather* t = c->g;
+    std::vector<char> mine((size_t)bytes), all;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
+    if (hipMemcpy(mine.data(), send, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    {
+        std::unique_lock<std::mutex> lock(t->mu);
+        if (t->arrived == 0) t->stage.assign(2 * (size_t)bytes, 0);
+        memcpy(t->stage.data() + (size_t)c->rank * bytes, mine.data(), (size_t)bytes);
+        if (t->arrived == 0) {
+            t->arrived = 1;
+            const long g = t->generation;
+            if (!t->cv.wait_for(lock, std::chrono::seconds(60), [&] { return t->generation != g; })) return 1;
+        } else {
+            t->arrived = 0;
+            ++t->generation;
+            t->cv.notify_all();
+        }
+        all = t->stage;          // (the first arriver copies after the second has filled its half; nobody clears it before both left:
+    }                            //  the next gather's first arriver re-assigns the buffer only after taking the lock again)
+    return hipMemcpyAsync(recv, all.data(), all.size(), hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess &&
                    hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1;
 }
 
@@ -269,8 +305,58 @@ int main() {
     bad3 += all.result[0] != sh[0].result[0] || all.result[0] != sh[1].result[0] || all.result[1] != sh[0].result[1] || all.result[1] != sh[1].result[1];
     printf("scd_kmeans_lloyd_run_sharded: 2 shards (%lld + %lld rows) vs one run of %lld rows, %d iterations, inertia %.6f: %d differences\n",
            (long long)n0, (long long)(nl - n0), (long long)nl, (int)all.result[1], all.result[0], bad3);
+    // ---- the k-means++ rounds of two restarts: all rows behind scd_kpp_seed_lockstep, and the same two shards behind
+    // scd_kpp_seed_lockstep_sharded with a host-side all-gather as the callback (sskm_constrained.py:28-44 for every restart in lock-step)
+    const int RS = 2, KS = 6, TS = KS - 1;
+    const int64_t first[2] = {17, 4211};                       // the restarts' first centres (global rows; the second lies in shard 1)
+    std::vector<float> uni(TS * RS), cfirst(RS * dl);
+    for (auto& u : uni) u = 0.5f * (rnd() + 1.0f);              // the uniforms a RandomState would supply, [round][restart]
+    for (int r = 0; r < RS; ++r)
+        for (int j = 0; j < dl; ++j) cfirst[r * dl + j] = XL[first[r] * dl + j];
+    float *dU, *dCf;
+    HIP(hipMalloc((void**)&dU, uni.size() * 4));
+    HIP(hipMemcpy(dU, uni.data(), uni.size() * 4, hipMemcpyHostToDevice));
+    HIP(hipMalloc((void**)&dCf, cfirst.size() * 4));
+    HIP(hipMemcpy(dCf, cfirst.data(), cfirst.size() * 4, hipMemcpyHostToDevice));
+    struct Seed { float *d2 = nullptr, *cbuf = nullptr; int64_t* picks = nullptr; void *ws = nullptr, *xbuf = nullptr; size_t nws = 0, nx = 0; int rc = 0; };
+    auto seed_setup = [&](Seed& q, Shard& s, bool sharded) -> int {
+        HIP(hipMalloc((void**)&q.d2, (size_t)RS * s.n * 4));
+        std::vector<float> inf((size_t)RS * s.n, INFINITY);
+        HIP(hipMemcpy(q.d2, inf.data(), inf.size() * 4, hipMemcpyHostToDevice));
+        CHECK(scd_kmeans_min_update_multi(s.h, s.X, dCf, s.n, dl, RS, q.d2, s.n, s.st));          // distances to the first centres
+        HIP(hipMalloc((void**)&q.cbuf, (size_t)RS * KS * dl * 4));
+        for (int r = 0; r < RS; ++r) HIP(hipMemcpy(q.cbuf + (size_t)r * KS * dl, dCf + (size_t)r * dl, dl * 4, hipMemcpyDeviceToDevice));
+        HIP(hipMalloc((void**)&q.picks, (size_t)TS * RS * 8));
+        q.nws = sharded ? scd_kpp_seed_sharded_ws_bytes(s.n, dl, RS) : scd_kpp_seed_ws_bytes(s.n, dl, RS);
+        HIP(hipMalloc(&q.ws, q.nws));
+        if (sharded) { q.nx = scd_kpp_seed_sharded_xbuf_bytes(dl, RS, 2); HIP(hipMalloc(&q.xbuf, q.nx)); }
+        HIP(hipStreamSynchronize(s.st));
+        return 0;
+    };
+    Seed sa, ss[2];
+    if (seed_setup(sa, all, false) || seed_setup(ss[0], sh[0], true) || seed_setup(ss[1], sh[1], true)) return 1;
+    CHECK(scd_kpp_seed_lockstep(h, all.X, all.X16, nl, dl, RS, sa.d2, nl, dU, TS, sa.cbuf, KS, 1, sa.picks, sa.ws, sa.nws, all.st));
+    HIP(hipStreamSynchronize(all.st));
+    TwoWayGather tg;
+    GatherCtx gc[2] = {{&tg, 0}, {&tg, 1}};
+    auto run_seed = [&](int w) {
+        ss[w].rc = scd_kpp_seed_lockstep_sharded(sh[w].h, sh[w].X, sh[w].X16, sh[w].n, dl, RS, ss[w].d2, sh[w].n, dU, TS, ss[w].cbuf, KS, 1,
+                                                 ss[w].picks, ss[w].ws, ss[w].nws, sh[w].st, ss[w].xbuf, ss[w].nx, two_way_gather, &gc[w], w, 2);
+        hipStreamSynchronize(sh[w].st);
+    };
+    std::thread u0(run_seed, 0), u1(run_seed, 1);
+    u0.join();
+    u1.join();
+    if (ss[0].rc || ss[1].rc) { fprintf(stderr, "scd_kpp_seed_lockstep_sharded failed: %d %d %s\n", ss[0].rc, ss[1].rc, scd_last_error()); return 1; }
+    std::vector<float> ca2((size_t)RS * KS * dl), c0s(ca2.size()), c1s(ca2.size());
+    HIP(hipMemcpy(ca2.data(), sa.cbuf, ca2.size() * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(c0s.data(), ss[0].cbuf, ca2.size() * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(c1s.data(), ss[1].cbuf, ca2.size() * 4, hipMemcpyDeviceToHost));
+    int bad4 = 0;
+    for (size_t i = 0; i < ca2.size(); ++i) bad4 += memcmp(&ca2[i], &c0s[i], 4) != 0 || memcmp(&ca2[i], &c1s[i], 4) != 0;
+    printf("scd_kpp_seed_lockstep_sharded: 2 shards vs one call, %d restarts x %d centres: %d seed differences\n", RS, KS, bad4);
     CHECK(scd_destroy(sh[0].h));
     CHECK(scd_destroy(sh[1].h));
     CHECK(scd_destroy(h));
-    return (bad || bad2 || bad3) ? 2 : 0;
+    return (bad || bad2 || bad3 || bad4) ? 2 : 0;
 }

@@ -1708,7 +1708,8 @@ def test_c_abi_host_program_without_torch(ops, tmp_path):
     """examples/c_abi_host.cpp - a C++ host that links libscd_hip.so and uses nothing but include/scd_hip.h and hipMalloc - builds
     with hipcc and reproduces float64 host loops: top-3 names + softmax probabilities (main_unsup.py:504-531) and E-step labels
     (faster_mix_k_means_pytorch.py:139-141); it then runs a restart's Lloyd loop over all rows and over two row shards (two host
-    threads, two handles, a host-side sum as the exchange callback of scd_kmeans_lloyd_run_sharded) and finds them bit-identical.
+    threads, two handles, a host-side sum as the exchange callback of scd_kmeans_lloyd_run_sharded) and finds them bit-identical, and
+    does the same for the k-means++ rounds (scd_kpp_seed_lockstep against scd_kpp_seed_lockstep_sharded with a host-side all-gather).
     The boundary is usable from compiled code, not only through ctypes."""
     import shutil
     import subprocess
@@ -1721,7 +1722,7 @@ def test_c_abi_host_program_without_torch(ops, tmp_path):
                     os.path.join(ROOT, "examples", "c_abi_host.cpp"), "-L", lib, "-lscd_hip", "-lpthread", "-Wl,-rpath," + lib], check=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)          # a child process of its own: no exec from this one
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 mismatches" in r.stdout and "0 label mismatches" in r.stdout and ": 0 differences" in r.stdout, r.stdout
+    assert "0 mismatches" in r.stdout and "0 label mismatches" in r.stdout and ": 0 differences" in r.stdout and ": 0 seed differences" in r.stdout, r.stdout
 
 
 @pytest.mark.parametrize("tol,max_it", [(5e-2, 10), (1e30, 10), (1e-4, 1), (1e-4, 2), (0.0, 4)])
