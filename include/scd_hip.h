@@ -119,7 +119,7 @@ int scd_kmeans_mstep(scd_handle h, const float* X, const int32_t* labels, const 
                      void* stream);
 /* The same partials from an fp16 copy of X (half the row bytes): valid when every value of X is exactly representable in fp16,
  * as features that left an fp16 encoder are - the float64 sums are then bit-identical.  scd_f16_exact writes the copy
- * (n_elems % 4 == 0) and counts the waves that saw a value that does not survive the round trip (*inexact_out == 0: exact). */
+ * (n_elems % 4 == 0) and counts the blocks that saw a value that does not survive the round trip (*inexact_out == 0: exact). */
 int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream);
 /* The same, also returning max |x| (device float; +inf when a value is infinite).  The incremental M-step's "exact sums" argument
  * (scd_kmeans_lloyd_step_delta) needs rows * max|x| * 2^24 < 2^53 on top of the exact copy: unit-scale features satisfy it by orders

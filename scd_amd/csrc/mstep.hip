@@ -360,29 +360,42 @@ __global__ void __launch_bounds__(256) mstep_segment16_kernel(const half_t* __re
     }
 }
 
-// out16 = fp16(X); *inexact_out (device int32) = number of values that do not survive the round trip (0: the copy is exact)
+// out16 = fp16(X); *inexact_out (device int32) != 0 iff some value does not survive the round trip (0: the copy is exact)
 // absmax_bits (may be NULL): max |x| over the values as float bits (non-negative floats order like their bit patterns; +-inf -> 0x7f800000)
+// Grid-stride, ONE atomic per block and output: an atomicMax per wave (round 4's first version) was 285,000 same-address atomics at
+// 95,000 x 768 - 3.2 ms for a 0.1-ms copy.
 __global__ void __launch_bounds__(256) f16_exact_kernel(const float* __restrict__ X, long long n4, half_t* __restrict__ out,
                                                         int* inexact, unsigned* absmax_bits) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const float4 v = *(const float4*)(X + i * 4);
-    half4 h;
-    h[0] = (half_t)v.x; h[1] = (half_t)v.y; h[2] = (half_t)v.z; h[3] = (half_t)v.w;
-    *(half4*)(out + i * 4) = h;
-    const bool bad = (float)h[0] != v.x || (float)h[1] != v.y || (float)h[2] != v.z || (float)h[3] != v.w;     // NaN counts as inexact
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(inexact, 1);
-    if (absmax_bits) {
-        float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));       // fmaxf drops NaN (counted above)
-        m = wave_max_f32(m);
-        if ((threadIdx.x & 63) == 0) atomicMax(absmax_bits, __float_as_uint(m));
+    __shared__ float wmax[4];
+    __shared__ int wbad[4];
+    bool bad = false;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = *(const float4*)(X + i * 4);
+        half4 h;
+        h[0] = (half_t)v.x; h[1] = (half_t)v.y; h[2] = (half_t)v.z; h[3] = (half_t)v.w;
+        *(half4*)(out + i * 4) = h;
+        bad |= (float)h[0] != v.x || (float)h[1] != v.y || (float)h[2] != v.z || (float)h[3] != v.w;     // NaN counts as inexact
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));                // fmaxf drops NaN (counted above)
     }
+    const int any_bad = __any(bad) ? 1 : 0;
+    m = wave_max_f32(m);
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wbad[threadIdx.x >> 6] = any_bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (wbad[0] | wbad[1] | wbad[2] | wbad[3]) atomicAdd(inexact, 1);
+        if (absmax_bits) atomicMax(absmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+    }
+}
+static unsigned f16_exact_grid(int64_t n_elems) {
+    const long long need = scd_cdiv(n_elems / 4, 256);
+    return (unsigned)(need < 2048 ? need : 2048);
 }
 extern "C" int scd_f16_exact(scd_handle h, const float* X, int64_t n_elems, void* out16, int32_t* inexact_out, void* stream_) {
     SCD_DEVICE_ENTRY(h, "scd_f16_exact");
     SCD_REQUIRE(h && X && out16 && inexact_out && n_elems > 0 && n_elems % 4 == 0, "scd_f16_exact: bad arguments (n_elems % 4 != 0?)");
     SCD_HIP(hipMemsetAsync(inexact_out, 0, 4, (hipStream_t)stream_));
-    f16_exact_kernel<<<(unsigned)scd_cdiv(n_elems / 4, 256), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out, nullptr);
+    f16_exact_kernel<<<f16_exact_grid(n_elems), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out, nullptr);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
@@ -392,7 +405,7 @@ extern "C" int scd_f16_exact_max(scd_handle h, const float* X, int64_t n_elems, 
     SCD_REQUIRE(h && X && out16 && inexact_out && absmax_out && n_elems > 0 && n_elems % 4 == 0, "scd_f16_exact_max: bad arguments (n_elems % 4 != 0?)");
     SCD_HIP(hipMemsetAsync(inexact_out, 0, 4, (hipStream_t)stream_));
     SCD_HIP(hipMemsetAsync(absmax_out, 0, 4, (hipStream_t)stream_));
-    f16_exact_kernel<<<(unsigned)scd_cdiv(n_elems / 4, 256), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out,
+    f16_exact_kernel<<<f16_exact_grid(n_elems), 256, 0, (hipStream_t)stream_>>>(X, n_elems / 4, (half_t*)out16, inexact_out,
                                                                                              (unsigned*)absmax_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;

@@ -229,7 +229,7 @@ def f16_exact(x):
     if x.numel() % 4 or x.shape[-1] % 2:
         return None
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    res = torch.empty(2, dtype=torch.int32, device=x.device)                  # [inexact waves | max |x| as float bits]
+    res = torch.empty(2, dtype=torch.int32, device=x.device)                  # [inexact blocks | max |x| as float bits]
     check(_L().scd_f16_exact_max(handle(), ptr(x), x.numel(), ptr(out), ptr(res), res.data_ptr() + 4, stream_ptr()))
     host = res.cpu()
     if int(host[0]) != 0:
