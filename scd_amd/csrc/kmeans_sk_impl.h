@@ -319,9 +319,16 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
         long long* picks_t = (long long*)picks_out + (size_t)t * R;
         if (use_filter) {
             for (int b = 0; b < y.nbat; ++b) {
+                // groups of 16 candidates in this batch of up to 64: every group is a pass over X16, so a single start (L = 6 candidates)
+                // gets ONE pass on the whole grid instead of four quarter-grids of which three had nothing to measure (94 -> 33 us per
+                // round); the regions [0, g) of counts / list are all written in each form
+                const int Mb = M - 64 * b < 64 ? M - 64 * b : 64;
+                const int ngrp = Mb <= 16 ? 1 : Mb <= 32 ? 2 : 4;
+#define KG_ARGS (const half_t*)X16, rn2, c16 + (size_t)b * 64 * y.dp, info + b * 128, n, d, M, d2, y.ld, counts + (size_t)b * y.g, \
+                list + (size_t)b * y.g * y.cap, y.cap, b * 64, L
 #define KG_GO(NKS)                                                                                                        \
-    muf_filter_kernel<NKS, 4><<<dim3(y.g / 4, 4), 256, 0, st>>>((const half_t*)X16, rn2, c16 + (size_t)b * 64 * y.dp, info + b * 128, n, d, M, d2, y.ld, \
-                                                   counts + (size_t)b * y.g, list + (size_t)b * y.g * y.cap, y.cap, b * 64, L)
+    if (ngrp == 1) muf_filter_kernel<NKS, 1><<<y.g, 256, 0, st>>>(KG_ARGS);                                               \
+    else muf_filter_kernel<NKS, 4><<<dim3(y.g / ngrp, ngrp), 256, 0, st>>>(KG_ARGS)
                 switch (y.dp / 32) {
                     case 4: KG_GO(4); break;
                     case 8: KG_GO(8); break;
@@ -330,6 +337,7 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
                     default: KG_GO(24); break;
                 }
 #undef KG_GO
+#undef KG_ARGS
             }
             kg_exact_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>((const half_t*)X16, Cn, d, L, M, counts, list, vals, y.cap, y.g, d2, y.ld, potd);
             kg_apply_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>(counts, list, vals, y.cap, y.g, potd, R, L, d2, y.ld, cand, Cn, d, slot, ldc, picks_t);
