@@ -12,6 +12,7 @@ def bench(m, n, k, iters=20):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print("torch m=%6d n=%5d k=%5d : %8.1f us  %7.1f TFLOP/s" % (m, n, k, us, 2.0 * m * n * k / us / 1e6), flush=True)
-M = 512 * 197
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+M = (B * 197 + 255) // 256 * 256
 for shp in [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (4096, 4096, 4096), (8192, 8192, 8192)]:
     bench(*shp)
