@@ -1519,6 +1519,82 @@ def test_extract_feature_writes_reference_dict(ops, tmp_path):
     assert _cos(torch.from_numpy(dd["all_feats"]), dref).min().item() > 1 - 1e-3
 
 
+class _OneRankExchange:
+    """Stand-in for scd_amd.kmeans._Dist on a world of one (no process group): the exchanges are identities; `fail_after` makes the n-th
+    all-reduce / all-gather raise, as a broken collective would."""
+    rank, world = 0, 1
+
+    def __init__(self, fail_after=None):
+        self.calls, self.fail_after = 0, fail_after
+
+    def _tick(self):
+        self.calls += 1
+        if self.fail_after is not None and self.calls > self.fail_after:
+            raise RuntimeError("collective failed (test)")
+
+    def allreduce_(self, t, op="sum"):
+        self._tick()
+        return t
+
+    def allgather(self, t):
+        self._tick()
+        return t.unsqueeze(0).clone()
+
+    def allgather_into(self, out, inp):
+        self._tick()
+        out.copy_(inp)
+
+
+def test_sharded_loops_as_a_world_of_one_and_their_error_path(ops):
+    """scd_kmeans_lloyd_run_sharded / scd_kpp_seed_lockstep_sharded with identity exchanges (a world of one, no process group) reproduce
+    the single-process entry points bit for bit - the callback plumbing itself - and an exception raised inside a callback comes back as
+    that exception after the C call has returned SCD_ERCCL (nothing unwinds through the C frames, nothing hangs)."""
+    from scd_amd import ops as O
+    n, d, k, rr = 20000, 128, 16, 3
+    x, y, _ = synth.clustered_features(n, d, k, seed=81, center_seed=82, noise=0.6)
+    X = dev(x.astype(np.float16).astype(np.float32))
+    data = O.KMeansData(X)
+    x16 = O.f16_exact(X)
+    # seeding: three restarts, first centres = rows 5, 1700, 19000
+    first = torch.tensor([5, 1700, 19000], device="cuda")
+    rv = torch.from_numpy(np.random.RandomState(4).rand(k - 1, rr).astype(np.float32)).cuda().contiguous()
+
+    def seed_inputs():
+        buf = torch.zeros((rr, k, d), dtype=torch.float32, device="cuda")
+        rows = X[first].contiguous()
+        buf[:, 0] = rows
+        d2 = torch.full((rr, n), float("inf"), dtype=torch.float32, device="cuda")
+        O.min_update_multi(X, rows, d2)
+        return buf, d2
+    b1, d21 = seed_inputs()
+    O.kpp_seed_lockstep(X, x16, d21, rv, b1, 1)
+    b2, d22 = seed_inputs()
+    pk = O.kpp_seed_lockstep_sharded(X, x16, d22, rv, b2, 1, _OneRankExchange())
+    assert torch.equal(b1, b2) and torch.equal(d21, d22) and int((pk < 0).sum()) == 0
+    b3, d23 = seed_inputs()
+    with pytest.raises(RuntimeError, match="collective failed"):
+        O.kpp_seed_lockstep_sharded(X, x16, d23, rv, b3, 1, _OneRankExchange(fail_after=7))
+    # Lloyd loop
+    lb1 = O.LloydBuffers(data, X, x16, k)
+    lb1.c0.copy_(b1[0])
+    r1 = lb1.run(10, 1e-4)
+    ex = _OneRankExchange()
+    lb2 = O.LloydBuffers(data, X, x16, k, ex)
+    assert lb2.inc
+    lb2.c0.copy_(b1[0])
+    r2 = lb2.run(10, 1e-4)
+    # (bit patterns: this seeding leaves one cluster empty, its centre is 0 / 0 = NaN as in the reference, and NaN != NaN)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[2].view(torch.int32), r2[2].view(torch.int32)) and r1[1] == r2[1] and r1[3] == r2[3] and ex.calls > 3
+    lb3 = O.LloydBuffers(data, X, x16, k, _OneRankExchange(fail_after=6))
+    lb3.c0.copy_(b1[0])
+    with pytest.raises(RuntimeError, match="collective failed"):
+        lb3.run(10, 1e-4)
+    torch.cuda.synchronize()
+    # the handle is still usable afterwards
+    r4 = lb1.run(10, 1e-4)
+    assert torch.equal(r1[0], r4[0])
+
+
 def test_rccl_entry_points_single_rank(ops):
     """scd_comm_* / scd_allreduce_centroids / scd_allgather_text through the C ABI on a one-rank communicator (the GPU box has one
     GPU; the multi-rank pattern is covered by tests/test_dist_gloo.py on CPU and by the driver's 8-GPU bench)."""
