@@ -94,6 +94,9 @@ class HipBackend:
         return self.ops.transport_solve(cost, size_min, size_max)
 
 
+_FLAT_GATHER = {}      # (backend, device type) -> the backend has all_gather_into_tensor (agreed across ranks)
+
+
 class _Dist:
     """Thin wrapper over torch.distributed for the three exchanges k-means needs."""
 
@@ -123,10 +126,26 @@ class _Dist:
         return torch.cat([allp[r, : lens[r]] for r in range(self.world)]), lens
 
     def allgather_into(self, out, inp):
-        """rank w's `inp` (flat, equal sizes) -> out[w * len(inp): (w + 1) * len(inp)] on every rank."""
-        try:
+        """rank w's `inp` (flat, equal sizes) -> out[w * len(inp): (w + 1) * len(inp)] on every rank.  Which form the backend offers
+        (the flat all_gather_into_tensor, or all_gather on views) is settled ONCE per (backend, device type) by a probe whose outcome the
+        ranks agree on with an all-reduce; afterwards exactly one form is issued and a collective's own errors propagate - a rank that
+        fell back on its own would issue a different collective from its peers."""
+        key = (str(self.d.get_backend(self.group)), inp.device.type)
+        flat = _FLAT_GATHER.get(key)
+        if flat is None:
+            ok = 1
+            try:
+                probe_in = torch.zeros(4, dtype=torch.uint8, device=inp.device)
+                probe_out = torch.zeros(4 * self.world, dtype=torch.uint8, device=inp.device)
+                self.d.all_gather_into_tensor(probe_out, probe_in, group=self.group)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=inp.device)
+            self.d.all_reduce(flag, op=self.d.ReduceOp.MIN, group=self.group)
+            flat = _FLAT_GATHER[key] = bool(int(flag.item()) == 1)
+        if flat:
             self.d.all_gather_into_tensor(out, inp, group=self.group)
-        except (RuntimeError, NotImplementedError, AttributeError):       # a backend without the flat form
+        else:
             parts = list(out.view(self.world, -1).unbind(0))
             self.d.all_gather(parts, inp, group=self.group)
 
@@ -164,6 +183,17 @@ class KMeansEngine:
 
     def _dist(self):
         return _Dist(self.group) if self.group is not None else None
+
+    def _agree_shards(self, x):
+        """Under a process group: the one precondition every sharded path shares (each rank owns at least one row to cluster) is
+        checked on ALL ranks at once, before any rank-local check, workspace sizing or collective - a rank that raised on its own
+        would leave its peers inside the next collective.  One all-reduce (MIN) per fit."""
+        dd = self._dist()
+        if dd is None:
+            return
+        n_min = dd.allreduce_(torch.tensor([len(x)], dtype=torch.int64, device=x.device), op="min")
+        if int(n_min) <= 0:
+            raise ValueError("a rank of the process group owns no row to cluster: every shard needs at least one (re-balance the shards)")
 
     def _class_means(self, l, l_targets):
         """l_centers = per-class mean in torch.unique order (sskm_constrained.py:88-96)."""
@@ -560,6 +590,7 @@ class KMeansEngine:
                 self.n_iter_ = n_iters
 
     def fit(self, X):
+        self._agree_shards(X)
         data = self._be().prepare(X)
         per = self._per_fit(data, data.x)
         inits = None
@@ -570,6 +601,7 @@ class KMeansEngine:
         self._run(self.fit_once, X, data=data, inits=inits, **per)
 
     def fit_mix(self, u_feats, l_feats, l_targets):
+        self._agree_shards(u_feats)
         data = self._be().prepare(u_feats)
         l = l_feats.to(device=data.x.device, dtype=torch.float32).contiguous()
         cat = torch.cat((l, data.x)).contiguous()

@@ -289,10 +289,6 @@ class LloydBuffers:
         self.counts = torch.empty(k, dtype=torch.int64, device=dev)
         # {inertia labelled, inertia unlabelled, centre shift, rows re-evaluated exactly, rows whose label changed}
         self.stats = [torch.zeros(5, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.nb_e = _L().scd_kmeans_estep_ws_bytes(data_u.n, data_u.d, k)
-        self.ws_e = data_u.ws(("e", k), self.nb_e)
-        self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)
-        self.ws_m = _ws(self.nb_m, dev)
         # incremental exact M-step: every float64 cluster sum must be exact, i.e. rows * max|x| * 2^24 < 2^53 on top of the exact fp16
         # copy (unit-scale features: 1e5 * 1 against 5e8; fp16 values near 65504 in big clusters, or infinities, take the fresh M-step)
         amax = getattr(cat16, "scd_absmax", float("inf")) if cat16 is not None else float("inf")
@@ -305,6 +301,11 @@ class LloydBuffers:
             mx = dd.allreduce_(torch.tensor([0.0 if bad else float(amax), 1.0 if bad else 0.0], dtype=torch.float64, device=dev), op="max")
             tot_h, mx_h = tot.cpu().numpy(), mx.cpu().numpy()
             n_glob, amax = float(tot_h[0]), (float("inf") if mx_h[1] > 0 else float(mx_h[0]))
+        # (rank-local sizing only after the ranks have agreed above: KMeansEngine.fit has also agreed that no shard is empty)
+        self.nb_e = _L().scd_kmeans_estep_ws_bytes(data_u.n, data_u.d, k)
+        self.ws_e = data_u.ws(("e", k), self.nb_e)
+        self.nb_m = _L().scd_kmeans_mstep_ws_bytes(n_cat, d, k)
+        self.ws_m = _ws(self.nb_m, dev)
         self.inc = (cat16 is not None and k <= 8192 and n_glob * amax < 2.0 ** 29 and os.environ.get("SCD_MSTEP_DELTA", "1") != "0")
         if self.inc:
             if dd is not None:

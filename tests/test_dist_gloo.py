@@ -35,6 +35,15 @@ def _worker(rank, world, port, kind, q):
             km.fit(torch.from_numpy(x[sx]))
             q.put((rank, km.labels_.numpy(), km.cluster_centers_.numpy(), float(km.inertia_)))
             return
+        if kind == "empty":                                          # rank 1 owns no unlabelled row: BOTH ranks must raise, nobody may hang
+            km = KMeansEngine(k=k, max_iterations=3, n_init=2, random_state=3, backend=OracleBackend(), group=dist.group.WORLD)
+            su = slice(0, len(u)) if rank == 0 else slice(0, 0)
+            try:
+                km.fit_mix(torch.from_numpy(u[su]), torch.from_numpy(l[sl]), torch.from_numpy(lt[sl]))
+                q.put((rank, "no error", None, 0.0))
+            except ValueError as e:
+                q.put((rank, "ValueError: " + str(e), None, 0.0))
+            return
         if kind == "sskm":
             km = KMeansEngine(k=k, max_iterations=6, n_init=2, random_state=3, backend=OracleBackend(), group=dist.group.WORLD)
         else:
@@ -105,6 +114,13 @@ def test_sharded_constrained_respects_global_bounds():
     cnt = np.bincount(lab_u, minlength=6)
     assert cnt.min() >= 60 and cnt.max() <= 200 and cnt.sum() == 900 - n_l
     assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
+def test_empty_shard_raises_on_every_rank():
+    """A rank whose shard has no row to cluster: the precondition is agreed with one all-reduce before any rank-local check, so
+    every rank raises the same ValueError instead of one rank raising while its peers wait inside the next collective."""
+    res = _run("empty")
+    assert res[0][0] == res[1][0] and res[0][0].startswith("ValueError: a rank of the process group owns no row")
 
 
 def _vocab_worker(rank, world, port, q):
