@@ -37,6 +37,10 @@ CONFIGS = {"c2": dict(images=IMAGES_PER_GPU, n_cluster=N_CLASSES,
            "c4": dict(images=160146, n_cluster=1000,
                       workload="ImageNet-1k synthetic shard (BASELINE configs[3], 1,281,167 images / 8 GPUs): CLIP ViT-B/16 encode + "
                                "V=%d vocab + SSKM k=1000 (10 restarts x 10 iters) + vote loop")}
+CONFIGS["c3"] = dict(images=12000, n_cluster=120,
+                     workload="Stanford Dogs partially supervised (BASELINE configs[2]): 12,000 images (~3,000 labelled), GCD/DINO ViT-B/16 "
+                              "+ CLIP ViT-B/16 encode, V=%d vocab raw top-5, ConSSKM k=120 size 50/1000 (10 restarts x 10 iters, "
+                              "main_ptsup.py defaults) + partially supervised vote loop")
 PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 17563453440        # CLIP ViT-B/16 visual tower
@@ -60,6 +64,10 @@ def parse():
                    help="clustering stage: SSKM (semi-supervised K-Means, the north-star path; default) or KM = the flag of the shipped "
                         "scripts/evaluate_unsupervised.sh, `KMeans(n_clusters, random_state=0).fit(u_feats)` (main_unsup.py:362)")
     a = p.parse_args()
+    if a.cluster == "KM" and a.gpus > 1:
+        p.error("--cluster KM is a single-process fit (as in the reference, main_unsup.py:362): use --gpus 1")
+    if a.config == "c3" and (a.gpus > 1 or a.cluster != "SSKM"):
+        p.error("--config c3 is the 1-GPU partially supervised path with its own clustering (ConSSKM): no --gpus / --cluster")
     a.images = a.images or CONFIGS[a.config]["images"]
     a.n_cluster = a.n_cluster or CONFIGS[a.config]["n_cluster"]
     return a
@@ -251,7 +259,7 @@ def dominant_kernel_roofline(ms, launches, flop):
             "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
 
-def secondary_rooflines(out, wt, dev):
+def secondary_rooflines(out, wt, dev, km_fit=False):
     """Call-level rates of the two other kernels north_star names, measured after the timed region on this run's own
     tensors (HIP events on the current stream, 20 calls each): the similarity + top-k call (MFMA-bound) and the k-means
     E-step call (HBM-bound: centre prep + streaming filter + refine) on the run's features and on clustered features of the
@@ -338,7 +346,7 @@ def secondary_rooflines(out, wt, dev):
     # (iii') `--cluster KM` (the shipped script's flag): `KMeans(k, random_state=0).fit` on the clustered features' unlabelled share
     # (95,000 rows at C2) - greedy k-means++ of the ten starts in lock-step + ten Lloyd runs in C (scd_kpp_greedy_lockstep,
     # scd_kmeans_lloyd_run_sk); wall time of the whole fit
-    if k <= 2048:
+    if km_fit and k <= 2048:         # with --cluster KM only: the default command's kernel statistics stay the default path's
         from scd_amd.cluster import KMeans
         n_km = min(n, int(n * 0.75))
         xk = xc[:n_km].half().float().contiguous()
@@ -495,6 +503,12 @@ def main():
         wt = wt_text
     mask_lab = pipeline.labelled_split(y, n_cls, seed=5 + rank)
     l_targets = y[torch.as_tensor(mask_lab, device=dev)]
+    feat_model = None
+    if args.config == "c3":
+        from scd_amd.clip import weights as W
+        from scd_amd.clip.model import DinoViT
+        feat_model = DinoViT(W.synthetic_dino_state_dict(seed=1, layers=12)).cuda()      # the GCD tower = DINO ViT-B/16 (main_ptsup.py:263-287)
+        lab_names = [nouns[c] for c in range(n_cls // 2)]                                 # the labelled classes' names are known (:597-603)
 
     def barrier():
         torch.cuda.synchronize()
@@ -507,8 +521,12 @@ def main():
 
     def step(i, timed):
         timers = [] if timed else None
-        out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, n_cls, topk=3, num_common_vote=10,
-                           num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers, cluster=args.cluster)
+        if args.config == "c3":
+            out = pipeline.run_ptsup(model, feat_model, images, mask_lab, l_targets, wt, nouns, lab_names, n_cls, topk=2, num_common_vote=5,
+                                     num_common_linear=2, size_min=50, size_max=1000, batch=args.batch, seed=i, timers=timers)
+        else:
+            out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, n_cls, topk=3, num_common_vote=10,
+                               num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers, cluster=args.cluster)
         if timed:
             torch.cuda.synchronize()
             for (n0, e0), (n1, e1) in zip(timers[:-1], timers[1:]):
@@ -560,7 +578,18 @@ def main():
             "roofline": roof,
             "board_power": power,
         }
-        line["secondary_rooflines"] = secondary_rooflines(out, wt, dev)
+        if args.config == "c3":
+            km = out["kmeans"]
+            line["config"]["cluster"] = "ConSSKM"
+            line["consskm"] = {"fit_ms_per_step": line["stage_ms_per_step"].get("kmeans"), "transport_solves_per_fit": km.stats.get("transport_solves"),
+                               "host_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                               "cluster_sizes_min_max": [int(np.bincount(out["labels"][int(mask_lab.sum()):], minlength=n_cls).min()),
+                                                         int(np.bincount(out["labels"][int(mask_lab.sum()):], minlength=n_cls).max())],
+                               "note": "the restarts' flow problems of an iteration are solved on host threads (scd_transport_solve_batch); "
+                                       "the step's images/s counts each image once although two towers encode it"}
+            line["secondary_rooflines"] = []
+        else:
+            line["secondary_rooflines"] = secondary_rooflines(out, wt, dev, km_fit=(args.cluster == "KM"))
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_child()
         print(json.dumps(line), flush=True)
     if world > 1:

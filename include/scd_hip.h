@@ -189,6 +189,37 @@ int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, const void* pre
                                  const double* sumsq4, double* stats_ring, int max_iter, double tol, int32_t* best_labels, float* best_C,
                                  double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream,
                                  double* xbuf, scd_exchange_fn exchange, void* exchange_ctx);
+/* ALL restarts of a fit in lock-step (faster_mix_k_means_pytorch.py:244-275: the n_init restarts are independent once seeded): iteration
+ * i of every restart still running is enqueued, then iteration i - 1 of each is settled; a restart that has converged drops out.  Every
+ * restart executes exactly the launches of scd_kmeans_lloyd_run with the same arguments, so its outputs are the same bits.  restarts[j]
+ * = restart j's own handle (scratch, centre hand-over and statistics ring are per handle: R distinct handles of the current device) and
+ * buffers - the per-restart arguments of scd_kmeans_lloyd_run, with E-step / M-step workspaces of its own; the rest is shared.
+ * xbuf / exchange NULL: one process.  Otherwise a row shard as in scd_kmeans_lloyd_run_sharded, with ONE exchange per iteration for all
+ * restarts: xbuf holds R * (k*d + 2k) doubles, the call is exchange(ctx, xbuf, (restarts still running) * (k*d + k), stream) with the
+ * running restarts' [k*d sums | k counts] packed densely in restart order (the same set on every rank: the stop decisions come from
+ * exchanged statistics) - R times fewer collectives per fit than one run per restart.
+ * n_streams > 1: the restarts' launches are spread over that many library-owned streams, ordered behind what `stream` already holds;
+ * `stream` continues behind all of them (under a group the exchange itself stays on `stream`). */
+typedef struct scd_lloyd_restart {
+    scd_handle h;
+    int32_t* lab_ring;        /* [3][n_cat] */
+    int32_t* labels_prev;     /* [n_cat] */
+    const float* C_start;     /* [k][d] the seeding */
+    float* C_ring;            /* [3][k][d] */
+    double* sums;             /* [k][d] */
+    int64_t* counts;          /* [k] */
+    double* stats_ring;       /* [2][5] */
+    int32_t* best_labels;     /* out [n_cat] */
+    float* best_C;            /* out [k][d] */
+    double* result_host;      /* out, host [4]: float32 inertia, iterations done, incremental iterations, iterations launched */
+    void* ws_e;               /* scd_kmeans_estep_ws_bytes */
+    void* ws_m;               /* scd_kmeans_mstep_ws_bytes */
+} scd_lloyd_restart;
+int scd_kmeans_lloyd_run_multi(const scd_lloyd_restart* restarts, int R, const float* X_u, const void* prep_u, int64_t n_u,
+                               const void* X16_cat, int64_t n_cat, int d, int k, const int32_t* labels_lab, const double* sums_lab,
+                               const int64_t* counts_lab, const double* sumsq4, int max_iter, double tol, size_t ws_e_bytes,
+                               size_t ws_m_bytes, void* stream, double* xbuf, scd_exchange_fn exchange, void* exchange_ctx, int n_streams);
+
 /* The lock-step k-means++ rounds of scd_kpp_seed_lockstep over a ROW SHARD (one process per GPU; sskm_constrained.py:28-44 is
  * single-process): per round three exchanges - shard sums, shard probability masses, candidate rows - each an all-gather of a few bytes
  * per restart through `gather(gather_ctx, send, recv, bytes_per_rank, stream)`: rank w's `bytes_per_rank` bytes at `send` must arrive at
@@ -307,6 +338,11 @@ int scd_munkres_sparse(int d, int64_t nnz, const int32_t* rows, const int32_t* c
 /* solve_min_cost_flow_graph (sskm_constrained.py:331-356) on the transportation form: cost int32 [n,k] */
 int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
                         int64_t* total_cost_out);
+/* `batch` problems of one shape - the E-steps of a fit's restarts (sskm_constrained.py:165-176, independent once seeded) - on up to
+ * `threads` host threads: cost int32 [batch,n,k], labels_out int32 [batch,n], totals_out int64 [batch] (or NULL).  Every problem's
+ * result is scd_transport_solve's for it, whatever the thread count; the status is that of the first problem that failed. */
+int scd_transport_solve_batch(const int32_t* cost, int64_t n, int k, int batch, int size_min, int size_max, int32_t* labels_out,
+                              int64_t* totals_out, int threads);
 
 /* ---- multi-GPU exchanges over RCCL (one process per GPU, one communicator per handle).  The reference is a
  * single process; these are the two collectives the sharded hot path needs.  librccl is dlopen'ed by the first call.

@@ -31,6 +31,15 @@ _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 # scd_exchange_fn (include/scd_hip.h): int (*)(void* ctx, double* buf, int64_t n_doubles, void* stream)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 # scd_gather_fn: int (*)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank, void* stream)
+
+
+class LloydRestart(C.Structure):
+    """scd_lloyd_restart (include/scd_hip.h): one restart's handle and buffers for scd_kmeans_lloyd_run_multi."""
+    _fields_ = [("h", C.c_void_p), ("lab_ring", C.c_void_p), ("labels_prev", C.c_void_p), ("C_start", C.c_void_p), ("C_ring", C.c_void_p),
+                ("sums", C.c_void_p), ("counts", C.c_void_p), ("stats_ring", C.c_void_p), ("best_labels", C.c_void_p), ("best_C", C.c_void_p),
+                ("result_host", C.c_void_p), ("ws_e", C.c_void_p), ("ws_m", C.c_void_p)]
+
+
 GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/scd_hip.h
@@ -85,6 +94,9 @@ SIGNATURES = {
     "scd_kpp_seed_lockstep": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "scd_kpp_seed_sharded_ws_bytes": (_sz, [_i64, _i, _i]),
     "scd_kpp_seed_sharded_xbuf_bytes": (_sz, [_i, _i, _i]),
+    # restarts, R, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, sums_lab, counts_lab, sumsq4, max_iter, tol, ws_e_bytes, ws_m_bytes, stream,
+    # xbuf, exchange (EXCHANGE_FN or NULL), exchange_ctx, n_streams
+    "scd_kmeans_lloyd_run_multi": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, C.c_double, _sz, _sz, _vp, _vp, _vp, _vp, _i]),
     # h, X, X16, n, d, R, d2, ld, r_dev, T, C_buf, k, m0, picks_out, ws, nb, stream, xbuf, xbuf_bytes, gather (GATHER_FN), ctx, rank, world
     "scd_kpp_seed_lockstep_sharded": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz,
                                            GATHER_FN, _vp, _i, _i]),
@@ -107,6 +119,7 @@ SIGNATURES = {
     "scd_munkres": (_i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
     "scd_munkres_sparse": (_i, [_i, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "scd_transport_solve": (_i, [_vp, _i64, _i, _i, _i, _vp, C.POINTER(_i64)]),
+    "scd_transport_solve_batch": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _i]),
     "scd_comm_unique_id_bytes": (_sz, []),
     "scd_comm_unique_id": (_i, [_vp]),
     "scd_comm_init": (_i, [_vp, _i, _i, _vp]),
@@ -171,6 +184,24 @@ def handle(device=None):
         check(load().scd_create(device, C.byref(out)))
         h = _handles[device] = out
     return h
+
+
+_extra_handles = {}
+
+
+def extra_handles(n, device=None):
+    """n further scd_handles of the device (scd_kmeans_lloyd_run_multi: every restart needs a handle of its own - scratch, centre
+    hand-over and statistics ring are per handle).  Created once and kept."""
+    import torch
+    if device is None:
+        device = torch.cuda.current_device()
+    device = int(device)
+    hs = _extra_handles.setdefault(device, [])
+    while len(hs) < n:
+        out = _vp()
+        check(load().scd_create(device, C.byref(out)))
+        hs.append(out)
+    return hs[:n]
 
 
 def stream_ptr():

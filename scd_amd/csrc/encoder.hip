@@ -718,6 +718,7 @@ struct EncWs {
     long long *stats_a, *stats_b;   // [rows][2] fixed-point row sums of x for the folded LayerNorms (LN1 / LN2 input)
     half_t *xsel, *ysel, *hsel;     // the last block's CLS / EOT rows only: [bh][width], [bh][width], [bh][mlp_dim]
     long long* stats_sel;
+    float* rs;                      // [rows][2] {rstd, -mean * rstd}: what the next LayerNorm-folded GEMM reads (scd_gemm_ln_finish)
     size_t total;
 };
 static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
@@ -739,6 +740,7 @@ static EncWs carve(const scd_encoder_desc& d, const EncPad& pad, char* base) {
     w.ysel = (half_t*)take((size_t)bp * d.width * 2);
     w.hsel = (half_t*)take((size_t)bp * d.mlp_dim * 2);
     w.stats_sel = (long long*)take((size_t)bp * 16);
+    w.rs = (float*)take(rows * 8);
     w.total = off + 256;
     return w;
 }
@@ -869,23 +871,29 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         if (last_q) {
             const int bh = pad.bh;
             const size_t wk = (size_t)d.width * d.width;
-            scd_gemm_ln lkv{w.stats_a, e->folded[l].csq + d.width, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_ln_finish(w.stats_a, rows, 1.0f / (float)d.width, d.ln_eps, w.rs, nullptr, st);
+            if (rc) return rc;
+            scd_gemm_ln lkv{w.stats_a, e->folded[l].csq + d.width, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr, w.rs};
             rc = scd_gemm_launch_ln(w.x, e->folded[l].wq + wk, e->folded[l].bq + d.width, nullptr, w.qkv, rows, 2 * d.width, d.width,
                                     SCD_ACT_NONE, &lkv, st);
             if (rc) return rc;
             gather_rows_stats_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.x, w.stats_a, w.rows, bh, d.width, w.xsel, w.stats_sel);
-            scd_gemm_ln lq{w.stats_sel, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_ln_finish(w.stats_sel, bh, 1.0f / (float)d.width, d.ln_eps, w.rs, nullptr, st);
+            if (rc) return rc;
+            scd_gemm_ln lq{w.stats_sel, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr, w.rs};
             rc = scd_gemm_launch_ln(w.xsel, e->folded[l].wq, e->folded[l].bq, nullptr, w.hsel, bh, d.width, d.width, SCD_ACT_NONE, &lq, st);
             if (rc) return rc;
             const int items = bp * d.heads;
             attention_single_query_kernel<<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.qkv, w.hsel, w.rows, w.ysel, pad.tokens, d.width,
                                                                                          d.heads, items, causal);
             SCD_HIP(hipMemsetAsync(w.stats_sel, 0, (size_t)bh * 16, st));
-            scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr};
+            scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr, nullptr};
             rc = scd_gemm_launch_ln(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
                                     SCD_ACT_NONE, &lo, st);
             if (rc) return rc;
-            scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+            rc = scd_gemm_ln_finish(w.stats_sel, bh, 1.0f / (float)d.width, d.ln_eps, w.rs, nullptr, st);
+            if (rc) return rc;
+            scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr, w.rs};
             rc = scd_gemm_launch_ln(w.xsel, e->folded[l].w1, e->folded[l].b1, nullptr, w.hsel, bh, d.mlp_dim, d.width, act, &li, st);
             if (rc) return rc;
             rc = scd_gemm_launch(w.hsel, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.xsel, w.xsel, bh, d.width, d.mlp_dim,
@@ -894,7 +902,9 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             break;
         }
         if (fuse) {
-            scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_b};   // also clears stats_b
+            rc = scd_gemm_ln_finish(w.stats_a, rows, 1.0f / (float)d.width, d.ln_eps, w.rs, w.stats_b, st);   // also clears stats_b
+            if (rc) return rc;
+            scd_gemm_ln ln{w.stats_a, e->folded[l].csq, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_b, w.rs};
             rc = scd_gemm_launch_ln(w.x, e->folded[l].wq, e->folded[l].bq, nullptr, w.qkv, rows, 3 * d.width, d.width, SCD_ACT_NONE, &ln, st);
         } else {
             layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN1_W],
@@ -918,11 +928,13 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             gather2_rows_kernel<<<(unsigned)scd_cdiv(bh, 4), 256, 0, st>>>(w.y, w.x, w.rows, bh, d.width, w.ysel, w.xsel);
             if (fuse) {
                 SCD_HIP(hipMemsetAsync(w.stats_sel, 0, (size_t)bh * 16, st));
-                scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr};
+                scd_gemm_ln lo{nullptr, nullptr, 0.f, 0.f, w.stats_sel, nullptr, nullptr};
                 rc = scd_gemm_launch_ln(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
                                         SCD_ACT_NONE, &lo, st);
                 if (rc) return rc;
-                scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr};
+                rc = scd_gemm_ln_finish(w.stats_sel, bh, 1.0f / (float)d.width, d.ln_eps, w.rs, nullptr, st);
+                if (rc) return rc;
+                scd_gemm_ln li{w.stats_sel, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, nullptr, w.rs};
                 rc = scd_gemm_launch_ln(w.xsel, e->folded[l].w1, e->folded[l].b1, nullptr, w.hsel, bh, d.mlp_dim, d.width, act, &li, st);
             } else {
                 rc = scd_gemm_launch(w.ysel, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.xsel, w.xsel, bh, d.width, d.width,
@@ -939,7 +951,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             break;
         }
         if (fuse) {
-            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b, nullptr};
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_b, nullptr, nullptr};
             rc = scd_gemm_launch_ln(w.y, (const half_t*)lw[L_PROJ_W], (const float*)lw[L_PROJ_B], w.x, w.x, rows, d.width, d.width,
                                     SCD_ACT_NONE, &ln, st);
             if (rc) return rc;
@@ -950,6 +962,10 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             layernorm_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.x, nullptr, rows, d.width, d.ln_eps, (const float*)lw[L_LN2_W],
                                                                            (const float*)lw[L_LN2_B], w.y);
         }
+        if (fuse) {   // the row pairs of LN2 (and stats_a cleared for fc2's epilogue) in front of the timed fc1 launch
+            rc = scd_gemm_ln_finish(w.stats_b, rows, 1.0f / (float)d.width, d.ln_eps, w.rs, w.stats_a, st);
+            if (rc) return rc;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (e->timing) {
             SCD_HIP(hipEventCreate(&e0));
@@ -957,7 +973,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             SCD_HIP(hipEventRecord(e0, st));
         }
         if (fuse) {
-            scd_gemm_ln ln{w.stats_b, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_a};   // also clears stats_a
+            scd_gemm_ln ln{w.stats_b, e->folded[l].cs1, 1.0f / (float)d.width, d.ln_eps, nullptr, w.stats_a, w.rs};
             rc = scd_gemm_launch_ln(w.x, e->folded[l].w1, e->folded[l].b1, nullptr, w.h, rows, d.mlp_dim, d.width, act, &ln, st);
         } else {
             rc = scd_gemm_launch(w.y, (const half_t*)lw[L_FC1_W], (const float*)lw[L_FC1_B], nullptr, w.h, rows, d.mlp_dim, d.width, act, st);
@@ -970,7 +986,7 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             me->timed_flop += 2.0 * (double)rows * d.mlp_dim * d.width;
         }
         if (fuse) {
-            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_a, nullptr};
+            scd_gemm_ln ln{nullptr, nullptr, 0.f, 0.f, w.stats_a, nullptr, nullptr};
             rc = scd_gemm_launch_ln(w.h, (const half_t*)lw[L_FC2_W], (const float*)lw[L_FC2_B], w.x, w.x, rows, d.width, d.mlp_dim,
                                     SCD_ACT_NONE, &ln, st);
         } else {

@@ -11,7 +11,11 @@ struct scd_gemm_ln {
     const float* colsum;     // [N] sum_k W'[n][k]                                       (with stats_in)
     float inv_k, eps;        // 1 / (row length), LayerNorm epsilon                       (with stats_in)
     long long* stats_out;    // [M][2] += the same fixed-point sums of the rows of C (integer atomics) - or null; needs bias + residual
-    long long* zero_out;     // with stats_in: a second [M][2] buffer this launch clears (the next residual GEMM's stats_out) - or null
+    long long* zero_out;     // with stats_in: a second [M][2] buffer cleared for the next residual GEMM's stats_out - or null (done by scd_gemm_ln_finish)
+    const float* rs_in;      // [M][2] {rstd, -mean * rstd} of A's rows: what scd_gemm_ln_finish made of stats_in (the four-wave kernel reads these)
 };
+// Once per folded LayerNorm, in front of the GEMM that applies it: rs_out[m] = {rstd, -mean * rstd} from the fixed-point row sums
+// stats[m], and zero_out (the other statistics buffer, or null) cleared.  One thread per row.
+int scd_gemm_ln_finish(const long long* stats, int64_t M, float inv_k, float eps, float* rs_out, long long* zero_out, hipStream_t st);
 int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
                        int act, const scd_gemm_ln* ln, hipStream_t st);

@@ -676,11 +676,14 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_LATE_TM
 #define W4_LATE_TM 2
 #endif
+#ifndef W4_LN_ABL
+#define W4_LN_ABL 0   // timing probes of the LayerNorm fold (results are wrong): 1 = no row-statistics loads / conversions (rstd = 1, mean = 0), 2 = no fold arithmetic either
+#endif
 __device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
 
 // LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
-//         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_stats[m] = {sum_k x, sum_k x^2} of the raw input rows
-//         (64-bit fixed point, units 2^-24 and 2^-20):
+//         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_rs[m] = {rstd, -mean * rstd} of the raw input rows, which
+//         ln_finish_kernel forms once per row from {sum_k x, sum_k x^2} (64-bit fixed point, units 2^-24 and 2^-20):
 //         out = rstd * (acc - mean * colsum[n]) + b'[n], then the activation.  The raw x goes through the MFMAs unchanged.
 // LN = 2: this GEMM produces the rows the NEXT LayerNorm normalises: the epilogue adds each row's {sum, sum of squares} of
 //         the fp16 values it stores into ln_out[m] (64-bit integer atomics - order-independent, so the encoder stays
@@ -689,8 +692,8 @@ template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN, bool NTS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-               int xmode_in, int ng, const long long* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, long long* __restrict__ ln_out, int stagger_in, long long* __restrict__ ln_zero) {
+               int xmode_in, int ng, const float2* __restrict__ ln_rs, const float* __restrict__ ln_colsum,
+               long long* __restrict__ ln_out, int stagger_in) {
     static_assert(NT == 8, "wave tile is 128 x 128");
 #ifdef SCD_ABLATE
     const int xmode = xmode_in, stagger = stagger_in;
@@ -737,11 +740,6 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
     const int tb = c0 + slot_id;
     const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
-    if (LN == 1 && ln_zero) {   // clear the OTHER statistics buffer (2*M floats) for the residual GEMM that follows: saves a memset launch
-        float4* z = (float4*)ln_zero;
-        const int n4 = M;
-        for (int i = blockIdx.x * 256 + tid; i < n4; i += gridDim.x * 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     const int chunks = my_tiles * nkc;
     if (chunks <= 0) return;
     const int tstride = per_xcd;
@@ -973,7 +971,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
         f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
         f32x4v bq[8], sq[8];
-        long long lst[8][2];
+        float2 lrs[8];
         float keep1[2] = {0.f, 0.f}, keep2[2] = {0.f, 0.f};   // LN = 2: this lane's rows 4*c16 + 64*j + q16
         // bias and the first residual rows are fetched one chunk before the tile ends: a plain load issued in the epilogue
         // would sit behind the ring refills in the (in-order) vmcnt queue and stall on them.
@@ -989,14 +987,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;                          \
             }                                                                                                    \
         }                                                                                                        \
-        if (LN == 1) {                                                                                           \
+        if (LN == 1 && W4_LN_ABL < 2) {                                                                          \
             _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
                 const float4 c4 = *(const float4*)(ln_colsum + nb0 + tn * 16 + q16 * 4);                         \
                 sq[tn][0] = c4.x; sq[tn][1] = c4.y; sq[tn][2] = c4.z; sq[tn][3] = c4.w;                          \
             }                                                                                                    \
-            _Pragma("unroll") for (int tm = 0; tm < 8; ++tm) {                                                   \
-                const longlong2 q = *(const longlong2*)(ln_stats + 2 * ((size_t)bm * BM + wm * 128 + tm * 16 + c16)); \
-                lst[tm][0] = q.x; lst[tm][1] = q.y;                                                              \
+            if (W4_LN_ABL == 0) {                                                                                \
+                _Pragma("unroll") for (int tm = 0; tm < 8; ++tm)                                                 \
+                    lrs[tm] = ln_rs[(size_t)bm * BM + wm * 128 + tm * 16 + c16];                                 \
             }                                                                                                    \
         }                                                                                                        \
     }
@@ -1023,16 +1021,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             half8 hvb[4];
             unsigned stash[8][16];
             float rstd_a[8], nmr_a[8];
-            if (LN == 1) {
+            if (LN == 1 && W4_LN_ABL) {
 #pragma unroll
-                for (int tm = 0; tm < 8; ++tm) {
-                    // row sums are 64-bit fixed point (2^-24 / 2^-20 units): integer atomics add in any order to the same bits
-                    const float mu = __ll2float_rn(lst[tm][0]) * (5.9604644775390625e-8f * ln_invk);
-                    const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(lst[tm][1]) * (9.5367431640625e-7f * ln_invk)), 0.f);
-                    rstd_a[tm] = __builtin_amdgcn_rsqf(var + ln_eps);
-                    nmr_a[tm] = -mu * rstd_a[tm];
-                }
-                asm volatile("" ::: "memory");
+                for (int tm = 0; tm < 8; ++tm) { rstd_a[tm] = 1.f; nmr_a[tm] = 0.f; }
+            } else if (LN == 1) {
+                // {rstd, -mean * rstd} of the row, formed once per row by ln_finish_kernel from the fixed-point row sums (as eight
+                // 64-bit loads + conversions per lane and tile, in front of every epilogue, they cost 2 % of an encode: round 5)
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm) { rstd_a[tm] = lrs[tm].x; nmr_a[tm] = lrs[tm].y; }
             }
 #pragma unroll
             for (int tm = 0; tm <= 8; ++tm) {
@@ -1048,7 +1044,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v01.y) : "a"(acc[tn][tm][1]));
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.x) : "a"(acc[tn][tm][2]));
                         asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v23.y) : "a"(acc[tn][tm][3]));
-                        if (LN == 1) {
+                        if (LN == 1 && W4_LN_ABL < 2) {
                             const float2v r2 = {rstd, rstd}, m2 = {nmr, nmr};
                             float2v t01 = m2 * sq[tn].lo, t23 = m2 * sq[tn].hi;
                             if (HAS_BIAS) { t01 += bq[tn].lo; t23 += bq[tn].hi; }
@@ -1541,9 +1537,8 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     const int stagger = stagger_env;
 #define W4_GO(NTSV)                                                                                                            \
     gemm_w4_kernel<NT, ACT, B, RR, LN, NTSV><<<grid, 256, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,         \
-                                                                     LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr, \
-                                                                     LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,             \
-                                                                     LN == 2 ? ln->stats_out : nullptr, stagger, LN == 1 ? ln->zero_out : nullptr)
+                                                                     LN == 1 ? (const float2*)ln->rs_in : nullptr, LN == 1 ? ln->colsum : nullptr, \
+                                                                     LN == 2 ? ln->stats_out : nullptr, stagger)
     if (nt) W4_GO(true); else W4_GO(false);
 #undef W4_GO
     if (xmode & 64) {
@@ -1578,7 +1573,7 @@ static int launch_w4_ln(const half_t* A, const half_t* W, const float* bias, con
     }
 #endif
     if (ln->stats_in) {
-        if (!bias || R || ln->stats_out) return SCD_EINVAL;
+        if (!bias || R || ln->stats_out || !ln->rs_in) return SCD_EINVAL;
         if (act == SCD_ACT_NONE) return launch_w4<8, SCD_ACT_NONE, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
         if (act == SCD_ACT_QUICKGELU) return launch_w4<8, SCD_ACT_QUICKGELU, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
         return launch_w4<8, SCD_ACT_GELU, true, false, 1>(A, W, bias, R, C, M, N, K, ln, st);
@@ -1646,6 +1641,27 @@ static void launch_act(const half_t* A, const half_t* W, const float* bias, cons
     else if (bias) gemm_f16_kernel<ACT, true, false><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
     else if (R) gemm_f16_kernel<ACT, false, true><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
     else gemm_f16_kernel<ACT, false, false><<<total, 256, 0, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total);
+}
+
+// {rstd, -mean * rstd} per row from the fixed-point row sums, exactly the arithmetic the GEMM epilogue used to repeat per lane and tile
+// (float(sum) * 2^-24 / k, max(E[x^2] - mean^2, 0), v_rsq_f32): the features keep their bits.  Also clears the statistics buffer the
+// NEXT residual GEMM accumulates into (was a loop in the GEMM's prologue).
+__global__ void __launch_bounds__(256) ln_finish_kernel(const long long* __restrict__ stats, long long m, float invk, float eps,
+                                                        float2* __restrict__ rs, float4* __restrict__ zero) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const longlong2 q = *(const longlong2*)(stats + 2 * i);
+    const float mu = __ll2float_rn(q.x) * (5.9604644775390625e-8f * invk);
+    const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(q.y) * (9.5367431640625e-7f * invk)), 0.f);
+    const float rstd = __builtin_amdgcn_rsqf(var + eps);
+    rs[i] = make_float2(rstd, -mu * rstd);
+    if (zero) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+int scd_gemm_ln_finish(const long long* stats, int64_t M, float inv_k, float eps, float* rs_out, long long* zero_out, hipStream_t st) {
+    SCD_REQUIRE(stats && rs_out && M > 0, "scd_gemm_ln_finish: bad arguments");
+    ln_finish_kernel<<<(unsigned)scd_cdiv(M, 256), 256, 0, st>>>(stats, M, inv_k, eps, (float2*)rs_out, (float4*)zero_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
 }
 
 int scd_gemm_launch_ln(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,

@@ -13,6 +13,8 @@
 // bound; rows whose best/second margin is inside the bound are re-evaluated exactly in float64.
 #include "common.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------
 // prepared data set layout (scd_kmeans_prepare):
@@ -2809,21 +2811,18 @@ __global__ void __launch_bounds__(256) xch_pack_kernel(const double* sums, const
     if (i < kd) buf[i] = sums[i];
     else if (i < kd + (size_t)k) buf[i] = (double)counts[i - kd];
 }
-__global__ void __launch_bounds__(256) xch_unpack_kernel(double* buf, size_t kd, int k) {
+__global__ void __launch_bounds__(256) xch_unpack_kernel(const double* counts_f64, int k, long long* counts_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < k) ((long long*)(buf + kd + k))[i] = llrint(buf[kd + i]);
+    if (i < k) counts_out[i] = llrint(counts_f64[i]);
 }
 
-static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
-                                 int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
-                                 float* C_out, double* sums, int64_t* counts, const double* sums_lab,
-                                 const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
-                                 size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq,
-                                 int shift_mode = 0, const LloydXch* xch = nullptr) {
+// One Lloyd iteration in two halves, so that the restarts of a fit can advance in lock-step (scd_kmeans_lloyd_run_multi): A = E-step +
+// M-step (+ the rank's [sums | counts] packed at `pack_dst` under a process group), B = centres / shift / inertia / the next E-step's
+// operands from `fsums` / `fcounts` (the rank's own, or the exchanged ones).
+static int lloyd_step_a(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat, int d, int k,
+                        int32_t* labels_cat, int32_t* labels_prev, const float* C_in, double* sums, int64_t* counts, double* stats,
+                        int flags, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* pack_dst) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
-    SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
-                "scd_kmeans_lloyd_step_delta: null argument");
-    SCD_REQUIRE(n_u > 0 && n_cat >= n_u && C_in != C_out && k <= 8192, "scd_kmeans_lloyd_step_delta: bad arguments");
     const int64_t l_num = n_cat - n_u;
     hipStream_t st = (hipStream_t)stream;
     int rc = scd_kmeans_estep_hint(h, flags & (SCD_ESTEP_FEW | SCD_ESTEP_CENTRES_FROM_FINALIZE));
@@ -2831,10 +2830,6 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
     if (rc) return rc;
     // rows whose label changed: accumulated in the handle's scratch (zero between iterations), handed to stats[4] by finalize_kernel
     double* changed_acc = (double*)((char*)h->scratch + 262144 + 40);
-    bool fused_inertia = false;
-    // sharded: the inertia always comes from the (global) sums - a rank's row-wise partial of a fresh M-step could not be mixed with
-    // the sums-based form another rank's incremental step needs, and each rank picks fresh / incremental from its own change count
-    const bool sums_inertia = xch || !(flags & SCD_LLOYD_FULL);
     if (flags & SCD_LLOYD_FULL) {
         // a fresh M-step (sums, counts, inertia from the rows), then labels_prev = labels for the incremental steps that follow
         rc = scd_kmeans_mstep_f16(h, X16_cat, labels_cat, C_in, n_cat, d, k, l_num, sums, counts, stats, ws_m, ws_m_bytes, stream);
@@ -2844,21 +2839,21 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
         mstep_delta_kernel<<<(unsigned)scd_cdiv(n_u, 256), 256, 0, st>>>((const half_t*)X16_cat, labels_cat, labels_prev, l_num, n_cat, d, k, sums,
                                                                           (unsigned long long*)counts, changed_acc);
     }
-    const double* fsums = sums;
-    const int64_t* fcounts = counts;
-    if (xch) {
+    if (pack_dst) {
         const size_t kd = (size_t)k * d;
-        xch_pack_kernel<<<(unsigned)scd_cdiv((int64_t)(kd + k), 256), 256, 0, st>>>(sums, (const long long*)counts, kd, k, xch->buf);
-        SCD_LAUNCH_CHECK();
-        rc = xch->fn(xch->ctx, xch->buf, (int64_t)(kd + k), stream);
-        if (rc) {
-            scd_set_error("scd_kmeans_lloyd_run_sharded: the exchange callback failed (%d)", rc);
-            return SCD_ERCCL;
-        }
-        xch_unpack_kernel<<<(unsigned)scd_cdiv(k, 256), 256, 0, st>>>(xch->buf, kd, k);
-        fsums = xch->buf;
-        fcounts = (const int64_t*)(xch->buf + kd + k);
+        xch_pack_kernel<<<(unsigned)scd_cdiv((int64_t)(kd + k), 256), 256, 0, st>>>(sums, (const long long*)counts, kd, k, pack_dst);
     }
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+static int lloyd_step_b(scd_handle h, const void* prep_u, int64_t n_u, int d, int k, const float* C_in, float* C_out, const double* fsums,
+                        const int64_t* fcounts, const double* sums_lab, const int64_t* counts_lab, const double* sumsq4, double* stats,
+                        int flags, void* ws_e, size_t ws_e_bytes, void* stream, double* mirror, double seq, int shift_mode, bool exchanged) {
+    hipStream_t st = (hipStream_t)stream;
+    bool fused_inertia = false;
+    // sharded: the inertia always comes from the (global) sums - a rank's row-wise partial of a fresh M-step could not be mixed with
+    // the sums-based form another rank's incremental step needs, and each rank picks fresh / incremental from its own change count
+    const bool sums_inertia = exchanged || !(flags & SCD_LLOYD_FULL);
     if (sums_inertia) {
         // the inertia from the sums: inside finalize_kernel when its 4 k partials fit behind the k shift partials in the handle's scratch
         // (32,768 doubles), else in a launch of its own (partials at the start of the scratch, free between two finalize launches)
@@ -2872,6 +2867,35 @@ static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* pre
                          stats, mirror, seq, sums_lab, counts_lab, sumsq4, fused_inertia ? stats : nullptr);
 }
 
+static int lloyd_step_delta_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
+                                 int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
+                                 float* C_out, double* sums, int64_t* counts, const double* sums_lab,
+                                 const int64_t* counts_lab, const double* sumsq4, double* stats, int flags, void* ws_e,
+                                 size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* mirror, double seq,
+                                 int shift_mode = 0, const LloydXch* xch = nullptr) {
+    SCD_REQUIRE(X_u && prep_u && X16_cat && labels_cat && labels_prev && C_in && C_out && sums && counts && sumsq4 && stats && ws_e && ws_m,
+                "scd_kmeans_lloyd_step_delta: null argument");
+    SCD_REQUIRE(n_u > 0 && n_cat >= n_u && C_in != C_out && k <= 8192, "scd_kmeans_lloyd_step_delta: bad arguments");
+    int rc = lloyd_step_a(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_cat, labels_prev, C_in, sums, counts, stats, flags, ws_e, ws_e_bytes,
+                          ws_m, ws_m_bytes, stream, xch ? xch->buf : nullptr);
+    if (rc) return rc;
+    const double* fsums = sums;
+    const int64_t* fcounts = counts;
+    if (xch) {
+        const size_t kd = (size_t)k * d;
+        rc = xch->fn(xch->ctx, xch->buf, (int64_t)(kd + k), stream);
+        if (rc) {
+            scd_set_error("scd_kmeans_lloyd_run_sharded: the exchange callback failed (%d)", rc);
+            return SCD_ERCCL;
+        }
+        xch_unpack_kernel<<<(unsigned)scd_cdiv(k, 256), 256, 0, (hipStream_t)stream>>>(xch->buf + kd, k, (long long*)(xch->buf + kd + k));
+        fsums = xch->buf;
+        fcounts = (const int64_t*)(xch->buf + kd + k);
+    }
+    return lloyd_step_b(h, prep_u, n_u, d, k, C_in, C_out, fsums, fcounts, sums_lab, counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, stream,
+                        mirror, seq, shift_mode, xch != nullptr);
+}
+
 extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
                                            int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,
                                            float* C_out, double* sums, int64_t* counts, const double* sums_lab,
@@ -2881,25 +2905,47 @@ extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const
                                  counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m, ws_m_bytes, stream, nullptr, 0.0);
 }
 
-// One restart's Lloyd loop behind ONE call (the loop of scd_amd/kmeans.py:_lloyd_pipelined, faster_mix_k_means_pytorch.py:187-214):
-// the host runs one iteration behind the device - iteration i + 1 is enqueued (from iteration i's centres, which is what the
-// sequential loop uses unless i has converged) before iteration i's statistics are looked at; if i turns out to have converged,
-// i + 1 is dropped unseen.  Nothing but the iteration's kernels enters the stream:
+// The Lloyd loops of a fit's restarts (the loop of scd_amd/kmeans.py:_lloyd_pipelined, faster_mix_k_means_pytorch.py:187-214, :244-275),
+// ONE restart (scd_kmeans_lloyd_run[_sharded]) or ALL of them in lock-step (scd_kmeans_lloyd_run_multi: the restarts are independent
+// once seeded).  Per restart the host runs one iteration behind the device - iteration i + 1 is enqueued (from iteration i's centres,
+// which is what the sequential loop uses unless i has converged) before iteration i's statistics are looked at; if i turns out to have
+// converged, i + 1 is dropped unseen.  Nothing but the iteration's kernels enters the stream:
 //  * the statistics reach the host through pinned memory written by finalize_kernel's last block (the host spins on a sequence
 //    number), not through a copy + event;
 //  * labels and centres of iteration i live in slot i % 3 of caller-owned rings, so the least-inertia iteration's (the reference's
 //    bookkeeping; nearly always one of the last two) are still there when the loop ends - a slot is copied out only when an OLDER best
 //    iteration's slot is about to be re-used.
-static int lloyd_run_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
-                          int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
-                          const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
-                          const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
-                          int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
-                          size_t ws_m_bytes, void* stream, const LloydXch* xch) {
-    SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_run");
-    SCD_REQUIRE(C_start && C_ring && stats_ring && lab_ring && best_labels && best_C && result_host, "scd_kmeans_lloyd_run: null argument");
-    SCD_REQUIRE(max_iter >= 1 && n_u > 0 && n_cat >= n_u && (n_cat == n_u || labels_lab), "scd_kmeans_lloyd_run: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+// In lock-step, iteration i of every restart still running is enqueued (restart by restart: each has its own handle - scratch, centre
+// hand-over, statistics ring - and its own buffers, and may have its own stream), under a process group the [sums | counts] of all of
+// them travel in ONE exchange, and then iteration i - 1 of every restart is settled.  Every restart executes exactly the launches of the
+// one-restart loop with the same arguments, so its labels, centres, inertia and iteration count are the same bits.
+struct LloydShared {
+    const float* X_u; const void* prep_u; int64_t n_u; const void* X16_cat; int64_t n_cat; int d, k;
+    const int32_t* labels_lab; const double* sums_lab; const int64_t* counts_lab; const double* sumsq4;
+    int max_iter; double tol; size_t ws_e_bytes, ws_m_bytes;
+};
+struct LloydRestart {
+    scd_handle h; int32_t* lab_ring; int32_t* labels_prev; const float* C_start; float* C_ring; double* sums; int64_t* counts;
+    double* stats_ring; int32_t* best_labels; float* best_C; double* result_host; void* ws_e; void* ws_m; hipStream_t st;
+    bool have_best = false, best_in_ring = false, active = true;
+    int best_it = -1;
+    float best = 0.f;
+    double refined_seen = -1., changed_seen = -1., changed_prev = -1.;      // counts of the iterations the host has seen last (-1: none yet)
+    int pending = -1, n_done = 0, delta_steps = 0, launched = 0, flags = 0;
+    double seq_of[2] = {0., 0.};
+};
+static int lr_save_best(LloydRestart& r, const LloydShared& S) {          // ring slot of the best iteration -> the output buffers
+    const size_t kd = (size_t)S.k * S.d;
+    SCD_HIP(hipMemcpyAsync(r.best_labels, r.lab_ring + (size_t)(r.best_it % 3) * S.n_cat, (size_t)S.n_cat * 4, hipMemcpyDeviceToDevice, r.st));
+    SCD_HIP(hipMemcpyAsync(r.best_C, r.C_ring + (size_t)(r.best_it % 3) * kd, kd * 4, hipMemcpyDeviceToDevice, r.st));
+    r.best_in_ring = false;
+    return SCD_OK;
+}
+static int lr_begin(LloydRestart& r, const LloydShared& S) {
+    SCD_DEVICE_ENTRY(r.h, "scd_kmeans_lloyd_run");
+    SCD_REQUIRE(r.C_start && r.C_ring && r.stats_ring && r.lab_ring && r.best_labels && r.best_C && r.result_host && r.labels_prev && r.sums &&
+                r.counts && r.ws_e && r.ws_m, "scd_kmeans_lloyd_run: null argument");
+    scd_handle h = r.h;
     if (!h->run_host) {
         SCD_HIP(hipHostMalloc((void**)&h->run_host, 2 * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         for (int i = 0; i < 16; ++i) h->run_host[i] = 0.0;
@@ -2907,100 +2953,219 @@ static int lloyd_run_impl(scd_handle h, const float* X_u, const void* prep_u, in
     }
     h->prep_C = nullptr;                            // no hand-over survives from an earlier fit on this handle
     h->prep_ok = 0;
-    const size_t kd = (size_t)k * d;
-    const int64_t l_num = n_cat - n_u;
+    const int64_t l_num = S.n_cat - S.n_u;
     for (int sl = 0; sl < 3 && l_num > 0; ++sl)     // the labelled rows' labels never change: every slot carries them
-        SCD_HIP(hipMemcpyAsync(lab_ring + (size_t)sl * n_cat, labels_lab, (size_t)l_num * 4, hipMemcpyDeviceToDevice, st));
-    bool have_best = false, best_in_ring = false;
-    int best_it = -1;
-    float best = 0.f;
-    double refined_seen = -1., changed_seen = -1., changed_prev = -1.;      // counts of the iterations the host has seen last (-1: none yet)
+        SCD_HIP(hipMemcpyAsync(r.lab_ring + (size_t)sl * S.n_cat, S.labels_lab, (size_t)l_num * 4, hipMemcpyDeviceToDevice, r.st));
+    return SCD_OK;
+}
+// first half of iteration `it`: E-step + M-step (+ pack)
+static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pack_dst) {
+    if (r.best_in_ring && r.best_it % 3 == it % 3) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }   // that slot is about to be re-used
+    const size_t kd = (size_t)S.k * S.d;
+    const float* c_in = it == 0 ? r.C_start : r.C_ring + (size_t)((it - 1) % 3) * kd;
+    double* stats = r.stats_ring + (it & 1) * 5;
     // a changed row costs the incremental M-step ~24 ns (two 768-column float64 flushes), a fresh M-step ~70 us: break-even ~ 2,900 rows at C2
-    const double many = (double)(n_u / 32 > 256 ? n_u / 32 : 256);
-    int pending = -1, n_done = 0, delta_steps = 0, launched = 0;
-    double seq_of[2] = {0., 0.};
-    auto save_best = [&]() -> int {                  // ring slot of the best iteration -> the output buffers
-        SCD_HIP(hipMemcpyAsync(best_labels, lab_ring + (size_t)(best_it % 3) * n_cat, (size_t)n_cat * 4, hipMemcpyDeviceToDevice, st));
-        SCD_HIP(hipMemcpyAsync(best_C, C_ring + (size_t)(best_it % 3) * kd, kd * 4, hipMemcpyDeviceToDevice, st));
-        best_in_ring = false;
-        return SCD_OK;
-    };
-    // settle(i): wait for iteration i's statistics; book-keep; *converged when its centre shift is below tol
-    auto settle = [&](int i, bool* converged) -> int {
-        volatile double* host = h->run_host + (i & 1) * 8;
-        const double want = seq_of[i & 1];
-        long long spins = 0;
-        while (host[7] != want) {
-            if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: has the stream failed, or is this taking absurdly long?
-                const hipError_t e = hipStreamQuery(st);
-                if (e != hipSuccess && e != hipErrorNotReady) {
-                    scd_set_error("scd_kmeans_lloyd_run: stream error while waiting for iteration %d: %s", i, hipGetErrorString(e));
-                    return SCD_EHIP;
-                }
-                if (e == hipSuccess && host[7] != want) {
-                    scd_set_error("scd_kmeans_lloyd_run: iteration %d finished without publishing its statistics", i);
-                    return SCD_EHIP;
-                }
+    const double many = (double)(S.n_u / 32 > 256 ? S.n_u / 32 : 256);
+    // SCD_ESTEP_FEW pays only when a handful of rows are flagged, the incremental M-step while few labels move: the cue is the
+    // count the host has seen last (iteration it - 2)
+    const bool few = it >= 2 && r.refined_seen >= 0. && r.refined_seen <= 64.;
+    // the changes seen last are two iterations old, and they decay fast (95,000 / 28,600 / 3,700 / 40 / 27 at C2): extrapolate with
+    // the last ratio squared.  A wrong guess costs time only - both M-steps give the same bits
+    double pred = r.changed_seen;
+    if (it >= 3 && r.changed_prev > 0. && r.changed_seen < r.changed_prev)
+        pred = r.changed_seen * (r.changed_seen / r.changed_prev) * (r.changed_seen / r.changed_prev);
+    const bool full = it < 2 || r.changed_seen < 0. || pred > many;
+    // the hand-over is vouched for only when c_in IS the previous step's C_out: C_start was not produced by a finalize of this
+    // run, and a recycled address from an earlier fit must not be mistaken for one
+    r.flags = (few ? SCD_ESTEP_FEW : 0) | (it > 0 ? SCD_ESTEP_CENTRES_FROM_FINALIZE : 0) | (full ? SCD_LLOYD_FULL : 0);
+    r.h->run_seq += 1.0;
+    r.seq_of[it & 1] = r.h->run_seq;
+    SCD_REQUIRE(S.k <= 8192, "scd_kmeans_lloyd_run: k > 8192");
+    return lloyd_step_a(r.h, S.X_u, S.prep_u, S.n_u, S.X16_cat, S.n_cat, S.d, S.k, r.lab_ring + (size_t)(it % 3) * S.n_cat, r.labels_prev, c_in,
+                        r.sums, r.counts, stats, r.flags, r.ws_e, S.ws_e_bytes, r.ws_m, S.ws_m_bytes, (void*)r.st, pack_dst);
+}
+// second half: centres, shift, inertia, the next E-step's operands, the statistics to the host
+static int lr_launch_b(LloydRestart& r, const LloydShared& S, int it, const double* fsums, const int64_t* fcounts, bool exchanged) {
+    const size_t kd = (size_t)S.k * S.d;
+    const float* c_in = it == 0 ? r.C_start : r.C_ring + (size_t)((it - 1) % 3) * kd;
+    float* c_out = r.C_ring + (size_t)(it % 3) * kd;
+    double* stats = r.stats_ring + (it & 1) * 5;
+    const int rc = lloyd_step_b(r.h, S.prep_u, S.n_u, S.d, S.k, c_in, c_out, fsums ? fsums : r.sums, fcounts ? fcounts : r.counts, S.sums_lab,
+                                S.counts_lab, S.sumsq4, stats, r.flags, r.ws_e, S.ws_e_bytes, (void*)r.st, r.h->run_dev + (it & 1) * 8,
+                                r.seq_of[it & 1], 0, exchanged);
+    if (rc) return rc;
+    ++r.launched;
+    r.delta_steps += (r.flags & SCD_LLOYD_FULL) ? 0 : 1;
+    return SCD_OK;
+}
+// settle(i): wait for iteration i's statistics; book-keep; *converged when its centre shift is below tol
+static int lr_settle(LloydRestart& r, const LloydShared& S, int i, bool* converged) {
+    volatile double* host = r.h->run_host + (i & 1) * 8;
+    const double want = r.seq_of[i & 1];
+    long long spins = 0;
+    while (host[7] != want) {
+        if ((++spins & 0xFFFFF) == 0) {           // every ~1M polls: has the stream failed, or is this taking absurdly long?
+            const hipError_t e = hipStreamQuery(r.st);
+            if (e != hipSuccess && e != hipErrorNotReady) {
+                scd_set_error("scd_kmeans_lloyd_run: stream error while waiting for iteration %d: %s", i, hipGetErrorString(e));
+                return SCD_EHIP;
+            }
+            if (e == hipSuccess && host[7] != want) {
+                scd_set_error("scd_kmeans_lloyd_run: iteration %d finished without publishing its statistics", i);
+                return SCD_EHIP;
             }
         }
-        refined_seen = host[3];
-        changed_prev = changed_seen;
-        changed_seen = host[4];
-        const float inertia = (float)host[1] + (float)host[0];          // float32 sum of the two float32 parts, as the reference's
-        if (!have_best || inertia < best) {
-            have_best = true;
-            best = inertia;
-            best_it = i;
-            best_in_ring = true;
-        }
-        *converged = host[2] < tol;
-        return SCD_OK;
-    };
-    for (int it = 0; it < max_iter; ++it) {
-        if (best_in_ring && best_it % 3 == it % 3) { const int rc0 = save_best(); if (rc0) return rc0; }   // that slot is about to be re-used
-        const float* c_in = it == 0 ? C_start : C_ring + (size_t)((it - 1) % 3) * kd;
-        float* c_out = C_ring + (size_t)(it % 3) * kd;
-        double* stats = stats_ring + (it & 1) * 5;
-        // SCD_ESTEP_FEW pays only when a handful of rows are flagged, the incremental M-step while few labels move: the cue is the
-        // count the host has seen last (iteration it - 2)
-        const bool few = it >= 2 && refined_seen >= 0. && refined_seen <= 64.;
-        // the changes seen last are two iterations old, and they decay fast (95,000 / 28,600 / 3,700 / 40 / 27 at C2): extrapolate with
-        // the last ratio squared.  A wrong guess costs time only - both M-steps give the same bits
-        double pred = changed_seen;
-        if (it >= 3 && changed_prev > 0. && changed_seen < changed_prev) pred = changed_seen * (changed_seen / changed_prev) * (changed_seen / changed_prev);
-        const bool full = it < 2 || changed_seen < 0. || pred > many;
-        // the hand-over is vouched for only when c_in IS the previous step's C_out: C_start was not produced by a finalize of this
-        // run, and a recycled address from an earlier fit must not be mistaken for one
-        const int flags = (few ? SCD_ESTEP_FEW : 0) | (it > 0 ? SCD_ESTEP_CENTRES_FROM_FINALIZE : 0) | (full ? SCD_LLOYD_FULL : 0);
-        h->run_seq += 1.0;
-        seq_of[it & 1] = h->run_seq;
-        const int rc = lloyd_step_delta_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, lab_ring + (size_t)(it % 3) * n_cat, labels_prev, c_in,
-                                             c_out, sums, counts, sums_lab, counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m,
-                                             ws_m_bytes, stream, h->run_dev + (it & 1) * 8, h->run_seq, 0, xch);
-        if (rc) return rc;
-        ++launched;
-        delta_steps += full ? 0 : 1;
-        if (pending >= 0) {
-            bool conv = false;
-            n_done = pending + 1;
-            { const int rc2 = settle(pending, &conv); if (rc2) return rc2; }
-            pending = -1;
-            if (conv) break;                          // iteration `it` was launched on speculation: dropped unseen (whatever follows on
-                                                      // this stream is ordered behind it)
-        }
-        pending = it;
     }
-    if (pending >= 0) {
-        bool conv = false;
-        n_done = pending + 1;
-        { const int rc2 = settle(pending, &conv); if (rc2) return rc2; }
+    r.refined_seen = host[3];
+    r.changed_prev = r.changed_seen;
+    r.changed_seen = host[4];
+    const float inertia = (float)host[1] + (float)host[0];          // float32 sum of the two float32 parts, as the reference's
+    if (!r.have_best || inertia < r.best) {
+        r.have_best = true;
+        r.best = inertia;
+        r.best_it = i;
+        r.best_in_ring = true;
     }
-    if (best_in_ring) { const int rc0 = save_best(); if (rc0) return rc0; }
-    result_host[0] = (double)best;
-    result_host[1] = (double)n_done;
-    result_host[2] = (double)delta_steps;
-    result_host[3] = (double)launched;
+    *converged = host[2] < S.tol;
     return SCD_OK;
+}
+static int lr_end(LloydRestart& r, const LloydShared& S) {
+    if (r.best_in_ring) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }
+    r.result_host[0] = (double)r.best;
+    r.result_host[1] = (double)r.n_done;
+    r.result_host[2] = (double)r.delta_steps;
+    r.result_host[3] = (double)r.launched;
+    return SCD_OK;
+}
+
+// streams / events of the lock-step driver, created once per device and kept (a stream costs ~100 us to create)
+struct LloydStreams {
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev;      // one per restart slot + 2
+};
+static LloydStreams* lloyd_streams(int device, int n_streams, int n_events) {
+    static std::mutex mu;
+    static std::map<int, LloydStreams> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    LloydStreams& p = pool[device];
+    while ((int)p.st.size() < n_streams) {
+        hipStream_t s;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        p.st.push_back(s);
+    }
+    while ((int)p.ev.size() < n_events) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        p.ev.push_back(e);
+    }
+    return &p;
+}
+
+static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared& S, hipStream_t st, const LloydXch* xch, int n_streams) {
+    const int R = (int)rs.size();
+    SCD_REQUIRE(R >= 1 && S.max_iter >= 1 && S.n_u > 0 && S.n_cat >= S.n_u && (S.n_cat == S.n_u || S.labels_lab), "scd_kmeans_lloyd_run: bad arguments");
+    const size_t kd = (size_t)S.k * S.d, per = kd + (size_t)S.k;
+    LloydStreams* ls = nullptr;
+    const int ns = n_streams > R ? R : n_streams;
+    if (ns > 1) {
+        ls = lloyd_streams(rs[0].h->device, ns, R + 2);
+        SCD_REQUIRE(ls, "scd_kmeans_lloyd_run_multi: could not create streams / events");
+        SCD_HIP(hipEventRecord(ls->ev[R], st));                       // whatever the caller enqueued before the call
+        for (int j = 0; j < ns; ++j) SCD_HIP(hipStreamWaitEvent(ls->st[j], ls->ev[R], 0));
+    }
+    for (int j = 0; j < R; ++j) {
+        rs[j].st = ls ? ls->st[j % ns] : st;
+        const int rc = lr_begin(rs[j], S);
+        if (rc) return rc;
+    }
+    std::vector<int> act;
+    int n_active = R;
+    for (int it = 0; it < S.max_iter && n_active > 0; ++it) {
+        act.clear();
+        for (int j = 0; j < R; ++j) if (rs[j].active) act.push_back(j);
+        for (size_t a = 0; a < act.size(); ++a) {
+            const int rc = lr_launch_a(rs[act[a]], S, it, xch ? xch->buf + a * per : nullptr);
+            if (rc) return rc;
+        }
+        if (xch) {
+            // ONE exchange for the iteration: [sums | counts] of every restart still running, densely packed in restart order (every rank
+            // holds the same set: the stop decisions come from exchanged statistics)
+            if (ls) {
+                for (size_t a = 0; a < act.size(); ++a) {
+                    SCD_HIP(hipEventRecord(ls->ev[act[a]], rs[act[a]].st));
+                    SCD_HIP(hipStreamWaitEvent(st, ls->ev[act[a]], 0));
+                }
+            }
+            const int rc = xch->fn(xch->ctx, xch->buf, (int64_t)(per * act.size()), (void*)st);
+            if (rc) {
+                scd_set_error("scd_kmeans_lloyd_run_sharded: the exchange callback failed (%d)", rc);
+                return SCD_ERCCL;
+            }
+            if (ls) {
+                SCD_HIP(hipEventRecord(ls->ev[R + 1], st));
+                for (int j = 0; j < ns; ++j) SCD_HIP(hipStreamWaitEvent(ls->st[j], ls->ev[R + 1], 0));
+            }
+        }
+        long long* cnt64 = xch ? (long long*)(xch->buf + per * (size_t)R) : nullptr;       // the int64 counts finalize reads, behind the exchange region
+        for (size_t a = 0; a < act.size(); ++a) {
+            LloydRestart& r = rs[act[a]];
+            const double* fsums = nullptr;
+            const int64_t* fcounts = nullptr;
+            if (xch) {
+                double* b = xch->buf + a * per;
+                xch_unpack_kernel<<<(unsigned)scd_cdiv(S.k, 256), 256, 0, r.st>>>(b + kd, S.k, cnt64 + a * (size_t)S.k);
+                fsums = b;
+                fcounts = (const int64_t*)(cnt64 + a * (size_t)S.k);
+            }
+            const int rc = lr_launch_b(r, S, it, fsums, fcounts, xch != nullptr);
+            if (rc) return rc;
+        }
+        for (size_t a = 0; a < act.size(); ++a) {
+            LloydRestart& r = rs[act[a]];
+            if (r.pending >= 0) {
+                bool conv = false;
+                r.n_done = r.pending + 1;
+                { const int rc2 = lr_settle(r, S, r.pending, &conv); if (rc2) return rc2; }
+                r.pending = -1;
+                if (conv) {                       // iteration `it` was launched on speculation: dropped unseen (whatever follows on
+                    r.active = false;             // this stream is ordered behind it)
+                    --n_active;
+                    continue;
+                }
+            }
+            r.pending = it;
+        }
+    }
+    for (int j = 0; j < R; ++j) {
+        LloydRestart& r = rs[j];
+        if (r.active && r.pending >= 0) {
+            bool conv = false;
+            r.n_done = r.pending + 1;
+            { const int rc2 = lr_settle(r, S, r.pending, &conv); if (rc2) return rc2; }
+        }
+        { const int rc = lr_end(r, S); if (rc) return rc; }
+    }
+    if (ls) {                                                       // the caller's stream continues behind every restart's stream
+        for (int j = 0; j < ns; ++j) {
+            SCD_HIP(hipEventRecord(ls->ev[j], ls->st[j]));
+            SCD_HIP(hipStreamWaitEvent(st, ls->ev[j], 0));
+        }
+    }
+    return SCD_OK;
+}
+
+static int lloyd_run_impl(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
+                          int d, int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev,
+                          const float* C_start, float* C_ring, double* sums, int64_t* counts, const double* sums_lab,
+                          const int64_t* counts_lab, const double* sumsq4, double* stats_ring, int max_iter, double tol,
+                          int32_t* best_labels, float* best_C, double* result_host, void* ws_e, size_t ws_e_bytes, void* ws_m,
+                          size_t ws_m_bytes, void* stream, const LloydXch* xch) {
+    const LloydShared S = {X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, sums_lab, counts_lab, sumsq4, max_iter, tol, ws_e_bytes, ws_m_bytes};
+    std::vector<LloydRestart> rs(1);
+    LloydRestart& r = rs[0];
+    r.h = h; r.lab_ring = lab_ring; r.labels_prev = labels_prev; r.C_start = C_start; r.C_ring = C_ring; r.sums = sums; r.counts = counts;
+    r.stats_ring = stats_ring; r.best_labels = best_labels; r.best_C = best_C; r.result_host = result_host; r.ws_e = ws_e; r.ws_m = ws_m;
+    return lloyd_run_multi_impl(rs, S, (hipStream_t)stream, xch, 0);
 }
 
 extern "C" int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat,
@@ -3030,6 +3195,33 @@ extern "C" int scd_kmeans_lloyd_run_sharded(scd_handle h, const float* X_u, cons
     return lloyd_run_impl(h, X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, lab_ring, labels_prev, C_start, C_ring, sums, counts, sums_lab,
                           counts_lab, sumsq4, stats_ring, max_iter, tol, best_labels, best_C, result_host, ws_e, ws_e_bytes, ws_m, ws_m_bytes,
                           stream, &x);
+}
+
+// All restarts of a fit in lock-step (see above).  rs[j] carries restart j's handle and buffers (the per-restart arguments of
+// scd_kmeans_lloyd_run); everything else is shared.  xbuf / exchange non-NULL: a row shard - xbuf holds R * (k*d + 2k) doubles and ONE
+// exchange per iteration carries the [k*d sums | k counts] of the restarts still running, (running restarts) * (k*d + k) doubles, in
+// restart order.  n_streams > 1: restart j's launches go to one of that many library-owned streams (ordered behind everything already
+// in `stream`, and `stream` continues behind them): the restarts' small latency-bound launches overlap each other's E-steps.
+extern "C" int scd_kmeans_lloyd_run_multi(const scd_lloyd_restart* restarts, int R, const float* X_u, const void* prep_u, int64_t n_u,
+                                          const void* X16_cat, int64_t n_cat, int d, int k, const int32_t* labels_lab,
+                                          const double* sums_lab, const int64_t* counts_lab, const double* sumsq4, int max_iter, double tol,
+                                          size_t ws_e_bytes, size_t ws_m_bytes, void* stream, double* xbuf, scd_exchange_fn exchange,
+                                          void* exchange_ctx, int n_streams) {
+    SCD_REQUIRE(restarts && R >= 1 && R <= 1024, "scd_kmeans_lloyd_run_multi: bad restart list");
+    SCD_REQUIRE((xbuf != nullptr) == (exchange != nullptr), "scd_kmeans_lloyd_run_multi: exchange buffer and callback come together");
+    const LloydShared S = {X_u, prep_u, n_u, X16_cat, n_cat, d, k, labels_lab, sums_lab, counts_lab, sumsq4, max_iter, tol, ws_e_bytes, ws_m_bytes};
+    std::vector<LloydRestart> rs((size_t)R);
+    for (int j = 0; j < R; ++j) {
+        const scd_lloyd_restart& q = restarts[j];
+        LloydRestart& r = rs[j];
+        SCD_REQUIRE(q.h, "scd_kmeans_lloyd_run_multi: restart %d has no handle", j);
+        for (int i = 0; i < j; ++i) SCD_REQUIRE(restarts[i].h != q.h, "scd_kmeans_lloyd_run_multi: restarts %d and %d share a handle", i, j);
+        r.h = q.h; r.lab_ring = q.lab_ring; r.labels_prev = q.labels_prev; r.C_start = q.C_start; r.C_ring = q.C_ring; r.sums = q.sums;
+        r.counts = q.counts; r.stats_ring = q.stats_ring; r.best_labels = q.best_labels; r.best_C = q.best_C; r.result_host = q.result_host;
+        r.ws_e = q.ws_e; r.ws_m = q.ws_m;
+    }
+    const LloydXch x = {xbuf, exchange, exchange_ctx};
+    return lloyd_run_multi_impl(rs, S, (hipStream_t)stream, xbuf ? &x : nullptr, n_streams);
 }
 
 extern "C" int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const float* X_cat,

@@ -21,6 +21,8 @@
 #include "common.h"
 #include <vector>
 #include <algorithm>
+#include <thread>
+#include <atomic>
 
 namespace {
 
@@ -79,8 +81,8 @@ struct Solver {
 
 }  // namespace
 
-extern "C" int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
-                                   int64_t* total_cost_out) {
+static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
+                               int64_t* total_cost_out) {
     SCD_REQUIRE(cost && labels_out && n > 0 && k > 0 && size_min >= 0 && size_max >= size_min,
                 "scd_transport_solve: bad arguments");
     if ((int64_t)k * size_min > n || (int64_t)k * size_max < n) {
@@ -222,5 +224,47 @@ extern "C" int scd_transport_solve(const int32_t* cost, int64_t n, int k, int si
             return SCD_EINFEASIBLE;
         }
     if (total_cost_out) *total_cost_out = total;
+    return SCD_OK;
+}
+
+extern "C" int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
+                                   int64_t* total_cost_out) {
+    return transport_solve_one(cost, n, k, size_min, size_max, labels_out, total_cost_out);
+}
+
+// `batch` independent problems of one shape (the ConSSKM E-steps of the restarts of one fit, sskm_constrained.py:165-176: the restarts
+// share nothing but X), solved on up to `threads` host threads.  Problem b reads cost + b * n * k and writes labels_out + b * n,
+// totals_out[b].  Each problem's result is what scd_transport_solve gives for it (one problem never spans threads), so the batch is
+// deterministic whatever the thread count.  Returns the status of the lowest-numbered problem that failed.
+extern "C" int scd_transport_solve_batch(const int32_t* cost, int64_t n, int k, int batch, int size_min, int size_max,
+                                         int32_t* labels_out, int64_t* totals_out, int threads) {
+    SCD_REQUIRE(cost && labels_out && batch > 0 && n > 0 && k > 0, "scd_transport_solve_batch: bad arguments");
+    std::vector<int> rc((size_t)batch, SCD_OK);
+    auto one = [&](int b) {
+        int64_t tot = 0;
+        rc[b] = transport_solve_one(cost + (size_t)b * n * k, n, k, size_min, size_max, labels_out + (size_t)b * n, &tot);
+        if (totals_out) totals_out[b] = tot;
+    };
+    const int nt = std::max(1, std::min(threads, batch));
+    if (nt == 1) {
+        for (int b = 0; b < batch; ++b) one(b);
+    } else {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (int b = next.fetch_add(1); b < batch; b = next.fetch_add(1)) one(b);
+        };
+        std::vector<std::thread> pool;
+        pool.reserve(nt - 1);
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    for (int b = 0; b < batch; ++b)
+        if (rc[b] != SCD_OK) {
+            // the worker's message lives in ITS thread: restate it here
+            if (rc[b] == SCD_EINFEASIBLE) scd_set_error("There was an issue with the min cost flow input.");
+            else scd_set_error("scd_transport_solve_batch: problem %d failed (status %d)", b, rc[b]);
+            return rc[b];
+        }
     return SCD_OK;
 }

@@ -93,6 +93,9 @@ class HipBackend:
     def transport(self, cost, size_min, size_max):
         return self.ops.transport_solve(cost, size_min, size_max)
 
+    def transport_batch(self, costs, size_min, size_max, labels_out=None):
+        return self.ops.transport_solve_batch(costs, size_min, size_max, labels_out=labels_out)
+
 
 _FLAT_GATHER = {}      # (backend, device type) -> the backend has all_gather_into_tensor (agreed across ranks)
 
@@ -580,6 +583,36 @@ class KMeansEngine:
         rs = check_random_state(self.random_state)
         best_inertia = None
         per = inits(rs) if inits is not None else [{} for _ in range(self.n_init)]
+        bufs = kw.get("bufs")
+        dd = self._dist()
+        if (inits is not None and len(per) > 1 and not self.constrained and bufs is not None and getattr(bufs, "inc", False)
+                and hasattr(bufs, "run_multi") and (dd is None or getattr(bufs, "dd", None) is not None)
+                and os.environ.get("SCD_LLOYD_RUN", "1") != "0" and os.environ.get("SCD_LLOYD_LOCKSTEP", "1") != "0"):
+            # the restarts' Lloyd loops in lock-step behind ONE call (scd_kmeans_lloyd_run_multi): iteration i of every restart still running
+            # is enqueued before iteration i - 1 of each is settled, and under a process group one all-reduce per iteration carries all of
+            # them (n_init times fewer collectives per fit).  Every restart runs exactly the launches of its own loop: same bits
+            mix = once == self.fit_mix_once
+            l_num = len(args[2]) if mix else 0
+            if mix:
+                bufs.lab32[:l_num] = per[0]["l_rank"]
+            c_inits = torch.stack([p["init_centers"] for p in per])
+            x0 = getattr(bufs, "_xch_n", 0)
+            res = bufs.run_multi(c_inits, self.max_iterations, self.tolerance, n_streams=int(os.environ.get("SCD_LLOYD_STREAMS", "1")))
+            self.stats["lockstep_fits"] = self.stats.get("lockstep_fits", 0) + 1
+            if dd is not None:                  # all-reduces of the fit's Lloyd loops: one per lock-step iteration, whatever n_init is
+                self.stats["lloyd_exchanges"] = self.stats.get("lloyd_exchanges", 0) + getattr(bufs, "_xch_n", 0) - x0
+            for lab, inertia, cen, n_done, n_delta, n_launched in res:
+                self.stats["estep_calls"] += n_launched
+                self.stats["delta_steps"] = self.stats.get("delta_steps", 0) + n_delta
+                if dd is not None:
+                    self.stats["sharded_runs"] = self.stats.get("sharded_runs", 0) + 1
+                if best_inertia is None or inertia < best_inertia:
+                    self.labels_ = lab.to(torch.int64)
+                    self.cluster_centers_ = cen.clone()
+                    best_inertia = inertia
+                    self.inertia_ = torch.tensor(float(inertia), dtype=torch.float32)
+                    self.n_iter_ = l_num if mix else n_done
+            return
         for extra in per:
             labels, inertia, centers, n_iters = once(*args, rs, **kw, **extra)
             if best_inertia is None or inertia < best_inertia:
@@ -660,3 +693,90 @@ class ConstrainedEngine(KMeansEngine):
         if dd:
             dd.allreduce_(tot)
         return labels.to(torch.int32), np.float32(float(tot))
+
+    # ------------------------------------------------------------------ the restarts' Lloyd loops in lock-step
+    def _run(self, once, *args, inits=None, **kw):
+        """The n_init restarts of a fit (sskm_constrained.py:165-176) share nothing but X once their seedings are drawn (kpp_lockstep
+        draws them all up front from the one random stream), and a restart's iteration is dominated by its flow problem on ONE host
+        core (sskm_constrained.py:116 -> OR-Tools in the reference, scd_transport_solve here).  So the restarts advance together:
+        per iteration the cost matrices of all restarts still running are formed on the device, copied out in one go, solved on as
+        many host threads (scd_transport_solve_batch), and the M-steps follow.  Every restart performs exactly the operations of
+        the sequential loop (KMeansEngine._lloyd) on its own state, so labels, centres, inertia and the winner are the same bits;
+        `SCD_CONSSKM_LOCKSTEP=0` runs the restarts one after the other.  Under a process group the restarts stay sequential (the
+        flow problem is gathered to rank 0 per iteration: _assign)."""
+        be = self._be()
+        data = kw.get("data")
+        if (inits is None or self._dist() is not None or data is None or not hasattr(be, "transport_batch")
+                or not getattr(data.x, "is_cuda", False) or os.environ.get("SCD_CONSSKM_LOCKSTEP", "1") == "0"):
+            return super()._run(once, *args, inits=inits, **kw)
+        rs = check_random_state(self.random_state)
+        per = inits(rs)
+        mix = once == self.fit_mix_once
+        cat = kw["cat"] if mix else data.x
+        l_num = len(args[2]) if mix else 0
+        l_rank = per[0]["l_rank"] if mix else None
+        res = self._lloyd_lockstep(data, cat, kw.get("cat16"), l_num, l_rank, [p["init_centers"] for p in per])
+        best_inertia = None
+        for labels, inertia, centers, n_iters in res:        # restart order, strict < : the sequential loop's winner
+            if best_inertia is None or inertia < best_inertia:
+                self.labels_ = labels.clone()
+                self.cluster_centers_ = centers.clone()
+                best_inertia = inertia
+                self.inertia_ = torch.tensor(float(inertia), dtype=torch.float32)
+                self.n_iter_ = l_num if mix else n_iters     # (fit_mix: the reference's stale-index quirk, sskm_constrained.py:104,139)
+
+    def _lloyd_lockstep(self, data_u, cat, cat16, l_num, l_rank, c_init):
+        be = self._be()
+        dev = cat.device
+        R, k, n_u = len(c_init), self.k, data_u.n
+        labels = []
+        for _ in range(R):
+            lab = torch.empty(len(cat), dtype=torch.int64, device=dev)
+            if l_num:
+                lab[:l_num] = l_rank
+            labels.append(lab)
+        centers = [c for c in c_init]
+        best = [(None, None, None)] * R
+        active = list(range(R))
+        host_cost = torch.empty((R, n_u, k), dtype=torch.int32).pin_memory()
+        host_lab = torch.empty((R, n_u), dtype=torch.int32).pin_memory()
+        n_iters = [0] * R
+        for it in range(self.max_iterations):
+            a_n = len(active)
+            d_sqrts = []
+            for a, j in enumerate(active):
+                d_sqrt, cost = be.dist(data_u, centers[j], sqrt=True, with_cost=True)
+                host_cost[a].copy_(cost, non_blocking=True)
+                d_sqrts.append(d_sqrt)
+            torch.cuda.current_stream(dev).synchronize()
+            be.transport_batch(host_cost[:a_n].numpy(), self.size_min, self.size_max, labels_out=host_lab[:a_n].numpy())
+            self.stats["transport_solves"] = self.stats.get("transport_solves", 0) + a_n
+            lab_dev = host_lab[:a_n].to(dev, non_blocking=True)
+            stats, new_c = [], []
+            for a, j in enumerate(active):
+                u_lab = lab_dev[a]
+                # distances[:] = D[arange, labels] ** 2 in float32, inertia = sum (sskm_constrained.py:271-272)
+                picked = d_sqrts[a].gather(1, u_lab.to(torch.int64).reshape(-1, 1)).reshape(-1)
+                tot = be.sum_f32((picked * picked).contiguous())
+                labels[j][l_num:] = u_lab.to(torch.int64)
+                lab32 = labels[j].to(torch.int32).contiguous()
+                old = centers[j]
+                sums, counts, inertia2 = be.mstep(cat, lab32, old, k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, k, l_num)
+                c_new, shift = be.finalize(sums, counts, old, data_u)
+                new_c.append(c_new)
+                stats.append(torch.cat([inertia2.to(torch.float64), shift.reshape(1).to(torch.float64), tot.reshape(1).to(torch.float64)]))
+            host = torch.stack(stats).cpu().numpy()            # the iteration's only read-back: [A, 4]
+            still = []
+            for a, j in enumerate(active):
+                centers[j] = new_c[a]
+                ui = np.float32(np.float32(float(host[a, 3])))
+                inertia = np.float32(ui + np.float32(host[a, 0]))
+                if best[j][1] is None or inertia < best[j][1]:
+                    best[j] = (labels[j].clone(), inertia, centers[j].clone())
+                n_iters[j] = it + 1
+                if not host[a, 2] < self.tolerance:
+                    still.append(j)
+            active = still
+            if not active:
+                break
+        return [(best[j][0], best[j][1], best[j][2], n_iters[j]) for j in range(R)]

@@ -413,6 +413,63 @@ class LloydBuffers:
         return best_lab, np.float32(r[0]), best_c, int(r[1]), int(r[2]), int(r[3])
 
 
+    def run_multi(self, c_inits, max_iter, tol, n_streams=0):
+        """ALL restarts of the fit in lock-step behind one call (scd_kmeans_lloyd_run_multi): c_inits float32 [R, k, d] are the restarts'
+        seedings (labelled rows' labels in self.lab32[:l_num], shared).  Under a process group ONE all-reduce per iteration carries every
+        running restart's [sums | counts].  Returns a list of run()'s tuples, restart by restart - the same bits as R calls of run()."""
+        if not self._fit_ready:
+            self._prepare_fit()
+        d = self.data
+        dev = self.cat.device
+        n_cat, k, dim = self.cat.shape[0], self.k, d.d
+        R = int(c_inits.shape[0])
+        c_inits = c_inits.to(torch.float32).contiguous()
+        hs = _lib.extra_handles(R)
+        per = getattr(self, "_multi", None)
+        if per is None or per["R"] != R:
+            per = self._multi = dict(
+                R=R, lab_ring=torch.empty((R, 3, n_cat), dtype=torch.int32, device=dev), lab_prev=torch.full((R, n_cat), -1, dtype=torch.int32, device=dev),
+                c_ring=torch.empty((R, 3, k, dim), dtype=torch.float32, device=dev), sums=torch.empty((R, k, dim), dtype=torch.float64, device=dev),
+                counts=torch.empty((R, k), dtype=torch.int64, device=dev), stats_ring=torch.zeros((R, 2, 5), dtype=torch.float64, device=dev),
+                ws_e=[_ws(self.nb_e, dev) for _ in range(R)], ws_m=[_ws(self.nb_m, dev) for _ in range(R)],
+                result=np.zeros((R, 4), dtype=np.float64))
+            if self.dd is not None:
+                xb = per["xbuf"] = torch.empty(R * (k * dim + 2 * k), dtype=torch.float64, device=dev)
+                dd = self.dd
+
+                def _cb(ctx, buf, n_doubles, stream):
+                    try:
+                        dd.allreduce_(xb[: int(n_doubles)])          # the running restarts' [sums | counts], densely packed
+                        self._xch_n = getattr(self, "_xch_n", 0) + 1
+                        return 0
+                    except BaseException as e:          # never let an exception unwind through the C frames
+                        self._xch_err = e
+                        return 1
+                per["cb"] = _lib.EXCHANGE_FN(_cb)
+        best_lab = torch.empty((R, n_cat), dtype=torch.int32, device=dev)
+        best_c = torch.empty((R, k, dim), dtype=torch.float32, device=dev)
+        arr = (_lib.LloydRestart * R)()
+        for j in range(R):
+            a = arr[j]
+            a.h = hs[j].value
+            a.lab_ring, a.labels_prev = per["lab_ring"][j].data_ptr(), per["lab_prev"][j].data_ptr()
+            a.C_start, a.C_ring = c_inits[j].data_ptr(), per["c_ring"][j].data_ptr()
+            a.sums, a.counts, a.stats_ring = per["sums"][j].data_ptr(), per["counts"][j].data_ptr(), per["stats_ring"][j].data_ptr()
+            a.best_labels, a.best_C = best_lab[j].data_ptr(), best_c[j].data_ptr()
+            a.result_host = per["result"][j].ctypes.data
+            a.ws_e, a.ws_m = per["ws_e"][j].data_ptr(), per["ws_m"][j].data_ptr()
+        self._xch_err = None
+        rc = _L().scd_kmeans_lloyd_run_multi(C.cast(arr, C.c_void_p), R, ptr(d.x), ptr(d.prep), d.n, ptr(self.cat16), n_cat, dim, k,
+                                             ptr(self.lab32) if n_cat > d.n else None, ptr(self.sums_lab), ptr(self.counts_lab), ptr(self.sumsq),
+                                             int(max_iter), float(tol), self.nb_e, self.nb_m, stream_ptr(),
+                                             ptr(per["xbuf"]) if self.dd is not None else None,
+                                             C.cast(per["cb"], C.c_void_p) if self.dd is not None else None, None, int(n_streams))
+        if self._xch_err is not None:
+            raise self._xch_err
+        check(rc)
+        res = per["result"]
+        return [(best_lab[j], np.float32(res[j, 0]), best_c[j], int(res[j, 1]), int(res[j, 2]), int(res[j, 3])) for j in range(R)]
+
     def run_sk(self, max_iter, tol):
         """sklearn's `_kmeans_single_lloyd` from self.c0 behind one call (scd_kmeans_lloyd_run_sk; no labelled rows).  Returns
         (labels int32 [n], centres [k, d], n_iter) - the E-step of the final centres and those centres, fresh tensors - or None when an
@@ -730,6 +787,23 @@ def transport_solve(cost, size_min, size_max):
         raise Exception("There was an issue with the min cost flow input.")
     check(rc)
     return labels, total.value
+
+
+def transport_solve_batch(costs, size_min, size_max, threads=None, labels_out=None):
+    """`costs` int32 [B, n, k] (host, C-contiguous): the B problems on up to `threads` host threads (default: the cores this process
+    may use, at most B).  Returns (labels int32 [B, n], totals int64 [B]); raises like transport_solve when a problem is infeasible."""
+    c = np.ascontiguousarray(costs, dtype=np.int32)
+    b, n, k = c.shape
+    labels = labels_out if labels_out is not None else np.empty((b, n), dtype=np.int32)
+    assert labels.dtype == np.int32 and labels.flags.c_contiguous and labels.shape == (b, n)
+    totals = np.zeros(b, dtype=np.int64)
+    if threads is None:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rc = _L().scd_transport_solve_batch(ptr(c), n, k, b, int(size_min), int(size_max), ptr(labels), ptr(totals), int(max(1, threads)))
+    if rc == _lib.SCD_EINFEASIBLE:
+        raise Exception("There was an issue with the min cost flow input.")
+    check(rc)
+    return labels, totals
 
 
 # ----------------------------------------------------------------------------- RCCL exchanges through the C ABI

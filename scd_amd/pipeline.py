@@ -51,7 +51,7 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
         # the shipped default of scripts/evaluate_unsupervised.sh: `KMeans(n_clusters, random_state=0).fit(u_feats).labels_` (:362)
         from .cluster import KMeans
         assert group is None, "--cluster KM is a single-process fit (as in the reference)"
-        km = KMeans(n_clusters=n_cluster, random_state=seed).fit(u_feats)
+        km = KMeans(n_clusters=n_cluster, random_state=0).fit(u_feats)        # the call site's fixed seed (main_unsup.py:362)
         mark("kmeans")
         u_preds = torch.from_numpy(km.labels_).to(feats.device)
         cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote, num_common_linear, max_iter=50)
@@ -71,6 +71,49 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
     mark("vote")
     return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace),
                 kmeans=km)
+
+
+def run_ptsup(model, feat_model, images, mask_lab, l_targets, wt, nouns, lab_names, n_cluster, topk=2, num_common_vote=5,
+              num_common_linear=2, size_min=50, size_max=1000, batch=3990, kmeans_iters=10, n_init=10, seed=0, timers=None):
+    """The partially supervised path (main_ptsup.py:272-705 with the I/O and the eval prints removed) on one GPU: clustering features
+    from the GCD / DINO tower and naming features from CLIP for every image (extract_feature, main_ptsup.py:132-166), raw-logit top-5
+    over the vocabulary (:526-545), size-constrained semi-supervised K-Means with the call-site values (:356-366: ten restarts x ten
+    iterations, bounds --cluster_size_min / --cluster_size_max) and the partially supervised vote (:588-676) with the labelled classes'
+    names kept.  Rows are brought into the reference's labelled-first order (data_utils.py:27-32) by one row selection per matrix."""
+    from .local_utils.sskm_constrained import K_Means as ConSemiSupKMeans
+
+    def mark(name):
+        if timers is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            timers.append((name, ev))
+    mark("start")
+    feats = encode_images(model, images, batch)
+    n = images.shape[0]
+    if feat_model._enc is None:
+        feat_model.cuda()
+    gfeats = torch.empty((n, feat_model._enc.out_dim), dtype=torch.float16, device=images.device)
+    for s in range(0, n, batch):
+        feat_model._enc.encode_image(images[s:s + batch], normalize=True, out=gfeats[s:s + batch])
+    mark("encode")
+    name_idx, _ = naming.full_vocab_topk(feats, None, 5, False, wt=wt)           # TOP_K = 5, no softmax (main_ptsup.py:526-545)
+    mark("sim_topk")
+    mask_h = np.asarray(mask_lab.cpu() if torch.is_tensor(mask_lab) else mask_lab, dtype=bool)
+    iu = torch.from_numpy(np.flatnonzero(~mask_h)).to(feats.device)
+    il = torch.from_numpy(np.flatnonzero(mask_h)).to(feats.device)
+    fu, _, nidx_u = ops.select_rows(feats, iu, name_idx, want32=False)
+    _, gu, _ = ops.select_rows(gfeats, iu, None, want16=False)
+    _, gl, _ = ops.select_rows(gfeats, il, None, want16=False)
+    km = ConSemiSupKMeans(k=n_cluster, tolerance=1e-4, max_iterations=kmeans_iters, init='k-means++', size_min=size_min, size_max=size_max,
+                          n_init=n_init, random_state=seed, n_jobs=None, pairwise_batch_size=1024)
+    km.fit_mix(gu, gl, torch.as_tensor(l_targets, device=feats.device))
+    mark("kmeans")
+    all_preds = km.labels_.cpu().numpy()
+    lab_first = np.arange(n) < int(mask_h.sum())
+    cand, preds, trace = naming.vote_loop_ptsup(nidx_u, all_preds, lab_first, fu, wt, nouns, lab_names, n_cluster, topk, num_common_vote,
+                                                num_common_linear, max_iter=50)
+    mark("vote")
+    return dict(feats=feats, labels=all_preds, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace), kmeans=km)
 
 
 def vote_loop_unsup_sharded(name_idx, u_preds, f_u, wt, nouns, n_cluster, ncv, ncl, group, max_iter=50, be=None, exchange="auto"):

@@ -64,6 +64,9 @@ def main():
     shd = KMeansEngine(k=k, max_iterations=8, n_init=3, random_state=5, group=grp)
     shd.fit_mix(T(u[su]), T(l[sl]), T(lt[sl]))
     assert shd.stats.get("sharded_runs", 0) == 3, "the sharded C loop did not run: %r" % (shd.stats,)
+    # the three restarts advance in lock-step behind ONE call (scd_kmeans_lloyd_run_multi) and share one all-reduce per iteration:
+    # at most max_iterations exchanges for the whole fit (3 x 8 with one loop per restart)
+    assert shd.stats.get("lockstep_fits", 0) == 1 and 1 <= shd.stats.get("lloyd_exchanges", 0) <= 8, shd.stats
     assert shd.stats.get("sharded_seedings", 0) == 1, "the sharded seeding rounds did not run behind scd_kpp_seed_lockstep_sharded: %r" % (shd.stats,)
     full, mine = one.labels_.cpu().numpy(), shd.labels_.cpu().numpy()
     assert np.array_equal(mine[:n_ls], full[:n_l][sl]) and np.array_equal(mine[n_ls:], full[n_l:][su]), "exact rows: sharded labels differ"

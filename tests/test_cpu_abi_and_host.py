@@ -185,6 +185,25 @@ def test_transport_optimal_and_feasible(n, k, smin, smax, seed):
     assert ok and tot == tot_chk == tot_lp
 
 
+def test_transport_batch_equals_single_solves():
+    """scd_transport_solve_batch (the restarts' flow problems of one ConSSKM iteration on host threads, sskm_constrained.py:165-176):
+    every problem's labels and total are scd_transport_solve's, whatever the thread count; an infeasible batch raises like one problem."""
+    from scd_amd import ops
+    rs = np.random.RandomState(9)
+    b, n, k, smin, smax = 7, 900, 12, 50, 110
+    pts = rs.randn(n, 4)
+    costs = np.stack([to.int_costs(((pts[:, None] - rs.randn(k, 4)[None] * 1.5) ** 2).sum(-1).astype(np.float32)) for _ in range(b)])
+    singles = [ops.transport_solve(costs[i], smin, smax) for i in range(b)]
+    for threads in (1, 3, 16):
+        labs, tots = ops.transport_solve_batch(costs, smin, smax, threads=threads)
+        for i in range(b):
+            assert np.array_equal(labs[i], singles[i][0]) and tots[i] == singles[i][1]
+            ok, tot_chk = to.check_assignment(costs[i], labs[i], smin, smax)
+            assert ok and tot_chk == tots[i] and to.check_optimal(costs[i], labs[i], smin, smax)
+    with pytest.raises(Exception, match="There was an issue with the min cost flow input."):
+        ops.transport_solve_batch(costs, 80, smax, threads=4)                 # 12 x 80 > 900
+
+
 def test_transport_infeasible_raises_like_reference():
     from scd_amd import ops
     from scd_amd.local_utils.sskm_constrained import _labels_constrained

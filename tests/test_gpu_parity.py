@@ -521,7 +521,15 @@ def _record_transport(monkeypatch):
         lab, tot = real(cost, size_min, size_max)
         calls.append((np.array(cost, copy=True), size_min, size_max, lab.copy(), tot))
         return lab, tot
+    real_batch = o.transport_solve_batch
+
+    def spy_batch(costs, size_min, size_max, threads=None, labels_out=None):
+        labs, tots = real_batch(costs, size_min, size_max, threads=threads, labels_out=labels_out)
+        for b in range(len(tots)):
+            calls.append((np.array(costs[b], copy=True), size_min, size_max, labs[b].copy(), int(tots[b])))
+        return labs, tots
     monkeypatch.setattr(o, "transport_solve", spy)
+    monkeypatch.setattr(o, "transport_solve_batch", spy_batch)
     calls_real.append(real)
     return calls
 
@@ -530,13 +538,15 @@ calls_real = []          # the un-patched solver (the checks below must not feed
 
 
 def _unique_optimum(cost, smin, smax, labels, ops):
-    """True when three random tie-breaking perturbations of the costs (cost * 1024 + r, r < 8) all give `labels` back:
-    the optimum is then unique (with overwhelming probability), so every exact solver must return these labels."""
+    """True when random tie-breaking perturbations of the costs (cost * 1024 + r, r < 8) AND their complements (cost * 1024 + 7 - r: every
+    tie broken the other way round) all give `labels` back: the optimum is then unique (an alternative optimum survives a seed only where
+    the perturbations of its moves cancel exactly, both ways), so every exact solver must return these labels."""
     for seed in range(3):
         r = np.random.RandomState(100 + seed).randint(0, 8, size=cost.shape)
-        lab, _ = calls_real[-1]((cost.astype(np.int64) * 1024 + r).astype(np.int32), smin, smax)
-        if not np.array_equal(lab, labels):
-            return False
+        for pert in (r, 7 - r):
+            lab, _ = calls_real[-1]((cost.astype(np.int64) * 1024 + pert).astype(np.int32), smin, smax)
+            if not np.array_equal(lab, labels):
+                return False
     return True
 
 
@@ -904,6 +914,108 @@ def test_dino_features_give_the_oracle_features_labels(ops):
     assert np.array_equal(labels[0], labels[1])
     acc = (labels[0][int(mask_lab.sum()):] == y[~mask_lab]).mean()      # and the clustering is the planted one (cluster ids of the
     assert acc > 0.45                                                  # labelled half are class ids; the novel half is permuted)
+
+
+def _assert_pathologies(st, sumsq_bits=43):
+    """The planted pathologies are there (outlier channels >= 50 x the median magnitude, attention logits of several tens, a
+    saturated MLP channel) and inside what the kernels' number formats hold: fp16 activations, and the LayerNorm row statistics
+    the proj / fc2 epilogues accumulate as 64-bit fixed point (sum in 2^-24 units, sum of squares in 2^-20 units: gemm.hip LN = 2)."""
+    assert st["max_abs"] >= 50 * st["median_abs"], st
+    assert st["max_logit"] >= 25, st
+    assert st["max_hidden"] >= 10, st
+    assert st["max_abs"] < 65504 / 8, st
+    assert st["max_sumsq"] < 2.0 ** sumsq_bits and st["max_abs_sum"] < 2.0 ** 39, st     # x 2^20 / x 2^24 stay below 2^63
+
+
+@pytest.mark.parametrize("tower", ["clip_image", "clip_text", "dino"])
+def test_towers_with_outlier_weights_match_oracle(ops, tower):
+    """The offline surrogate for the real checkpoints (main_unsup.py:237 clip.load, :241 dino): seeded weights carrying a trained
+    ViT's pathologies - outlier residual channels, LayerNorm gains over 2.6 decades, sharp attention heads, bias spikes
+    (tests/outlier_weights.py) - through all twelve blocks of each tower, against the fp32 oracle, at the north-star tolerance."""
+    import outlier_weights as ow
+    from scd_amd.clip.model import CLIP, DinoViT
+    img = torch.randn(5, 3, 224, 224, generator=torch.Generator().manual_seed(78)).half().float()
+    if tower == "dino":
+        sd, _ = ow.dino_outlier_state_dict(seed=1, layers=12)
+        sd16 = ow.round_like_the_device(sd)
+        _assert_pathologies(ow.residual_stream_stats(sd16, "dino", img[:2]))
+        out = DinoViT(sd).cuda()(img.cuda()).float().cpu()
+        ref = co.dino_forward(sd16, img)
+    else:
+        sd, _, _ = ow.clip_outlier_state_dict(seed=0, layers=12)
+        sd16 = ow.round_like_the_device(sd)
+        model = CLIP(sd).cuda().eval()
+        if tower == "clip_image":
+            _assert_pathologies(ow.residual_stream_stats(sd16, "clip_visual", img[:2]))
+            out = model.encode_image(img.cuda()).float().cpu()
+            ref = co.clip_encode_image(sd16, img)
+        else:
+            tok = torch.zeros(6, 77, dtype=torch.int32)
+            g = torch.Generator().manual_seed(79)
+            for i, ln in enumerate((1, 3, 8, 20, 40, 75)):
+                tok[i, 0] = 49406
+                tok[i, 1:1 + ln] = torch.randint(1, 49405, (ln,), generator=g, dtype=torch.int32)
+                tok[i, 1 + ln] = 49407
+            _assert_pathologies(ow.residual_stream_stats(sd16, "clip_text", tok.long()))
+            out = model.encode_text(tok.cuda()).float().cpu()
+            ref = co.clip_encode_text(sd16, tok.long())
+    assert bool(torch.isfinite(out).all())
+    assert _cos(out, ref).min().item() > 1 - 1e-3
+    assert (out - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+
+
+def test_outlier_weight_features_give_the_oracle_features_labels_and_names(ops):
+    """What the towers' features are USED for, on the outlier-weight checkpoints: on a class-structured image set the SSKM labels
+    (main_unsup.py:339-350) from the HIP DINO features equal those from the fp32 oracle's features row for row, and the top-1 names
+    (main_unsup.py:504-531) of the HIP CLIP image features against a vocabulary built by the HIP text tower equal the top-1 names
+    of the oracle's image features against the oracle's text features."""
+    import outlier_weights as ow
+    from scd_amd.clip.model import CLIP, DinoViT
+    from scd_amd.kmeans import KMeansEngine
+    n_cls, per = 6, 10
+    g = torch.Generator().manual_seed(321)
+    base = torch.randn(n_cls, 3, 224, 224, generator=g)
+    y = np.repeat(np.arange(n_cls), per)
+    img = (base[torch.from_numpy(y)] + 0.6 * torch.randn(n_cls * per, 3, 224, 224, generator=g)).half().float()
+    norm = lambda t: torch.nn.functional.normalize(t.float(), dim=-1)
+    # clustering features
+    sdd, _ = ow.dino_outlier_state_dict(seed=1, layers=12)
+    sdd16 = ow.round_like_the_device(sdd)
+    hip = norm(DinoViT(sdd).cuda()(img.cuda())).cpu()
+    ref = norm(torch.cat([co.dino_forward(sdd16, img[i:i + 12]) for i in range(0, len(img), 12)]))
+    assert _cos(hip, ref).min().item() > 1 - 1e-3
+    rs = np.random.RandomState(3)
+    mask_lab = (y < n_cls // 2) & (rs.rand(len(y)) < 0.5)
+    labels = []
+    for feats in (hip, ref):
+        km = KMeansEngine(k=n_cls, tolerance=1e-4, max_iterations=10, n_init=10, random_state=0)
+        km.fit_mix(feats[~mask_lab].cuda(), feats[mask_lab].cuda(), torch.from_numpy(y[mask_lab]).cuda())
+        labels.append(km.labels_.cpu().numpy())
+    assert np.array_equal(labels[0], labels[1])
+    # names
+    sd, _, _ = ow.clip_outlier_state_dict(seed=0, layers=12)
+    sd16 = ow.round_like_the_device(sd)
+    model = CLIP(sd).cuda().eval()
+    f_hip = norm(model.encode_image(img.cuda())).cpu()
+    f_ref = norm(torch.cat([co.clip_encode_image(sd16, img[i:i + 12]) for i in range(0, len(img), 12)]))
+    assert _cos(f_hip, f_ref).min().item() > 1 - 1e-3
+    v = 48
+    tok = torch.zeros(v, 77, dtype=torch.int32)
+    gt = torch.Generator().manual_seed(5)
+    for i in range(v):
+        ln = 2 + i % 9
+        tok[i, 0] = 49406
+        tok[i, 1:1 + ln] = torch.randint(1, 49405, (ln,), generator=gt, dtype=torch.int32)
+        tok[i, 1 + ln] = 49407
+    w_hip = norm(model.encode_text(tok.cuda())).cpu()
+    w_ref = norm(co.clip_encode_text(sd16, tok.long()))
+    assert _cos(w_hip, w_ref).min().item() > 1 - 1e-3
+    idx, _ = ops.sim_topk(f_hip.half().cuda(), w_hip.half().cuda().contiguous(), 1, "raw")
+    s_ref = f_ref.double() @ w_ref.double().t()
+    top2 = s_ref.topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 4e-3                     # both operands within 1e-3 in cosine: a margin no such error flips
+    assert decided.float().mean().item() > 0.8
+    assert np.array_equal(idx[:, 0].cpu().numpy()[decided.numpy()], s_ref.argmax(1).numpy()[decided.numpy()])
 
 
 def test_zeroshot_classifier_pooling(ops):
@@ -1390,6 +1502,89 @@ def test_c3_shape_ptsup_end_to_end(ops, tmp_path, monkeypatch, capsys):
     assert set(lab_names) <= set(cand) and len(cand) == k
 
 
+def test_c3_shape_ptsup_end_to_end_consskm(ops, tmp_path, monkeypatch, capsys):
+    """BASELINE configs[2] AS NAMED: Stanford Dogs partially supervised through main_ptsup.main() with its DEFAULT clustering -
+    `--cluster ConSSKM`, size bounds 50 / 1000, ten restarts x ten iterations (main_ptsup.py:236,239-240,356-366) - on the
+    reference's cache files at the config's shape (12,000 x 768 GCD features, ~3,000 labelled, K = 120, dog-name corpus).
+    * every flow problem of the fit (one per restart and iteration) is feasible, inside the bounds and optimal (no negative cycle in
+      the residual graph = the LP certificate of oracle/transport_oracle.py); where its optimum is unique (perturbation check) the
+      labels are the LP's labels.  OR-Tools' own labels are third-party-unpinned (SURVEY.md 8c);
+    * the restarts advance in lock-step over host threads (ConstrainedEngine._run): all_preds equals the sequential fit's, bit for bit;
+    * everything downstream of the clustering - top-5 indices, every iteration of the partially supervised vote, final names and
+      u_preds - equals the oracle chain run from OUR all_preds (main_ptsup.py:526-545,588-676)."""
+    import importlib
+    import json
+    import time
+    import scd_amd.clip as clip
+    from scd_amd import naming
+    from scd_amd.local_utils.sskm_constrained import K_Means
+    root = str(tmp_path)
+    n, k, v = 12000, 120, 1000
+    x, y, mask_lab, w, xf = _write_cache_tree(root, n=n, k=k, v=v, seed=71, dataset="sdogs", corpus="wikidog", d_feat=768, feat_model="gcd")
+    monkeypatch.setenv("SCD_ROOT", root)
+    monkeypatch.setenv("SCD_DATA", os.path.join(root, "data"))
+    monkeypatch.setattr(clip, "_tokenizer", None)
+    monkeypatch.setenv("SCD_SYNTHETIC", "1")
+    mp_ = importlib.import_module("main_ptsup")
+    calls = _record_transport(monkeypatch)
+    np.random.seed(11)                                  # random_state=None at the call site (main_ptsup.py:369): numpy's global stream
+    cand, u_preds = mp_.main(["--root_dir", root, "--dataset_name", "sdogs", "--corpus", "wikidog", "--feat_model", "gcd", "--n_cluster", str(k),
+                              "--topk", "2", "--num_common_vote", "5", "--num_common_linear", "2", "--run_cluster", "true",
+                              "--save_cluster", "true", "--class_names", os.path.join(root, "class_names.json")])
+    out = capsys.readouterr().out
+    assert "Fitting ConSSKM" in out
+    saved = torch.load(os.path.join(root, "cluster", "ConSSKM_gcd_sdogs.pt"), weights_only=False)
+    all_preds = np.asarray(saved["all_preds"])
+    n_l = int(mask_lab.sum())
+    cnt = np.bincount(all_preds[n_l:], minlength=k)
+    assert cnt.min() >= 50 and cnt.max() <= 1000
+    assert np.array_equal(all_preds[:n_l], np.searchsorted(np.unique(y[:n_l]), y[:n_l]))       # labelled rows keep their classes
+    # the flow problems: 10 restarts x (up to) 10 iterations
+    n_calls = len(calls)
+    assert 10 <= n_calls <= 100 and all(c[0].shape == (n - n_l, k) for c in calls)
+    n_unique = 0
+    for i, (cost, smin, smax, labs, tot) in enumerate(list(calls)):
+        ok, tot_chk = to.check_assignment(cost, labs, smin, smax)
+        assert (smin, smax) == (50, 1000) and ok and tot == tot_chk and to.check_optimal(cost, labs, smin, smax)
+        if i % 9 == 0 and _unique_optimum(cost, smin, smax, labs, ops):       # a sample: the uniqueness check is three more solves,
+            n_unique += 1                                                      # and the LP takes 10-30 s per problem at this size
+            if n_unique <= 2:
+                lp_lab, lp_tot = to.solve_lp(cost, smin, smax)
+                assert lp_tot == tot and np.array_equal(labs, lp_lab)
+    # lock-step restarts = sequential restarts (same fit, same stream), and the time of the default fit
+    fits = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCD_CONSSKM_LOCKSTEP", mode)
+        np.random.seed(11)
+        km = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", size_min=50, size_max=1000, n_init=10,
+                     random_state=None, n_jobs=None, pairwise_batch_size=1024)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        km.fit_mix(dev(xf[~mask_lab]), dev(xf[mask_lab]), dev(y[mask_lab]))
+        torch.cuda.synchronize()
+        fits[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), time.time() - t0)
+    monkeypatch.delenv("SCD_CONSSKM_LOCKSTEP")
+    assert np.array_equal(fits["1"][0], fits["0"][0]) and np.array_equal(fits["1"][1], fits["0"][1]) and fits["1"][2] == fits["0"][2]
+    assert np.array_equal(fits["1"][0], all_preds)
+    print("C3 ConSSKM fit (10 restarts x 10 iterations, 9,000 x 120 flow problems): lock-step %.2f s, sequential %.2f s, %d solves, "
+          "%d of the sampled optima unique" % (fits["1"][3], fits["0"][3], n_calls, n_unique))
+    assert fits["1"][3] < 10.0
+    # downstream of OUR labels: the oracle chain
+    nouns = ["noun_%03d" % i for i in range(v)]
+    f16, w16 = x.astype(np.float16), w.astype(np.float16)
+    oidx, _ = no.sim_topk(f16, w16, 5, "raw")
+    model, _ = clip.load("ViT-B/16")
+    with open(os.path.join(root, "class_names.json")) as fh:
+        class_to_idx = {kk: int(vv) for kk, vv in json.load(fh).items()}
+    wt = ops.transpose_f16(dev(w16))
+    cname = naming.resolve_class_names("sdogs", "wikidog", class_to_idx, nouns, wt, model.cuda().eval())
+    lab_names = [cname[c] for c in range(k // 2)]
+    otr = no.vote_loop_ptsup(oidx[~mask_lab], all_preds, mask_lab, f16[~mask_lab], w16, nouns, lab_names, k, 2, 5, 2)
+    assert "voting converged after %d iterations" % len(otr) in out
+    assert list(cand) == [nouns[c] for c in otr[-1]["cand"].tolist()] and np.array_equal(np.asarray(u_preds), otr[-1]["u_preds"])
+    assert set(lab_names) <= set(cand) and len(cand) == k
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "e", "c", "c1"])
 def test_sklearn_102_seeding_matches_reference_k_init(ops, golden, tag):
     """The default mode of scd_amd.cluster.KMeans (scikit-learn 1.0.2 rules, the reference's pin): scd_kpp_greedy_lockstep picks the
@@ -1634,6 +1829,31 @@ def test_multi_rank_rccl(ops):
         assert "rank %d ok" % rank in r.stdout
 
 
+def test_bench_launcher_four_ranks_tiny_gloo(ops):
+    """`python bench.py --gpus 4` end to end at a tiny size: bench.py starts torch.distributed.run as a child (the driver's own launch
+    line), four ranks share this box's one GPU (gloo collectives on device tensors: RCCL refuses a duplicate device) and
+    run the whole sharded job - sharded text-tower vocabulary build + all-gather, encode, similarity, the sharded k-means++ rounds and
+    Lloyd loops behind their C calls, the sharded vote - through the barriers and the max-over-ranks timing to rank 0's JSON line.
+    What it proves is that the launcher / ranks path of the N > 1 job neither deadlocks nor diverges before an 8-GPU node ever runs
+    it.  Four ranks, not eight: a GPU box admits at most six processes on its card, this one included."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SCD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SCD_HIP_LIB", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--images", "1200", "--n-cluster", "12",
+           "--vocab", "1024", "--batch", "665", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "dp4" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vote_iters"] >= 1
+    assert abs(d["value"] - 4 * 1200 / (d["ms_per_step"] / 1e3)) <= 1e-2 * d["value"]      # whole-job images over the max-over-ranks time
+    assert d["synthetic_name_accuracy"] > 0.5
+
+
 def test_two_ranks_one_gpu_sharded_kmeans(ops):
     """The same worker as two ranks SHARING this box's one GPU (gloo collectives on device tensors; RCCL refuses a duplicate device):
     the sharded SSKM / K-Means fits - lock-step seeding over the three all-gathers, Lloyd loops behind scd_kmeans_lloyd_run_sharded
@@ -1711,22 +1931,30 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     x = x.astype(np.float16).astype(np.float32)
     mask = (y < k // 2) & (np.random.RandomState(7).rand(n) < 0.5) if labelled else np.zeros(n, dtype=bool)
     res = {}
-    # "1": scd_kmeans_lloyd_run (the restart's loop in C); "py": the same steps driven from Python; "0": a fresh M-step per iteration
-    for mode in ("1", "py", "0"):
+    # "1": scd_kmeans_lloyd_run_multi (all restarts' loops in lock-step behind one C call, the default); "streams": the same over four
+    # streams; "seq": scd_kmeans_lloyd_run, one restart after the other; "py": the same steps driven from Python; "0": a fresh M-step
+    # per iteration
+    for mode in ("1", "streams", "seq", "py", "0"):
         monkeypatch.setenv("SCD_MSTEP_DELTA", "0" if mode == "0" else "1")
         monkeypatch.setenv("SCD_LLOYD_RUN", "0" if mode == "py" else "1")
+        monkeypatch.setenv("SCD_LLOYD_LOCKSTEP", "0" if mode == "seq" else "1")
+        monkeypatch.setenv("SCD_LLOYD_STREAMS", "4" if mode == "streams" else "1")
         km = KMeansEngine(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
         if labelled:
             km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
         else:
             km.fit(dev(x))
-        res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, dict(km.stats))
+        st = dict(km.stats)
+        lockstep = st.pop("lockstep_fits", 0)
+        assert lockstep == (1 if mode in ("1", "streams") else 0)
+        res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, st)
     assert res["1"][4].get("delta_steps", 0) > 0 and res["0"][4].get("delta_steps", 0) == 0
     # (an empty cluster's centre is NaN in the reference and here: equal_nan)
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
     assert res["1"][2] == res["0"][2] and res["1"][3] == res["0"][3]
-    assert np.array_equal(res["1"][0], res["py"][0]) and np.array_equal(res["1"][1], res["py"][1], equal_nan=True)
-    assert res["1"][2] == res["py"][2] and res["1"][3] == res["py"][3] and res["1"][4] == res["py"][4]
+    for other in ("streams", "seq", "py"):
+        assert np.array_equal(res["1"][0], res[other][0]) and np.array_equal(res["1"][1], res[other][1], equal_nan=True), other
+        assert res["1"][2] == res[other][2] and res["1"][3] == res[other][3] and res["1"][4] == res[other][4], other
     okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
     if labelled:
         okm.fit_mix(x[~mask], x[mask], y[mask])
