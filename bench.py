@@ -504,11 +504,20 @@ def main():
     mask_lab = pipeline.labelled_split(y, n_cls, seed=5 + rank)
     l_targets = y[torch.as_tensor(mask_lab, device=dev)]
     feat_model = None
+    name_row = np.arange(n_cls)                    # vocabulary row of class c's true name
     if args.config == "c3":
         from scd_amd.clip import weights as W
         from scd_amd.clip.model import DinoViT
         feat_model = DinoViT(W.synthetic_dino_state_dict(seed=1, layers=12)).cuda()      # the GCD tower = DINO ViT-B/16 (main_ptsup.py:263-287)
-        lab_names = [nouns[c] for c in range(n_cls // 2)]                                 # the labelled classes' names are known (:597-603)
+        # the true names sit at scattered vocabulary rows, as in a real corpus: with them at rows 0..K-1 the reference's `known_name_idx`
+        # quirk (candidate POSITIONS compared with vocabulary indices from the second vote iteration on, main_ptsup.py:638,666) would
+        # filter out exactly the true names
+        name_row = np.sort(np.random.RandomState(123).choice(np.arange(n_cls, args.vocab), size=n_cls, replace=False))
+        rows_t = torch.as_tensor(name_row, device=dev)
+        proto, other = wt[:n_cls].clone(), wt[rows_t].clone()
+        wt[rows_t] = proto
+        wt[:n_cls] = other
+        lab_names = [nouns[name_row[c]] for c in range(n_cls // 2)]                       # the labelled classes' names are known (:597-603)
 
     def barrier():
         torch.cuda.synchronize()
@@ -555,7 +564,8 @@ def main():
     # quality of the synthetic run (not part of the metric): cluster purity and names found
     yn = y.cpu().numpy()
     u_true = yn[~mask_lab]
-    name_hits = float(np.mean(np.array([int(n.split("_")[1]) for n in out["cand_names"]])[out["u_preds"]] == u_true))
+    class_of_row = {int(r): c for c, r in enumerate(name_row)}
+    name_hits = float(np.mean(np.array([class_of_row.get(int(n.split("_")[1]), -1) for n in out["cand_names"]])[out["u_preds"]] == u_true))
 
     if rank == 0:
         total_images = args.images * world * args.steps

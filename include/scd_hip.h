@@ -49,6 +49,14 @@ size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k);
 int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
                  int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws, size_t ws_bytes,
                  void* stream);
+/* The vocabulary is constant over a run (main_unsup.py:389-394 loads it once; :504-531 uses it for every block of rows): its only
+ * data-dependent ingredient in the error bound, max_v ||w_v||^2, can be computed ONCE (wmax2_out: 4 bytes of device memory) and handed
+ * to every later call instead of being recomputed by each (12 us of a 2.7-ms call at V = 21,000).  The caller vouches that Wt has not
+ * changed since; scd_sim_topk computes the norm itself. */
+int scd_sim_vocab_norm(scd_handle h, const void* Wt, int64_t v, int d, void* wmax2_out, void* stream);
+int scd_sim_topk_prenorm(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
+                         int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws, size_t ws_bytes,
+                         const void* wmax2, void* stream);
 /* argmax re-classification over the K candidate names (main_unsup.py:601-614, main_ptsup.py:668-676, get_clip_preds_fast
  * main_ptsup.py:78-99): idx_out int64 [n], val_out float32 [n] = scd_sim_topk with k = 1 on the raw logits (ws: scd_sim_topk_ws_bytes(n, d, v, 1)). */
 int scd_sim_argmax(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int64_t* idx_out,

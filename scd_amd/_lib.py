@@ -51,6 +51,8 @@ SIGNATURES = {
     "scd_l2norm_rows": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp]),
     "scd_sim_topk_ws_bytes": (_sz, [_i64, _i, _i64, _i]),
     "scd_sim_topk": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "scd_sim_vocab_norm": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "scd_sim_topk_prenorm": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "scd_sim_argmax": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _sz, _vp]),
     "scd_transpose_f16": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scd_gather_rows_f16": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),

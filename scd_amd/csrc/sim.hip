@@ -1903,9 +1903,35 @@ extern "C" size_t scd_sim_topk_ws_bytes(int64_t n, int d, int64_t v, int k) {
            scd_align(sizeof(ExPart) * (size_t)ex_rows_cap(v) * ex_nchunks(v)) + SIM_SPLIT_BYTES;
 }
 
-extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
-                            int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws,
-                            size_t ws_bytes, void* stream_) {
+// one launch instead of three fills: the header ({max ||w||^2, fallback counter}), and the output slots no pass fills (a row whose logits
+// are NaN has no ordered candidates) as index -1 / value NaN (all-ones bits), never garbage
+__global__ void __launch_bounds__(256) sim_init_kernel(SimHdr* hdr, const unsigned* __restrict__ wmax2_src, unsigned long long* __restrict__ idx_out,
+                                                       unsigned* __restrict__ val_out, long long nk) {
+    const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (i0 == 0) {
+        hdr->wmax2_bits = wmax2_src ? *wmax2_src : 0u;
+        hdr->fb_cnt = 0;
+    }
+    for (long long i = i0; i < nk; i += step) {
+        idx_out[i] = ~0ull;
+        val_out[i] = ~0u;
+    }
+}
+
+extern "C" int scd_sim_vocab_norm(scd_handle h, const void* Wt, int64_t v, int d, void* wmax2_out, void* stream_) {
+    SCD_DEVICE_ENTRY(h, "scd_sim_vocab_norm");
+    SCD_REQUIRE(Wt && wmax2_out && v > 0 && d > 0 && d % 8 == 0, "scd_sim_vocab_norm: bad arguments");
+    hipStream_t st = (hipStream_t)stream_;
+    SCD_HIP(hipMemsetAsync(wmax2_out, 0, 4, st));
+    const long long wb = scd_cdiv(v, 32);
+    wmax_kernel<<<(unsigned)(wb < 256 ? 256 : (wb > 2048 ? 2048 : wb)), 256, 0, st>>>((const half_t*)Wt, v, d, (unsigned*)wmax2_out);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
+static int sim_topk_impl(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
+                         int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws,
+                         size_t ws_bytes, const void* wmax2, void* stream_) {
     SCD_REQUIRE(h && F && Wt && idx_out && val_out && ws, "scd_sim_topk: null argument");
     SCD_REQUIRE(n > 0 && v > 0 && n < (1ll << 31) && v < (1ll << 31), "scd_sim_topk: bad shape n=%lld v=%lld", (long long)n, (long long)v);
     SCD_REQUIRE(d > 0 && d <= 512 && d % 64 == 0, "scd_sim_topk: d=%d must be a multiple of 64, <= 512", d);
@@ -1915,9 +1941,6 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     SCD_REQUIRE(ws_bytes >= scd_sim_topk_ws_bytes(n, d, v, k), "scd_sim_topk: workspace too small");
     { const int rc_ = scd_check_device(h, "scd_sim_topk"); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream_;
-    // slots no pass fills (a row whose logits are NaN has no ordered candidates) read as index -1 / value NaN, never as garbage
-    SCD_HIP(hipMemsetAsync(idx_out, 0xFF, (size_t)n * k * 8, st));
-    SCD_HIP(hipMemsetAsync(val_out, 0xFF, (size_t)n * k * 4, st));
     char* w = (char*)ws;
     SimHdr* hdr = (SimHdr*)w;
     const size_t csz = scd_align((size_t)n * 2 * TOPM * 4);
@@ -1929,10 +1952,16 @@ extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t
     ExPart* expart = (ExPart*)(w + 64 + 2 * csz + scd_align((size_t)n * 32) + scd_align((size_t)n * 4) * 2 + 256);
     const half_t* f = (const half_t*)F;
     const half_t* wt = (const half_t*)Wt;
-    SCD_HIP(hipMemsetAsync(hdr, 0, 64, st));
+    {   // header + unfilled output slots in one launch (were three fills); max ||w||^2 from the caller (scd_sim_vocab_norm: the vocabulary is
+        // constant over a run, its norm was recomputed by every call: 12 us of a 2.7-ms call) or computed here
+        const long long nk = (long long)n * k;
+        const long long ib = scd_cdiv(nk, 256 * 8);
+        sim_init_kernel<<<(unsigned)(ib < 1 ? 1 : (ib > 1024 ? 1024 : ib)), 256, 0, st>>>(hdr, (const unsigned*)wmax2, (unsigned long long*)idx_out,
+                                                                                         (unsigned*)val_out, nk);
+    }
     // one sweep of the rows (32 per block and iteration) up to 2,048 blocks: at V = 21,000 the 256-block launch walked the vocabulary in
     // three dependent iterations per wave (12 us for 21.5 MB)
-    { const long long wb = scd_cdiv(v, 32); wmax_kernel<<<(unsigned)(wb < 256 ? 256 : (wb > 2048 ? 2048 : wb)), 256, 0, st>>>(wt, v, d, &hdr->wmax2_bits); }
+    if (!wmax2) { const long long wb = scd_cdiv(v, 32); wmax_kernel<<<(unsigned)(wb < 256 ? 256 : (wb > 2048 ? 2048 : wb)), 256, 0, st>>>(wt, v, d, &hdr->wmax2_bits); }
     const unsigned g1 = (unsigned)scd_cdiv(n, 256), g2 = (unsigned)scd_cdiv(n, 4);
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<true, 8>, 65536 + 32768); if (rc_) return rc_; }
     { const int rc_ = scd_set_max_lds((const void*)sim_topk_kernel<false, 8>, 65536 + 32768); if (rc_) return rc_; }
@@ -2243,6 +2272,17 @@ extern "C" int scd_prompt_pool(scd_handle h, const void* emb, int n_names, int t
 
 // SURVEY.md 8b names the re-classification `argmax(scale * F @ Wt^T, -1)` (main_unsup.py:601-614, main_ptsup.py:668-676) as an entry
 // point of its own: it is scd_sim_topk with k = 1 on the raw logits (same kernels, same tie rule: the lowest index wins).
+extern "C" int scd_sim_topk(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
+                            int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return sim_topk_impl(h, F, Wt, n, d, v, scale, k, mode, idx_out, val_out, fallback_rows_out, ws, ws_bytes, nullptr, stream);
+}
+extern "C" int scd_sim_topk_prenorm(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int k,
+                                    int mode, int64_t* idx_out, float* val_out, int32_t* fallback_rows_out, void* ws,
+                                    size_t ws_bytes, const void* wmax2, void* stream) {
+    SCD_REQUIRE(wmax2, "scd_sim_topk_prenorm: null vocabulary norm (scd_sim_vocab_norm)");
+    return sim_topk_impl(h, F, Wt, n, d, v, scale, k, mode, idx_out, val_out, fallback_rows_out, ws, ws_bytes, wmax2, stream);
+}
 extern "C" int scd_sim_argmax(scd_handle h, const void* F, const void* Wt, int64_t n, int d, int64_t v, float scale, int64_t* idx_out,
                               float* val_out, void* ws, size_t ws_bytes, void* stream) {
     return scd_sim_topk(h, F, Wt, n, d, v, scale, 1, SCD_SIM_RAW, idx_out, val_out, nullptr, ws, ws_bytes, stream);

@@ -103,11 +103,31 @@ def mean2_f16(a, b):
 
 
 # ----------------------------------------------------------------------------- similarity
+_vocab_norms = {}        # id(wt) -> (weakref, data_ptr, _version, shape, device tensor with max ||w||^2)
+
+
+def vocab_norm(wt):
+    """max_v ||w_v||^2 of a name-major fp16 vocabulary, computed once per tensor (scd_sim_vocab_norm) and reused by every sim_topk call on
+    it while the tensor is unchanged (same storage address, same shape, and torch's in-place write counter `_version` has not moved)."""
+    key = id(wt)
+    ent = _vocab_norms.get(key)
+    if ent is not None and ent[0]() is wt and ent[1] == wt.data_ptr() and ent[2] == wt._version and ent[3] == tuple(wt.shape):
+        return ent[4]
+    out = torch.empty(1, dtype=torch.int32, device=wt.device)
+    check(_L().scd_sim_vocab_norm(handle(), ptr(wt), wt.shape[0], wt.shape[1], ptr(out), stream_ptr()))
+    if len(_vocab_norms) > 64:
+        for kk in [kk for kk, e in _vocab_norms.items() if e[0]() is None]:
+            del _vocab_norms[kk]
+    _vocab_norms[key] = (weakref.ref(wt), wt.data_ptr(), wt._version, tuple(wt.shape), out)
+    return out
+
+
 def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
     """Top-k of scale * f @ wt.T per row.  f [n,d] fp16, wt [v,d] fp16 (name-major).
     Returns (idx int64 [n,k], val float32 [n,k])."""
     _need_cuda(f, wt)
     f = f.to(torch.float16).contiguous()
+    wt_in = wt
     wt = wt.to(torch.float16).contiguous()
     n, d = f.shape
     v = wt.shape[0]
@@ -117,8 +137,13 @@ def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
     nb = _L().scd_sim_topk_ws_bytes(n, d, v, k)
     ws = _ws(nb, f.device)
     m = SIM_SOFTMAX if mode == "softmax" else SIM_RAW
-    check(_L().scd_sim_topk(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb),
-                            ptr(ws), nb, stream_ptr()))
+    if wt is wt_in and v >= 4096:
+        # a vocabulary tensor handed in as it is stored (the full vocabulary of main_unsup.py:504-531, reused by every call): its norm once
+        check(_L().scd_sim_topk_prenorm(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb),
+                                        ptr(ws), nb, ptr(vocab_norm(wt)), stream_ptr()))
+    else:
+        check(_L().scd_sim_topk(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb),
+                                ptr(ws), nb, stream_ptr()))
     if return_fallback:
         return idx, val, fb
     return idx, val

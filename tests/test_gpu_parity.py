@@ -675,6 +675,36 @@ def test_sim_topk_shapes(ops, n, v, d, k):
     assert np.array_equal(a.cpu().numpy(), oi[:, 0])
 
 
+def test_sim_topk_vocabulary_norm_is_computed_once_and_follows_the_tensor(ops):
+    """ops.sim_topk hands the vocabulary's max ||w||^2 (the data-dependent part of the filter's error bound) to scd_sim_topk_prenorm and
+    computes it once per vocabulary tensor (scd_sim_vocab_norm); an in-place change of the tensor (torch's `_version`) or a new tensor
+    gets a fresh one - a stale, too small norm would certify rows it must not.  Indices equal the oracle's before and after the change,
+    and equal the plain scd_sim_topk call's (main_unsup.py:504-531)."""
+    n, v, d, k = 700, 5000, 512, 3
+    rs = np.random.RandomState(17)
+    f = (rs.randn(n, d) / np.sqrt(d)).astype(np.float16)
+    w = (rs.randn(d, v) / np.sqrt(d)).astype(np.float16)
+    wt = ops.transpose_f16(dev(w))
+    idx1, val1 = ops.sim_topk(dev(f), wt, k, "softmax")
+    norm1 = ops.vocab_norm(wt)
+    assert ops.vocab_norm(wt) is norm1                             # cached
+    idx2, val2 = ops.sim_topk(dev(f), wt, k, "softmax")
+    oi, ov = no.sim_topk(f, w, k, "softmax")
+    assert np.array_equal(idx1.cpu().numpy(), oi) and torch.equal(idx1, idx2) and torch.equal(val1, val2)
+    w32 = float(norm1.view(torch.float32).item())
+    assert abs(w32 - float((w.astype(np.float64) ** 2).sum(0).max())) <= 1e-3 * w32
+    # in place: 40 x larger names in the second half - with the old norm the bound would be 40 x too small
+    wt[v // 2:] *= 40.0
+    w2 = w.copy()
+    w2[:, v // 2:] = (w2[:, v // 2:].astype(np.float32) * 40.0).astype(np.float16)
+    assert torch.equal(wt.cpu(), torch.from_numpy(w2).t())
+    idx3, _ = ops.sim_topk(dev(f), wt, k, "raw")
+    norm3 = ops.vocab_norm(wt)
+    assert norm3 is not norm1 and float(norm3.view(torch.float32).item()) > 1000 * w32
+    oi3, _ = no.sim_topk(f, w2, k, "raw")
+    assert np.array_equal(idx3.cpu().numpy(), oi3)
+
+
 def test_ablation_variables_change_nothing_in_the_default_library():
     """SCD_GEMM_X / SCD_SIM_X / SCD_ATTN_X / SCD_ESTEP_DBG removed kernel pieces (wrong results) in rounds 1-2; the default build
     ignores them: a child process with all of them set returns the oracle's top-k and labels."""
