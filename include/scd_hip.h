@@ -35,6 +35,9 @@ int scd_version(void);
 const char* scd_last_error(void);
 int scd_create(int device, scd_handle* out);
 int scd_destroy(scd_handle h);
+/* Profiling aid: launches an empty kernel named scd_mark_begin_kernel (end = 0) or scd_mark_end_kernel (end != 0) on `stream`, so that a
+ * kernel trace shows where a measured region starts and ends (bench.py brackets its timed steps; tools/trace_window_stats.py). */
+int scd_trace_mark(scd_handle h, int end, void* stream);
 
 /* ---- L2 normalisation: F.normalize(feats, dim=-1) main_unsup.py:130; clip_lang_util.py:103-105 ---- */
 int scd_l2norm_rows(scd_handle h, const void* x, int dtype, int64_t n, int d, void* out, void* stream);

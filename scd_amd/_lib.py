@@ -48,6 +48,7 @@ SIGNATURES = {
     "scd_last_error": (C.c_char_p, []),
     "scd_create": (_i, [_i, C.POINTER(_vp)]),
     "scd_destroy": (_i, [_vp]),
+    "scd_trace_mark": (_i, [_vp, _i, _vp]),
     "scd_l2norm_rows": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp]),
     "scd_sim_topk_ws_bytes": (_sz, [_i64, _i, _i64, _i]),
     "scd_sim_topk": (_i, [_vp, _vp, _vp, _i64, _i, _i64, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -676,6 +676,12 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_LATE_TM
 #define W4_LATE_TM 2
 #endif
+#ifndef W4_ABL_STATS
+#define W4_ABL_STATS 0   // timing probe (results wrong): 1 = the LN = 2 epilogue computes / adds no row statistics
+#endif
+#ifndef W4_ABL_PRE
+#define W4_ABL_PRE 0     // timing probe (results wrong): 1 = no bias / column-sum loads in front of the epilogue (zeros)
+#endif
 #ifndef W4_LN_ABL
 #define W4_LN_ABL 0   // timing probes of the LayerNorm fold (results are wrong): 1 = no row-statistics loads / conversions (rstd = 1, mean = 0), 2 = no fold arithmetic either
 #endif
@@ -981,13 +987,16 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             _Pragma("unroll") for (int e = 0; e < RD - 1; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
                 *(const half8*)(Rt + (size_t)((e * 16 + p * 4) * N) + lane_el);                                  \
         }                                                                                                        \
-        if (HAS_BIAS) {                                                                                          \
+        if (HAS_BIAS && W4_ABL_PRE) {                                                                            \
+            _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) { bq[tn][0] = 0.f; bq[tn][1] = 0.f; bq[tn][2] = 0.f; bq[tn][3] = 0.f; sq[tn] = bq[tn]; } \
+        }                                                                                                        \
+        if (HAS_BIAS && !W4_ABL_PRE) {                                                                           \
             _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
                 const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);                              \
                 bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;                          \
             }                                                                                                    \
         }                                                                                                        \
-        if (LN == 1 && W4_LN_ABL < 2) {                                                                          \
+        if (LN == 1 && W4_LN_ABL < 2 && !W4_ABL_PRE) {                                                                          \
             _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) {                                                   \
                 const float4 c4 = *(const float4*)(ln_colsum + nb0 + tn * 16 + q16 * 4);                         \
                 sq[tn][0] = c4.x; sq[tn][1] = c4.y; sq[tn][2] = c4.z; sq[tn][3] = c4.w;                          \
@@ -1083,7 +1092,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                         half_t* const crow = Ct + (size_t)((ts * 16 + p * 4) * N);          // wave-uniform (residual variants)
                         (void)rr;
                         if (HAS_RES) hv = hv + rq[ts % RD][p];   // fp16 add of two fp16 values: the same rounding as via fp32
-                        if (LN == 2) {
+                        if (LN == 2 && !W4_ABL_STATS) {
                             // row sums of the stored fp16 values over this wave's 128 columns: 8 values in-lane, then the 16 lanes
                             // (c16) that share row rr by DPP (rotations by 8 and 4 inside the 16-lane row, then inside the quad)
                             float s1 = 0.f, s2 = 0.f;
@@ -1160,6 +1169,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             }
         }
         if (LN == 2 && !(xmode & 16)) {
+            if (W4_ABL_STATS) { keep1[0] = keep1[1] = 0.f; keep2[0] = keep2[1] = 128.f; }   // probe: mean 0 / variance 1 rows, the atomics stay
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // fixed point so that the six partial sums of a row (3 tile columns x 2 waves) add up deterministically

@@ -757,7 +757,9 @@ __global__ void __launch_bounds__(256) estep_stream_kernel(const half_t* __restr
         if (j > 1 && tid < 32) merge_unit(j - 2);      // unit j-2's patch was written during unit j-1, before this barrier
         if (!(dbg & 16)) {
             const unsigned sl = sbase + slot * SLOTB + r * (DP * 2);
-            f32x16 acc;           // one accumulation chain: back-to-back dependent MFMAs of this shape run at full rate
+            // one accumulation chain: back-to-back dependent MFMAs of this shape run at full rate (round 5 measured it: odd k-steps on a
+            // second chain + one add per unit changed nothing, 31.3 -> 31.9 us at 131,072 x 512; profiles/r05_estep_chains_ab.txt)
+            f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             half8 fb[3][4];
@@ -1133,6 +1135,249 @@ __global__ void __launch_bounds__(512) estep_rb_kernel(const half_t* __restrict_
         return;
     }
     erb_decide(row, b0, b1, b2, cm2, xnorm, eh, flag_list, flag_cand, full_list, labels);
+#undef ERB_RD
+#undef ERB_RDX
+#undef ERB_WAIT
+#undef ERB_MFMA
+#undef ERB_MFMAV
+#undef ERB_MFMA0
+}
+
+// The same sweep for the centres of SEVERAL restarts of one fit at once (scd_kmeans_lloyd_run_multi: the restarts' Lloyd loops in
+// lock-step; faster_mix_k_means_pytorch.py:244-275 runs them one after the other): the rows of a block stay in registers while the centre
+// matrices of the restarts stream past them back to back, `upseg` units (kp / 32) per restart.  A restart is a SEGMENT of the unit
+// stream: its keys carry the centre's index inside the segment, at the segment's end the lane's three best keys are decided exactly as
+// estep_rb_kernel decides (erb_decide's arithmetic) - into one packed register per segment, the selection state is reset - and the label
+// stores / list atomics of all segments happen after the stream has drained (a store inside the loop would sit among the ring fills in
+// the vmcnt queue, and loads and stores do not retire in order with each other: the counted waits would no longer mean "unit u + 1 has
+// landed").  The restarts' E-step workspaces (EHdr | norms | fp16 centres | ... | lists, the layout of scd_kmeans_estep) are equally
+// strided (`ws_stride` bytes from `ws0`), so are their label slots; `segmap` packs the workspace slot of the a-th RUNNING restart in
+// 4-bit fields.  Grid: row blocks x nparts; part p takes the running restarts [p A / nparts, (p + 1) A / nparts) - whole segments, so
+// the parts need no merge.  At most 8 segments and 1,920 centres per part.
+struct RbmArgs {
+    char* ws0; size_t ws_stride;                   // restart slot s: ws0 + s * ws_stride
+    size_t cn_off, ch_off, flags_off, fcand_off, fulls_off;
+    int32_t* lab0; size_t lab_stride;              // labels of slot s: lab0 + s * lab_stride (elements)
+    unsigned long long segmap;
+    int n_active, nparts, kp;
+};
+__global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict__ xh, const float* __restrict__ xnorm, const RbmArgs a,
+                                                        long long n) {
+    constexpr int D = 512, UB = 32768, MAXSEG = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int part = (int)blockIdx.x % a.nparts;
+    const long long rblock = blockIdx.x / a.nparts;
+    const int a0 = part * a.n_active / a.nparts, a1 = (part + 1) * a.n_active / a.nparts;
+    const int nseg = a1 - a0, upseg = a.kp >> 5, nunits = nseg * upseg, kp = a.kp;
+    if (nseg <= 0) return;
+    auto slot_of = [&](int sg) { return (int)((a.segmap >> (4 * (a0 + sg))) & 15ull); };
+    float* cm2s = (float*)(smem + 4 * UB + 1920 * 16);            // [MAXSEG] max ||c'||^2 of the part's segments
+
+    // the extension column of every centre of the part (||c'||^2 / 8 as an fp16 pair hi + lo, see estep_ext_kernel), 16 B per centre
+    // behind the ring - formed here from the restarts' norms (no launch per restart) - and the segments' largest norms
+    for (int c = tid; c < nseg * kp; c += 512) {
+        const int sg = c / kp, cc = c - sg * kp;
+        const float v = ((const float*)(a.ws0 + (size_t)slot_of(sg) * a.ws_stride + a.cn_off))[cc];
+        float hv = v * 0.125f;
+        if (!(v < 3.0e38f)) hv = 60000.f;                         // dead centre (padding, NaN): never the best of a row
+        const half_t hi = (half_t)hv;
+        const half_t lo = (half_t)(hv - (float)hi);
+        half8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (half_t)0.f;
+        o[0] = hi;
+        o[1] = lo;
+        *(half8*)(smem + 4 * UB + c * 16) = o;
+    }
+    for (int sg = wave; sg < nseg; sg += 8) {
+        const float* cn = (const float*)(a.ws0 + (size_t)slot_of(sg) * a.ws_stride + a.cn_off);
+        float cm2 = 0.f;
+        for (int c = lane; c < kp; c += 64) {
+            const float v = cn[c];
+            if (v < 3.0e38f) cm2 = fmaxf(cm2, v);
+        }
+        cm2 = wave_max_f32(cm2);
+        if (lane == 0) cm2s[sg] = cm2;
+    }
+
+    half8 bf[32];
+    const long long row = rblock * 256 + wave * 32 + r;
+    const float xn = xnorm[row < n ? row : n - 1];
+    {
+        const half_t* xr = xh + (row < n ? row : n - 1) * D + 8 * hh;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                              // eight fragments at a time (see sim_topk_rb8_kernel)
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) bf[s] = *(const half8*)(xr + 16 * s);
+#pragma unroll
+            for (int s = 8 * b; s < 8 * b + 8; ++s) asm volatile("" : "+a"(bf[s]) : : "memory");
+        }
+    }
+    half8 bx;                                                    // B fragment of the extension step: -4 against (hi, lo) = ||c'||^2 / 8, lanes r only
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bx[q] = (half_t)((hh == 0 && q < 2) ? -4.f : 0.f);
+
+    const unsigned bsw = (unsigned)((lane ^ ((4 * wave) & 12)) << 4);
+    const half_t* fbase = nullptr;
+    unsigned fm0 = 0;
+    int f_unit = 0, f_seg = 0, f_in = 0;                         // the unit whose fills are being issued: number, segment, unit inside it
+    auto fill_next = [&]() {                                     // units are filled in order: 0, 1, 2, ...
+        fbase = (const half_t*)(a.ws0 + (size_t)slot_of(f_seg) * a.ws_stride + a.ch_off) + (size_t)f_in * 32 * D;
+        fm0 = sbase + (f_unit & 3) * UB + 4 * wave * 1024;
+        ++f_unit;
+        if (++f_in == upseg) { f_in = 0; ++f_seg; }
+    };
+    auto fill = [&](int p) {
+        const unsigned off = (bsw ^ (unsigned)(p << 4)) + (unsigned)(4 * wave + p) * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     ::"s"(fm0 + p * 1024), "v"(off), "s"(fbase) : "memory");
+    };
+    unsigned fa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] = sbase + (unsigned)(r * 1024 + ((32 * j) ^ (16 * (hh ^ (r & 15)))));
+    unsigned fxa = sbase + 4 * UB + (unsigned)(r * 16);          // extension fragment of unit 0, row r (both half-waves read it)
+
+#define ERB_RD(DST, J, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fa[J]), "n"(IMM))
+#define ERB_RDX(DST) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(fxa))
+#define ERB_WAIT(N, FR) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FR))
+#define ERB_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "a"(B))
+#define ERB_MFMAV(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define ERB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
+
+    float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;        // the lane's three largest keys of the current segment
+    unsigned resv[MAXSEG];                                       // per segment: label | second centre << 11 | state << 22 (1 pair list, 2 all-centres list)
+#pragma unroll
+    for (int i = 0; i < MAXSEG; ++i) resv[i] = 0u;
+    // decision of one finished segment from the half-wave's three best keys: erb_decide's arithmetic, the outcome packed
+    auto decide = [&](int sg) {
+        const float o0 = es_swap32(b0), o1 = es_swap32(b1), o2 = es_swap32(b2);
+        erb_insert(b0, b1, b2, o0);
+        erb_insert(b0, b1, b2, o1);
+        erb_insert(b0, b1, b2, o2);
+        const float m0 = -2.f * b0, m1 = -2.f * b1, m2 = -2.f * b2;
+        const unsigned j0 = __float_as_uint(b0) & 2047u, j1 = __float_as_uint(b1) & 2047u;
+        const float cmax = sqrtf(cm2s[sg]) * 1.0000002f;
+        const float sq = 22.627417f;                             // sqrt(512)
+        const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 4.9e-4f * cmax);
+        const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 2.45e-4f * cmax * cmax);
+        const float E = A * xn + B;
+        unsigned state = 0u;
+        if (!(m1 - m0 > 2.0f * E)) state = (m2 - m0 > 2.0f * E) ? 1u : 2u;     // also catches NaN
+        const unsigned packed = j0 | (j1 << 11) | (state << 22);
+#pragma unroll
+        for (int i = 0; i < MAXSEG; ++i) resv[i] = (i == sg) ? packed : resv[i];
+        b0 = -INFINITY; b1 = -INFINITY; b2 = -INFINITY;
+    };
+    f32x16 acc[2];
+    half8 fr[4], fx;
+    using yes = std::true_type;
+    using no = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int e_in = 0, e_seg = 0;                                      // unit u - 1 (the one whose keys are inserted): unit inside its segment, segment
+    auto body = [&](auto has_prev, auto parity, int u) {
+        constexpr int P = decltype(parity)::value;
+        constexpr bool EPI = decltype(has_prev)::value;
+        if (u + 2 < nunits) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = u + 1 < nunits;
+        const bool fills = u + 3 < nunits;
+        if (fills) fill_next();
+        const unsigned ub = (unsigned)(e_in * 32 + 4 * hh);      // centre index (inside its segment) of value i of unit u - 1: ub + (i & 3) + 8 (i >> 2)
+        static_for<0, 32>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s == 29) {
+                const unsigned delta = ((u + 1) & 3) ? (unsigned)UB : (unsigned)(-3 * UB);      // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fa[j] += delta;
+            }
+            if constexpr (s < 29) ERB_RD(fr[(s + 3) & 3], (s + 3) & 7, ((s + 3) >> 3) * 256);
+            else if (more) ERB_RD(fr[(s + 3) & 3], (s + 3 - 32) & 7, 0);
+            if constexpr (s == 8) ERB_RDX(fx);
+            if constexpr (s >= 8 && s <= 10) ERB_WAIT(3, fr[(s + 1) & 3]);
+            else if (s < 29 || more) ERB_WAIT(2, fr[(s + 1) & 3]);
+            else if (s == 29) ERB_WAIT(1, fr[(s + 1) & 3]);
+            else if (s == 30) ERB_WAIT(0, fr[(s + 1) & 3]);
+            if (s == 0) ERB_MFMA0(acc[P], fr[s & 3], bf[s]);
+            else ERB_MFMA(acc[P], fr[s & 3], bf[s]);
+            if constexpr (s == 20) {
+                asm volatile("" : "+v"(fx));
+                ERB_MFMAV(acc[P], fx, bx);
+                fxa += 512;                                      // next unit's 32 extension entries
+            }
+            if ((s & 7) == 7 && fills) fill(s >> 3);
+            if constexpr (EPI && s >= 2 && s < 18) {
+                constexpr int i = s - 2;
+                const unsigned idx = ub + (unsigned)((i & 3) + 8 * (i >> 2));
+                const float k = __uint_as_float((__float_as_uint(acc[1 - P][i]) & 0xfffff800u) | idx);
+                erb_insert(b0, b1, b2, k);
+            }
+            if constexpr (EPI && s == 22) {                      // unit u - 1 closed its segment: decide it (wave-uniform branch)
+                if (e_in + 1 == upseg) decide(e_seg);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (EPI) { if (++e_in == upseg) { e_in = 0; ++e_seg; } }
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < 3; ++pre)
+        if (pre < nunits) {
+            fill_next();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fill(p);
+        }
+    if (nunits > 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (nunits > 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // unit 0, the extension table and the segments' norms are in LDS
+    asm volatile("" ::: "memory");
+    ERB_RD(fr[0], 0, 0);
+    ERB_RD(fr[1], 1, 0);
+    ERB_RD(fr[2], 2, 0);
+    ERB_WAIT(2, fr[0]);
+
+    body(no{}, P0{}, 0);
+    int u = 1;
+    for (; u + 1 < nunits; u += 2) {
+        body(yes{}, P1{}, u);
+        body(yes{}, P0{}, u + 1);
+    }
+    const bool odd_tail = u < nunits;
+    if (odd_tail) body(yes{}, P1{}, u);
+    {   // keys of the last unit (the last of the last segment), then that segment's decision
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+        const unsigned ub = (unsigned)((upseg - 1) * 32 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float av = odd_tail ? acc[1][i] : acc[0][i];
+            erb_insert(b0, b1, b2, __uint_as_float((__float_as_uint(av) & 0xfffff800u) | (ub + (unsigned)((i & 3) + 8 * (i >> 2)))));
+        }
+        decide(nseg - 1);
+    }
+    if (hh != 0 || row >= n) return;
+    // the stream has drained: labels and list entries of every segment
+#pragma unroll
+    for (int sg = 0; sg < MAXSEG; ++sg) {
+        if (sg >= nseg) break;
+        char* wsb = a.ws0 + (size_t)slot_of(sg) * a.ws_stride;
+        const unsigned pk = resv[sg];
+        const int j0 = (int)(pk & 2047u), j1 = (int)((pk >> 11) & 2047u), state = (int)(pk >> 22);
+        (a.lab0 + (size_t)slot_of(sg) * a.lab_stride)[row] = j0;
+        EHdr* eh = (EHdr*)wsb;
+        if (state == 1) {
+            const int pos = atomicAdd(&eh->flag_cnt, 1);
+            ((int*)(wsb + a.flags_off))[pos] = (int)row;
+            ((int*)(wsb + a.fcand_off))[pos] = j0 | (j1 << 16);
+        } else if (state == 2) {
+            ((int*)(wsb + a.fulls_off))[atomicAdd(&eh->full_cnt, 1)] = (int)row;
+        }
+    }
 #undef ERB_RD
 #undef ERB_RDX
 #undef ERB_WAIT
@@ -2821,13 +3066,17 @@ __global__ void __launch_bounds__(256) xch_unpack_kernel(const double* counts_f6
 // operands from `fsums` / `fcounts` (the rank's own, or the exchanged ones).
 static int lloyd_step_a(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat, int d, int k,
                         int32_t* labels_cat, int32_t* labels_prev, const float* C_in, double* sums, int64_t* counts, double* stats,
-                        int flags, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* pack_dst) {
+                        int flags, void* ws_e, size_t ws_e_bytes, void* ws_m, size_t ws_m_bytes, void* stream, double* pack_dst,
+                        bool estep_done = false) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_lloyd_step_delta");
     const int64_t l_num = n_cat - n_u;
     hipStream_t st = (hipStream_t)stream;
-    int rc = scd_kmeans_estep_hint(h, flags & (SCD_ESTEP_FEW | SCD_ESTEP_CENTRES_FROM_FINALIZE));
-    if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
-    if (rc) return rc;
+    int rc = SCD_OK;
+    if (!estep_done) {          // (else: the filter of all restarts ran as one launch, estep_multi_launch, and this restart's refine follows it)
+        rc = scd_kmeans_estep_hint(h, flags & (SCD_ESTEP_FEW | SCD_ESTEP_CENTRES_FROM_FINALIZE));
+        if (!rc) rc = scd_kmeans_estep(h, X_u, prep_u, C_in, n_u, d, k, labels_cat + l_num, nullptr, ws_e, ws_e_bytes, stream);
+        if (rc) return rc;
+    }
     // rows whose label changed: accumulated in the handle's scratch (zero between iterations), handed to stats[4] by finalize_kernel
     double* changed_acc = (double*)((char*)h->scratch + 262144 + 40);
     if (flags & SCD_LLOYD_FULL) {
@@ -2905,6 +3154,84 @@ extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const
                                  counts_lab, sumsq4, stats, flags, ws_e, ws_e_bytes, ws_m, ws_m_bytes, stream, nullptr, 0.0);
 }
 
+// The filter launch of scd_kmeans_estep for SEVERAL restarts at once (estep_rbm_kernel; Dp = 512, Kp <= 256 per restart): the centre
+// operands of restart j live in its own E-step workspace ws[j] (written by its finalize launch, or by prep_centers_kernel here when the
+// hand-over does not hold - the same test as scd_kmeans_estep's), the workspaces and the label slots are equally strided.  Per restart the
+// refine launch follows on the restart's own stream.  Returns SCD_OK, or a status; *served = false when the shape is not served.
+struct EstepMultiItem { scd_handle h; const float* C; void* ws; int32_t* labels; int slot; };
+static bool estep_multi_serves(int d, int k, int n_items) {
+    const char* ev = getenv("SCD_ESTEP_MERGED");          // read per fit (a test switches it inside one process)
+    const int en = ev ? atoi(ev) : 1;
+    return en && dpad(d) == 512 && kpad(k) <= 256 && n_items >= 2 && n_items <= 16;
+}
+static int estep_multi_launch(const EstepMultiItem* it, int n_items, const float* X, const void* prep, int64_t n, int d, int k, char* ws0,
+                              size_t ws_stride, int32_t* lab0, size_t lab_stride, int n_cu, hipStream_t st) {
+    const int dp = dpad(d), kp = kpad(k);
+    const char* p = (const char*)prep;
+    const PrepHdr* ph = (const PrepHdr*)p;
+    const size_t xnorm_off = scd_align(64 + 8 * (size_t)dp);
+    const size_t xh_off = xnorm_off + scd_align(4 * (size_t)n);
+    RbmArgs a;
+    a.ws0 = ws0; a.ws_stride = ws_stride;
+    a.cn_off = 64;
+    a.ch_off = 64 + scd_align(4 * (size_t)kp);
+    const size_t ct_off = a.ch_off + scd_align(2 * (size_t)kp * dp);
+    a.flags_off = ct_off + scd_align(4 * (size_t)kp * dp);
+    a.fcand_off = a.flags_off + scd_align(4 * (size_t)n);
+    a.fulls_off = a.fcand_off + scd_align(4 * (size_t)n);
+    const size_t chf_off = a.fulls_off + scd_align(4 * (size_t)n);
+    a.lab0 = lab0; a.lab_stride = lab_stride;
+    a.segmap = 0ull;
+    a.n_active = n_items; a.kp = kp;
+    for (int j = 0; j < n_items; ++j) {
+        scd_handle h = it[j].h;
+        char* w = (char*)it[j].ws;
+        SCD_REQUIRE(w == ws0 + (size_t)it[j].slot * ws_stride && it[j].labels == lab0 + (size_t)it[j].slot * lab_stride && it[j].slot < 16,
+                    "estep_multi_launch: workspaces / label slots are not equally strided");
+        a.segmap |= (unsigned long long)it[j].slot << (4 * j);
+        // the finalize hand-over of this restart's handle, consumed exactly as scd_kmeans_estep consumes it
+        const bool handover = h->prep_ok && h->prep_C == it[j].C && h->prep_ws == it[j].ws && h->prep_k == k && h->prep_d == d;
+        h->estep_few = 0;
+        h->prep_ok = 0;
+        h->prep_C = nullptr;
+        if (!handover)
+            prep_centers_kernel<<<kp, 256, 0, st>>>(it[j].C, k, d, dp, ph, (const double*)(p + 64), (EHdr*)w, (float*)(w + a.cn_off), (half_t*)(w + a.ch_off),
+                                                    (float*)(w + ct_off), kp, 1, (half_t*)(w + chf_off));
+    }
+    // parts: whole restarts per part (no merge), at most 8 restarts and 1,920 centres each; the count that minimises rounds x (units + ramp)
+    const long long nblk = scd_cdiv(n, 256);
+    const int upseg = kp / 32, ncu = n_cu > 0 ? n_cu : 256;
+    int best_parts = 0;
+    double best_cost = 0.;
+    for (int np = 1; np <= n_items; ++np) {
+        const int segs = (n_items + np - 1) / np;
+        if (segs > 8 || segs * kp > 1920) continue;
+        const double cost = (double)scd_cdiv(nblk * np, ncu) * (segs * upseg + 3);
+        if (!best_parts || cost < best_cost) { best_parts = np; best_cost = cost; }
+    }
+    SCD_REQUIRE(best_parts > 0, "estep_multi_launch: no part count fits");
+    a.nparts = best_parts;
+    { const int rc_ = scd_set_max_lds((const void*)estep_rbm_kernel, ERB_LDS); if (rc_) return rc_; }
+    estep_rbm_kernel<<<(unsigned)(nblk * best_parts), 512, ERB_LDS, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off), a, n);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+// the refine launch of scd_kmeans_estep for one restart, behind the merged filter
+static int estep_multi_refine(const float* X, const float* C, void* ws, int64_t n, int d, int k, int32_t* labels, hipStream_t st) {
+    const int dp = dpad(d), kp = kpad(k);
+    char* w = (char*)ws;
+    const size_t ch_off = 64 + scd_align(4 * (size_t)kp);
+    const size_t ct_off = ch_off + scd_align(2 * (size_t)kp * dp);
+    const size_t flags_off = ct_off + scd_align(4 * (size_t)kp * dp);
+    const size_t fcand_off = flags_off + scd_align(4 * (size_t)n);
+    const size_t fulls_off = fcand_off + scd_align(4 * (size_t)n);
+    estep_refine_both_kernel<<<REFINE_GRID, 512, (size_t)d * 32 + 64, st>>>(X, C, (const float*)(w + ct_off), (EHdr*)w, (int*)(w + flags_off),
+                                                                            (int*)(w + fcand_off), (int*)(w + fulls_off), d, k, kp, labels, nullptr,
+                                                                            REFINE_PAIR);
+    SCD_LAUNCH_CHECK();
+    return SCD_OK;
+}
+
 // The Lloyd loops of a fit's restarts (the loop of scd_amd/kmeans.py:_lloyd_pipelined, faster_mix_k_means_pytorch.py:187-214, :244-275),
 // ONE restart (scd_kmeans_lloyd_run[_sharded]) or ALL of them in lock-step (scd_kmeans_lloyd_run_multi: the restarts are independent
 // once seeded).  Per restart the host runs one iteration behind the device - iteration i + 1 is enqueued (from iteration i's centres,
@@ -2959,7 +3286,7 @@ static int lr_begin(LloydRestart& r, const LloydShared& S) {
     return SCD_OK;
 }
 // first half of iteration `it`: E-step + M-step (+ pack)
-static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pack_dst) {
+static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pack_dst, bool estep_done = false) {
     if (r.best_in_ring && r.best_it % 3 == it % 3) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }   // that slot is about to be re-used
     const size_t kd = (size_t)S.k * S.d;
     const float* c_in = it == 0 ? r.C_start : r.C_ring + (size_t)((it - 1) % 3) * kd;
@@ -2981,8 +3308,12 @@ static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pa
     r.h->run_seq += 1.0;
     r.seq_of[it & 1] = r.h->run_seq;
     SCD_REQUIRE(S.k <= 8192, "scd_kmeans_lloyd_run: k > 8192");
+    if (estep_done) {          // the merged filter has run: this restart's refine, then its M-step
+        const int rc = estep_multi_refine(S.X_u, c_in, r.ws_e, S.n_u, S.d, S.k, r.lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), r.st);
+        if (rc) return rc;
+    }
     return lloyd_step_a(r.h, S.X_u, S.prep_u, S.n_u, S.X16_cat, S.n_cat, S.d, S.k, r.lab_ring + (size_t)(it % 3) * S.n_cat, r.labels_prev, c_in,
-                        r.sums, r.counts, stats, r.flags, r.ws_e, S.ws_e_bytes, r.ws_m, S.ws_m_bytes, (void*)r.st, pack_dst);
+                        r.sums, r.counts, stats, r.flags, r.ws_e, S.ws_e_bytes, r.ws_m, S.ws_m_bytes, (void*)r.st, pack_dst, estep_done);
 }
 // second half: centres, shift, inertia, the next E-step's operands, the statistics to the host
 static int lr_launch_b(LloydRestart& r, const LloydShared& S, int it, const double* fsums, const int64_t* fcounts, bool exchanged) {
@@ -3078,13 +3409,48 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
         const int rc = lr_begin(rs[j], S);
         if (rc) return rc;
     }
+    // one merged filter launch per iteration when the shape is served and the restarts' E-step workspaces and label rings are equally
+    // strided (the Python mirror allocates them as one tensor each)
+    bool merge_ok = R >= 2 && estep_multi_serves(S.d, S.k, R);
+    size_t ws_stride = 0, lab_stride = 0;
+    if (merge_ok) {
+        ws_stride = (size_t)((char*)rs[1].ws_e - (char*)rs[0].ws_e);
+        lab_stride = (size_t)(rs[1].lab_ring - rs[0].lab_ring);
+        merge_ok = (char*)rs[1].ws_e > (char*)rs[0].ws_e && rs[1].lab_ring > rs[0].lab_ring && ws_stride >= S.ws_e_bytes;
+        for (int j = 0; j < R && merge_ok; ++j)
+            merge_ok = (char*)rs[j].ws_e == (char*)rs[0].ws_e + (size_t)j * ws_stride && rs[j].lab_ring == rs[0].lab_ring + (size_t)j * lab_stride;
+    }
     std::vector<int> act;
     int n_active = R;
     for (int it = 0; it < S.max_iter && n_active > 0; ++it) {
         act.clear();
         for (int j = 0; j < R; ++j) if (rs[j].active) act.push_back(j);
+        bool merged = false;
+        if (merge_ok && act.size() >= 2) {
+            // ONE filter launch for every running restart (estep_rbm_kernel): the slots the labels go to are freed first, every
+            // restart's stream is joined (its previous finalize wrote the centre operands), and the restarts' streams continue behind it
+            std::vector<EstepMultiItem> items(act.size());
+            for (size_t a = 0; a < act.size(); ++a) {
+                LloydRestart& r = rs[act[a]];
+                if (r.best_in_ring && r.best_it % 3 == it % 3) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }
+                const float* c_in = it == 0 ? r.C_start : r.C_ring + (size_t)((it - 1) % 3) * kd;
+                items[a] = {r.h, c_in, r.ws_e, r.lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), act[a]};
+                if (ls) {
+                    SCD_HIP(hipEventRecord(ls->ev[act[a]], r.st));
+                    SCD_HIP(hipStreamWaitEvent(st, ls->ev[act[a]], 0));
+                }
+            }
+            const int rc = estep_multi_launch(items.data(), (int)items.size(), S.X_u, S.prep_u, S.n_u, S.d, S.k, (char*)rs[0].ws_e, ws_stride,
+                                              rs[0].lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), lab_stride, rs[0].h->n_cu, st);
+            if (rc) return rc;
+            if (ls) {
+                SCD_HIP(hipEventRecord(ls->ev[R + 1], st));
+                for (int j = 0; j < ns; ++j) SCD_HIP(hipStreamWaitEvent(ls->st[j], ls->ev[R + 1], 0));
+            }
+            merged = true;
+        }
         for (size_t a = 0; a < act.size(); ++a) {
-            const int rc = lr_launch_a(rs[act[a]], S, it, xch ? xch->buf + a * per : nullptr);
+            const int rc = lr_launch_a(rs[act[a]], S, it, xch ? xch->buf + a * per : nullptr, merged);
             if (rc) return rc;
         }
         if (xch) {

@@ -597,7 +597,7 @@ class KMeansEngine:
                 bufs.lab32[:l_num] = per[0]["l_rank"]
             c_inits = torch.stack([p["init_centers"] for p in per])
             x0 = getattr(bufs, "_xch_n", 0)
-            res = bufs.run_multi(c_inits, self.max_iterations, self.tolerance, n_streams=int(os.environ.get("SCD_LLOYD_STREAMS", "1")))
+            res = bufs.run_multi(c_inits, self.max_iterations, self.tolerance, n_streams=int(os.environ.get("SCD_LLOYD_STREAMS", "4")))
             self.stats["lockstep_fits"] = self.stats.get("lockstep_fits", 0) + 1
             if dd is not None:                  # all-reduces of the fit's Lloyd loops: one per lock-step iteration, whatever n_init is
                 self.stats["lloyd_exchanges"] = self.stats.get("lloyd_exchanges", 0) + getattr(bufs, "_xch_n", 0) - x0

@@ -44,6 +44,12 @@ def _ws(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+def trace_mark(end=False):
+    """An empty marker kernel on the current stream (scd_mark_begin_kernel / scd_mark_end_kernel): brackets a measured region in a
+    rocprofv3 kernel trace."""
+    check(_L().scd_trace_mark(handle(), 1 if end else 0, stream_ptr()))
+
+
 # ----------------------------------------------------------------------------- normalise / layout
 def l2norm_rows(x):
     """F.normalize(x, dim=-1) (main_unsup.py:130)."""
@@ -456,8 +462,13 @@ class LloydBuffers:
                 R=R, lab_ring=torch.empty((R, 3, n_cat), dtype=torch.int32, device=dev), lab_prev=torch.full((R, n_cat), -1, dtype=torch.int32, device=dev),
                 c_ring=torch.empty((R, 3, k, dim), dtype=torch.float32, device=dev), sums=torch.empty((R, k, dim), dtype=torch.float64, device=dev),
                 counts=torch.empty((R, k), dtype=torch.int64, device=dev), stats_ring=torch.zeros((R, 2, 5), dtype=torch.float64, device=dev),
-                ws_e=[_ws(self.nb_e, dev) for _ in range(R)], ws_m=[_ws(self.nb_m, dev) for _ in range(R)],
+                ws_m=[_ws(self.nb_m, dev) for _ in range(R)],
                 result=np.zeros((R, 4), dtype=np.float64))
+            # the restarts' E-step workspaces as equal strides of ONE buffer (and the label rings above as one tensor): the library then
+            # serves all running restarts' filters with one launch per iteration (estep_rbm_kernel) where the shape allows
+            stride = (int(self.nb_e) + 255) // 256 * 256
+            per["ws_e_all"] = _ws(R * stride, dev)
+            per["ws_e"] = [per["ws_e_all"][j * stride:(j + 1) * stride] for j in range(R)]
             if self.dd is not None:
                 xb = per["xbuf"] = torch.empty(R * (k * dim + 2 * k), dtype=torch.float64, device=dev)
                 dd = self.dd

@@ -1964,7 +1964,10 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     # "1": scd_kmeans_lloyd_run_multi (all restarts' loops in lock-step behind one C call, the default); "streams": the same over four
     # streams; "seq": scd_kmeans_lloyd_run, one restart after the other; "py": the same steps driven from Python; "0": a fresh M-step
     # per iteration
-    for mode in ("1", "streams", "seq", "py", "0"):
+    # "nomerge": lock-step, but every restart's filter launch of its own (at d = 512, K <= 256 the default serves all running restarts'
+    # filters with ONE launch per iteration, estep_rbm_kernel)
+    for mode in ("1", "streams", "nomerge", "seq", "py", "0"):
+        monkeypatch.setenv("SCD_ESTEP_MERGED", "0" if mode == "nomerge" else "1")
         monkeypatch.setenv("SCD_MSTEP_DELTA", "0" if mode == "0" else "1")
         monkeypatch.setenv("SCD_LLOYD_RUN", "0" if mode == "py" else "1")
         monkeypatch.setenv("SCD_LLOYD_LOCKSTEP", "0" if mode == "seq" else "1")
@@ -1976,16 +1979,49 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
             km.fit(dev(x))
         st = dict(km.stats)
         lockstep = st.pop("lockstep_fits", 0)
-        assert lockstep == (1 if mode in ("1", "streams") else 0)
+        assert lockstep == (1 if mode in ("1", "streams", "nomerge") else 0)
         res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, st)
     assert res["1"][4].get("delta_steps", 0) > 0 and res["0"][4].get("delta_steps", 0) == 0
     # (an empty cluster's centre is NaN in the reference and here: equal_nan)
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
     assert res["1"][2] == res["0"][2] and res["1"][3] == res["0"][3]
-    for other in ("streams", "seq", "py"):
+    for other in ("streams", "nomerge", "seq", "py"):
         assert np.array_equal(res["1"][0], res[other][0]) and np.array_equal(res["1"][1], res[other][1], equal_nan=True), other
         assert res["1"][2] == res[other][2] and res["1"][3] == res[other][3] and res["1"][4] == res[other][4], other
     okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=2)
+    if labelled:
+        okm.fit_mix(x[~mask], x[mask], y[mask])
+    else:
+        okm.fit(x)
+    assert np.array_equal(res["1"][0], okm.labels_) and np.array_equal(res["1"][1], okm.cluster_centers_, equal_nan=True)
+    assert res["1"][2] == float(okm.inertia_)
+
+
+@pytest.mark.parametrize("n,d,k,R,labelled,tol", [(30011, 512, 100, 10, True, 1e-4), (9000, 448, 130, 5, False, 1e-4), (70000, 512, 37, 12, True, 5e-2),
+                                                   (4100, 512, 256, 2, True, 1e-4), (20000, 512, 60, 16, False, 1e30)])
+def test_lockstep_merged_estep_equals_per_restart_filters(ops, monkeypatch, n, d, k, R, labelled, tol):
+    """The restarts' Lloyd loops in lock-step (scd_kmeans_lloyd_run_multi) with ONE filter launch per iteration for all running restarts
+    (estep_rbm_kernel: Dp = 512, Kp <= 256; segments of the unit stream, whole restarts per part) against the same loops with one filter
+    launch per restart and against the float64 oracle (faster_mix_k_means_pytorch.py:187-214, :244-275): labels, centres, inertia and
+    n_iter_ bit-identical.  Ragged row counts, Kp = 128 and 256, 2-16 restarts (more than eight: several parts), restarts that converge at
+    different iterations (the set of running restarts shrinks) and a tolerance that stops every restart after its first iteration."""
+    from scd_amd.kmeans import KMeansEngine
+    x, y, _ = synth.clustered_features(n, d, k, seed=81, center_seed=82, noise=0.8)
+    x = x.astype(np.float16).astype(np.float32)
+    mask = (y < k // 2) & (np.random.RandomState(9).rand(n) < 0.5) if labelled else np.zeros(n, dtype=bool)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCD_ESTEP_MERGED", mode)
+        km = KMeansEngine(k=k, tolerance=tol, max_iterations=7, n_init=R, random_state=4)
+        if labelled:
+            km.fit_mix(dev(x[~mask]), dev(x[mask]), dev(y[mask]))
+        else:
+            km.fit(dev(x))
+        assert km.stats.get("lockstep_fits", 0) == 1
+        res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, km.stats["estep_calls"])
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
+    assert res["1"][2:] == res["0"][2:]
+    okm = ko.K_Means(k=k, tolerance=tol, max_iterations=7, n_init=R, random_state=4)
     if labelled:
         okm.fit_mix(x[~mask], x[mask], y[mask])
     else:
