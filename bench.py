@@ -243,11 +243,12 @@ def dominant_kernel_roofline(ms, launches, flop):
     sec = ms / 1e3
     tf = flop / max(sec, 1e-12) / 1e12
     # HBM-side traffic per launch cannot be read without the profiler: it is taken from this round's committed PMC passes
-    # (profiles/r04_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/gpu_r04_profiles.sh)
+    # (profiles/r05_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/gpu_r05_final.sh)
     # at the default launch size (3,990 images = 786,432 rows); another --batch scales it by its rows per launch
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_fc1.json")) as f:
+        pmf = os.path.join(ROOT, "profiles", "r05_pmc_fc1.json")
+        with open(pmf if os.path.exists(pmf) else os.path.join(ROOT, "profiles", "r04_pmc_fc1.json")) as f:
             pm = json.load(f)
         rows_per_launch = flop / max(launches, 1) / (2.0 * 3072 * 768)
         traffic = round(pm["traffic_bytes_per_launch"] * rows_per_launch / pm["rows"])
@@ -342,7 +343,7 @@ def secondary_rooflines(out, wt, dev, km_fit=False):
                     "kernel_us_all_launches": round(float(smp.mean()) * 1e6, 1),
                     "fit_wall_ms_incl_seeding": round(wall * 1e3, 2),
                     "note": "HIP-event brackets include the dispatch latency of the bracketed launch (~5-8 us on a 30 us kernel); the "
-                            "rocprofv3 kernel trace of tools/sskm_phases.py (profiles/r03_sskm_phases_kernel_stats.csv) has the kernel alone"})
+                            "rocprofv3 kernel trace of a whole fit (tools/lloyd_multi_prof.py, profiles/r05_lloyd_fit_kernel_stats.csv) has the kernel alone"})
     # (iii') `--cluster KM` (the shipped script's flag): `KMeans(k, random_state=0).fit` on the clustered features' unlabelled share
     # (95,000 rows at C2) - greedy k-means++ of the ten starts in lock-step + ten Lloyd runs in C (scd_kpp_greedy_lockstep,
     # scd_kmeans_lloyd_run_sk); wall time of the whole fit
@@ -388,7 +389,7 @@ def secondary_rooflines(out, wt, dev, km_fit=False):
                     "bound": "hbm", "achieved": round(byr / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byr / t / 8e12, 4),
                     "round_us": round(t * 1e6, 1),
                     "note": "the round's distance update alone (muf_filter_kernel 33 us + muf_exact_kernel 11 us at this size, "
-                            "profiles/r03_seed_kernel_stats.csv) moves these bytes at ~3.2 TB/s; the draw's three dependent launches add 23 us"})
+                            "profiles/r05_lloyd_fit_kernel_stats.csv) moves these bytes at ~3.2 TB/s; the draw's three dependent launches add 21 us"})
     return res
 
 

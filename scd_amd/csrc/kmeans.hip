@@ -1249,7 +1249,7 @@ __global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict
 #define ERB_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "a"(B))
 
     float b0 = -INFINITY, b1 = -INFINITY, b2 = -INFINITY;        // the lane's three largest keys of the current segment
-    unsigned resv[MAXSEG];                                       // per segment: label | second centre << 11 | state << 22 (1 pair list, 2 all-centres list)
+    unsigned resv[MAXSEG];                                       // per segment: label | second centre << 8 | state << 16 (1 pair list, 2 all-centres list)
 #pragma unroll
     for (int i = 0; i < MAXSEG; ++i) resv[i] = 0u;
     // decision of one finished segment from the half-wave's three best keys: erb_decide's arithmetic, the outcome packed
@@ -1259,15 +1259,17 @@ __global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict
         erb_insert(b0, b1, b2, o1);
         erb_insert(b0, b1, b2, o2);
         const float m0 = -2.f * b0, m1 = -2.f * b1, m2 = -2.f * b2;
-        const unsigned j0 = __float_as_uint(b0) & 2047u, j1 = __float_as_uint(b1) & 2047u;
+        // (a segment holds at most 256 centres: EIGHT index bits in a key, i.e. a relative perturbation below 2^-15 of the score where
+        // estep_rb_kernel's eleven bits cost 2^-12 - the key terms of the bound shrink by 8 and with them the rows sent to the refine)
+        const unsigned j0 = __float_as_uint(b0) & 255u, j1 = __float_as_uint(b1) & 255u;
         const float cmax = sqrtf(cm2s[sg]) * 1.0000002f;
         const float sq = 22.627417f;                             // sqrt(512)
-        const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 4.9e-4f * cmax);
-        const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 2.45e-4f * cmax * cmax);
+        const float A = 1.5f * (2.02f * (9.765625e-4f + D * 5.9604645e-8f) * cmax + 4.8e-7f * cmax + 6.0e-8f * sq + 6.2e-5f * cmax);
+        const float B = 1.5f * (6.0e-8f * sq * cmax + 4.8e-7f * cmax * cmax + 3.1e-5f * cmax * cmax);
         const float E = A * xn + B;
         unsigned state = 0u;
         if (!(m1 - m0 > 2.0f * E)) state = (m2 - m0 > 2.0f * E) ? 1u : 2u;     // also catches NaN
-        const unsigned packed = j0 | (j1 << 11) | (state << 22);
+        const unsigned packed = j0 | (j1 << 8) | (state << 16);
 #pragma unroll
         for (int i = 0; i < MAXSEG; ++i) resv[i] = (i == sg) ? packed : resv[i];
         b0 = -INFINITY; b1 = -INFINITY; b2 = -INFINITY;
@@ -1315,7 +1317,7 @@ __global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict
             if constexpr (EPI && s >= 2 && s < 18) {
                 constexpr int i = s - 2;
                 const unsigned idx = ub + (unsigned)((i & 3) + 8 * (i >> 2));
-                const float k = __uint_as_float((__float_as_uint(acc[1 - P][i]) & 0xfffff800u) | idx);
+                const float k = __uint_as_float((__float_as_uint(acc[1 - P][i]) & 0xffffff00u) | idx);
                 erb_insert(b0, b1, b2, k);
             }
             if constexpr (EPI && s == 22) {                      // unit u - 1 closed its segment: decide it (wave-uniform branch)
@@ -1356,7 +1358,7 @@ __global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float av = odd_tail ? acc[1][i] : acc[0][i];
-            erb_insert(b0, b1, b2, __uint_as_float((__float_as_uint(av) & 0xfffff800u) | (ub + (unsigned)((i & 3) + 8 * (i >> 2)))));
+            erb_insert(b0, b1, b2, __uint_as_float((__float_as_uint(av) & 0xffffff00u) | (ub + (unsigned)((i & 3) + 8 * (i >> 2)))));
         }
         decide(nseg - 1);
     }
@@ -1367,7 +1369,7 @@ __global__ void __launch_bounds__(512) estep_rbm_kernel(const half_t* __restrict
         if (sg >= nseg) break;
         char* wsb = a.ws0 + (size_t)slot_of(sg) * a.ws_stride;
         const unsigned pk = resv[sg];
-        const int j0 = (int)(pk & 2047u), j1 = (int)((pk >> 11) & 2047u), state = (int)(pk >> 22);
+        const int j0 = (int)(pk & 255u), j1 = (int)((pk >> 8) & 255u), state = (int)(pk >> 16);
         (a.lab0 + (size_t)slot_of(sg) * a.lab_stride)[row] = j0;
         EHdr* eh = (EHdr*)wsb;
         if (state == 1) {
@@ -1495,21 +1497,20 @@ __global__ void __launch_bounds__(128) estep_refine_full_kernel(const float* __r
 // both refine passes in one launch (streaming path): all-centres rows one 8-wave block per row, pair rows one wave per row.
 #define REFINE_GRID (unsigned)SCD_ABLATE_ENV("SCD_REFINE_GRID", 1024)
 #define REFINE_PAIR SCD_ABLATE_ENV("SCD_REFINE_PAIR", 256)
-__global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
-                                                                const float* __restrict__ ct, const EHdr* eh, const int* flag_list,
-                                                                const int* flag_cand, const int* full_list, int d, int k, int kp,
-                                                                int32_t* labels, int32_t* refine_rows_out, int pair_blocks) {
+__device__ __forceinline__ void refine_both_body(const float* __restrict__ X, const float* __restrict__ C, const float* __restrict__ ct,
+                                                 const EHdr* eh, const int* flag_list, const int* flag_cand, const int* full_list, int d,
+                                                 int k, int kp, int32_t* labels, int32_t* refine_rows_out, int pair_blocks, int bx, int gx) {
     extern __shared__ double xs[];
     __shared__ double rv[32];
     __shared__ int ri[32];
-    // the first gridDim.x - pair_blocks blocks: the all-centres list, one block per row (the long chain of latencies: scheduled first);
+    // the first gx - pair_blocks blocks: the all-centres list, one block per row (the long chain of latencies: scheduled first);
     // the others: the pair list, one wave per row.  A block without work ends at once and makes room.
-    const int full_grid = gridDim.x - pair_blocks;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && refine_rows_out) *refine_rows_out = eh->flag_cnt + eh->full_cnt;
-    if ((int)blockIdx.x >= full_grid) {
+    const int full_grid = gx - pair_blocks;
+    if (bx == 0 && threadIdx.x == 0 && refine_rows_out) *refine_rows_out = eh->flag_cnt + eh->full_cnt;
+    if (bx >= full_grid) {
         const int lane = threadIdx.x & 63;
         const int cnt = eh->flag_cnt;
-        for (int f = (blockIdx.x - full_grid) * 8 + (threadIdx.x >> 6); f < cnt; f += 8 * pair_blocks) {
+        for (int f = (bx - full_grid) * 8 + (threadIdx.x >> 6); f < cnt; f += 8 * pair_blocks) {
             refine_pair_row(X, C, flag_list[f], flag_cand[f], d, lane, labels);
         }
         return;
@@ -1521,11 +1522,33 @@ __global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __r
     // against the same centre loads (the sweep's L2 traffic is the bound then)
     const int cnt = eh->full_cnt;
     if (cnt <= 2 * full_grid) {
-        for (int f = blockIdx.x; f < cnt; f += full_grid) refine_full_row<8>(X, C, full_list[f], d, k, xs, rv, ri, labels);
+        for (int f = bx; f < cnt; f += full_grid) refine_full_row<8>(X, C, full_list[f], d, k, xs, rv, ri, labels);
     } else {
-        for (int f = blockIdx.x * 4; f < cnt; f += full_grid * 4)
+        for (int f = bx * 4; f < cnt; f += full_grid * 4)
             refine_full_rows4<8>(X, C, full_list + f, cnt - f < 4 ? cnt - f : 4, d, k, xs, rv, ri, labels);
     }
+}
+__global__ void __launch_bounds__(512) estep_refine_both_kernel(const float* __restrict__ X, const float* __restrict__ C,
+                                                                const float* __restrict__ ct, const EHdr* eh, const int* flag_list,
+                                                                const int* flag_cand, const int* full_list, int d, int k, int kp,
+                                                                int32_t* labels, int32_t* refine_rows_out, int pair_blocks) {
+    refine_both_body(X, C, ct, eh, flag_list, flag_cand, full_list, d, k, kp, labels, refine_rows_out, pair_blocks, (int)blockIdx.x, (int)gridDim.x);
+}
+// the same refine for SEVERAL restarts in one launch (behind estep_rbm_kernel): blockIdx.y = the a-th running restart, whose centres,
+// workspace and label slot are strided like the filter's (RbmArgs); the latency-bound chain of an all-centres row is then paid once per
+// iteration, not once per restart
+struct RefmArgs {
+    const float* C0; size_t c_stride;              // centres of slot s: C0 + s * c_stride (floats)
+    char* ws0; size_t ws_stride; size_t ct_off, flags_off, fcand_off, fulls_off;
+    int32_t* lab0; size_t lab_stride;
+    unsigned long long segmap;
+};
+__global__ void __launch_bounds__(512) estep_refine_multi_kernel(const float* __restrict__ X, const RefmArgs a, int d, int k, int kp, int pair_blocks) {
+    const int slot = (int)((a.segmap >> (4 * blockIdx.y)) & 15ull);
+    char* w = a.ws0 + (size_t)slot * a.ws_stride;
+    refine_both_body(X, a.C0 + (size_t)slot * a.c_stride, (const float*)(w + a.ct_off), (const EHdr*)w, (const int*)(w + a.flags_off),
+                     (const int*)(w + a.fcand_off), (const int*)(w + a.fulls_off), d, k, kp, a.lab0 + (size_t)slot * a.lab_stride, nullptr,
+                     pair_blocks, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ void refine_count_kernel(const EHdr* eh, int32_t* out) { *out = eh->flag_cnt + eh->full_cnt; }
@@ -3161,11 +3184,12 @@ extern "C" int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const
 struct EstepMultiItem { scd_handle h; const float* C; void* ws; int32_t* labels; int slot; };
 static bool estep_multi_serves(int d, int k, int n_items) {
     const char* ev = getenv("SCD_ESTEP_MERGED");          // read per fit (a test switches it inside one process)
-    const int en = ev ? atoi(ev) : 1;
+    const int en = ev ? atoi(ev) : 0;          // opt-in: at C2 the per-restart filters over four streams are faster (9.7-9.9 against 10.2-10.3 ms per stage, round 5)
     return en && dpad(d) == 512 && kpad(k) <= 256 && n_items >= 2 && n_items <= 16;
 }
 static int estep_multi_launch(const EstepMultiItem* it, int n_items, const float* X, const void* prep, int64_t n, int d, int k, char* ws0,
-                              size_t ws_stride, int32_t* lab0, size_t lab_stride, int n_cu, hipStream_t st) {
+                              size_t ws_stride, int32_t* lab0, size_t lab_stride, const float* C0, size_t c_stride, bool vouch, int n_cu,
+                              hipStream_t st) {
     const int dp = dpad(d), kp = kpad(k);
     const char* p = (const char*)prep;
     const PrepHdr* ph = (const PrepHdr*)p;
@@ -3189,8 +3213,10 @@ static int estep_multi_launch(const EstepMultiItem* it, int n_items, const float
         SCD_REQUIRE(w == ws0 + (size_t)it[j].slot * ws_stride && it[j].labels == lab0 + (size_t)it[j].slot * lab_stride && it[j].slot < 16,
                     "estep_multi_launch: workspaces / label slots are not equally strided");
         a.segmap |= (unsigned long long)it[j].slot << (4 * j);
-        // the finalize hand-over of this restart's handle, consumed exactly as scd_kmeans_estep consumes it
-        const bool handover = h->prep_ok && h->prep_C == it[j].C && h->prep_ws == it[j].ws && h->prep_k == k && h->prep_d == d;
+        SCD_REQUIRE(!C0 || it[j].C == C0 + (size_t)it[j].slot * c_stride, "estep_multi_launch: centres are not equally strided");
+        // the finalize hand-over of this restart's handle, consumed exactly as scd_kmeans_estep consumes it (`vouch` = the caller's
+        // SCD_ESTEP_CENTRES_FROM_FINALIZE: these centres ARE the previous step's output)
+        const bool handover = vouch && h->prep_C == it[j].C && h->prep_ws == it[j].ws && h->prep_k == k && h->prep_d == d;
         h->estep_few = 0;
         h->prep_ok = 0;
         h->prep_C = nullptr;
@@ -3213,6 +3239,16 @@ static int estep_multi_launch(const EstepMultiItem* it, int n_items, const float
     a.nparts = best_parts;
     { const int rc_ = scd_set_max_lds((const void*)estep_rbm_kernel, ERB_LDS); if (rc_) return rc_; }
     estep_rbm_kernel<<<(unsigned)(nblk * best_parts), 512, ERB_LDS, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off), a, n);
+    if (C0) {
+        // the refine of all running restarts in one launch as well (blockIdx.y = restart), each with the single-restart launch's shape
+        // (768 all-centres + 256 pair blocks: with 192 + 64 the all-centres rows of a late iteration took several rounds of their
+        // ~16-us chain, 137 us per launch where the single-restart launches take 10-20)
+        RefmArgs r;
+        r.C0 = C0; r.c_stride = c_stride;
+        r.ws0 = ws0; r.ws_stride = ws_stride; r.ct_off = ct_off; r.flags_off = a.flags_off; r.fcand_off = a.fcand_off; r.fulls_off = a.fulls_off;
+        r.lab0 = lab0; r.lab_stride = lab_stride; r.segmap = a.segmap;
+        estep_refine_multi_kernel<<<dim3(REFINE_GRID, (unsigned)n_items), 512, (size_t)d * 32 + 64, st>>>(X, r, d, k, kp, REFINE_PAIR);
+    }
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
@@ -3286,7 +3322,7 @@ static int lr_begin(LloydRestart& r, const LloydShared& S) {
     return SCD_OK;
 }
 // first half of iteration `it`: E-step + M-step (+ pack)
-static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pack_dst, bool estep_done = false) {
+static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pack_dst, bool estep_done = false, bool refine_done = false) {
     if (r.best_in_ring && r.best_it % 3 == it % 3) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }   // that slot is about to be re-used
     const size_t kd = (size_t)S.k * S.d;
     const float* c_in = it == 0 ? r.C_start : r.C_ring + (size_t)((it - 1) % 3) * kd;
@@ -3308,7 +3344,7 @@ static int lr_launch_a(LloydRestart& r, const LloydShared& S, int it, double* pa
     r.h->run_seq += 1.0;
     r.seq_of[it & 1] = r.h->run_seq;
     SCD_REQUIRE(S.k <= 8192, "scd_kmeans_lloyd_run: k > 8192");
-    if (estep_done) {          // the merged filter has run: this restart's refine, then its M-step
+    if (estep_done && !refine_done) {          // the merged filter has run: this restart's refine, then its M-step
         const int rc = estep_multi_refine(S.X_u, c_in, r.ws_e, S.n_u, S.d, S.k, r.lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), r.st);
         if (rc) return rc;
     }
@@ -3420,12 +3456,24 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
         for (int j = 0; j < R && merge_ok; ++j)
             merge_ok = (char*)rs[j].ws_e == (char*)rs[0].ws_e + (size_t)j * ws_stride && rs[j].lab_ring == rs[0].lab_ring + (size_t)j * lab_stride;
     }
+    size_t cs_stride = 0, cr_stride = 0;
+    bool cs_ok = false, cr_ok = false;
+    if (merge_ok) {
+        cs_ok = rs[1].C_start > rs[0].C_start;
+        cr_ok = rs[1].C_ring > rs[0].C_ring;
+        cs_stride = cs_ok ? (size_t)(rs[1].C_start - rs[0].C_start) : 0;
+        cr_stride = cr_ok ? (size_t)(rs[1].C_ring - rs[0].C_ring) : 0;
+        for (int j = 0; j < R; ++j) {
+            cs_ok = cs_ok && rs[j].C_start == rs[0].C_start + (size_t)j * cs_stride;
+            cr_ok = cr_ok && rs[j].C_ring == rs[0].C_ring + (size_t)j * cr_stride;
+        }
+    }
     std::vector<int> act;
     int n_active = R;
     for (int it = 0; it < S.max_iter && n_active > 0; ++it) {
         act.clear();
         for (int j = 0; j < R; ++j) if (rs[j].active) act.push_back(j);
-        bool merged = false;
+        bool merged = false, refined = false;
         if (merge_ok && act.size() >= 2) {
             // ONE filter launch for every running restart (estep_rbm_kernel): the slots the labels go to are freed first, every
             // restart's stream is joined (its previous finalize wrote the centre operands), and the restarts' streams continue behind it
@@ -3440,8 +3488,15 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
                     SCD_HIP(hipStreamWaitEvent(st, ls->ev[act[a]], 0));
                 }
             }
+            // the restarts' centres of this iteration: the seedings (it = 0) or slot (it - 1) % 3 of the centre rings - one refine launch for
+            // all of them when they are equally strided too
+            const float* c00 = it == 0 ? rs[0].C_start : rs[0].C_ring + (size_t)((it - 1) % 3) * kd;
+            const size_t c_stride = it == 0 ? cs_stride : cr_stride;
+            const bool c_ok = it == 0 ? cs_ok : cr_ok;
             const int rc = estep_multi_launch(items.data(), (int)items.size(), S.X_u, S.prep_u, S.n_u, S.d, S.k, (char*)rs[0].ws_e, ws_stride,
-                                              rs[0].lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), lab_stride, rs[0].h->n_cu, st);
+                                              rs[0].lab_ring + (size_t)(it % 3) * S.n_cat + (S.n_cat - S.n_u), lab_stride, c_ok ? c00 : nullptr,
+                                              c_stride, it > 0, rs[0].h->n_cu, st);
+            refined = c_ok;
             if (rc) return rc;
             if (ls) {
                 SCD_HIP(hipEventRecord(ls->ev[R + 1], st));
@@ -3450,7 +3505,7 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
             merged = true;
         }
         for (size_t a = 0; a < act.size(); ++a) {
-            const int rc = lr_launch_a(rs[act[a]], S, it, xch ? xch->buf + a * per : nullptr, merged);
+            const int rc = lr_launch_a(rs[act[a]], S, it, xch ? xch->buf + a * per : nullptr, merged, refined);
             if (rc) return rc;
         }
         if (xch) {

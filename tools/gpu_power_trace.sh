@@ -1,7 +1,7 @@
 #!/bin/bash
-# Board power / clocks / temperature sampled by rocm-smi (read-only) while bench.py runs -> gpurun_out/r04/r04_power_trace.txt
+# Board power / clocks / temperature sampled by rocm-smi (read-only) while bench.py runs -> gpurun_out/r05/r05_power_trace.txt
 set -u
-R=$PWD; out=$R/gpurun_out/r04; mkdir -p $out
+R=$PWD; out=$R/gpurun_out/r05; mkdir -p $out
 rm -f $out/power_samples.txt
 timeout -k 10 400 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/pw_bench.json 2> $out/pw.err &
 BP=$!
@@ -11,7 +11,7 @@ for i in $(seq 1 110); do
   sleep 0.4
 done
 wait $BP; echo "[bench] rc=$?"
-python3 - <<PY > $out/r04_power_trace.txt
+python3 - <<PY > $out/r05_power_trace.txt
 import re, json
 txt = open("$out/power_samples.txt").read().split("== t=")[1:]
 rows = []
@@ -30,4 +30,4 @@ print("# t (s)   power (W)  sclk (MHz)  mclk (MHz)  junction (C)  memory (C)  GP
 t0 = rows[0][0]
 for r in rows: print("%7.1f  %9s  %9s  %9s  %11s  %10s  %10s" % ((r[0] - t0,) + r[1:]))
 PY
-head -n 5 $out/r04_power_trace.txt; awk 'NR>3' $out/r04_power_trace.txt | sort -k2 -n -r | head -n 12
+head -n 5 $out/r05_power_trace.txt; awk 'NR>3' $out/r05_power_trace.txt | sort -k2 -n -r | head -n 12
