@@ -164,6 +164,8 @@ int scd_kmeans_lloyd_step(scd_handle h, const float* X_u, const void* prep_u, in
  * the labelled rows alone (NULL when there are none).  stats: device double [5] = {inertia labelled, inertia unlabelled, centre
  * shift, rows re-evaluated exactly, rows whose label changed}.  Reference: faster_mix_k_means_pytorch.py:187-214. */
 #define SCD_LLOYD_FULL 8
+/* (scd_kmeans_sumsq reads the rows as one flat array with 16-byte loads: the base pointer must be 16-byte aligned - an unaligned one is
+ * refused with SCD_EINVAL; n, d and split are free.) */
 int scd_kmeans_sumsq(scd_handle h, const void* X16, const float* X, int64_t n, int d, int64_t split, double* out4, void* stream);
 int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat,
                                 int64_t n_cat, int d, int k, int32_t* labels_cat, int32_t* labels_prev, const float* C_in,

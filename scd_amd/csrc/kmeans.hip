@@ -2954,6 +2954,10 @@ extern "C" int scd_kmeans_sumsq(scd_handle h, const void* X16, const float* X, i
                                 void* stream_) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_sumsq");
     SCD_REQUIRE((X16 || X) && out4 && n > 0 && d > 0 && split >= 0 && split <= n, "scd_kmeans_sumsq: bad arguments");
+    // the rows are walked as ONE flat array in 8-value steps with 16-byte loads (half8 / float4 pairs; the split boundary and the tail are
+    // handled value by value): the base pointer must be 16-byte aligned - a whole row set from an allocator is, a row-offset pointer with
+    // an odd row length need not be
+    SCD_REQUIRE(((uintptr_t)(X16 ? X16 : (const void*)X) & 15) == 0, "scd_kmeans_sumsq: the rows' base pointer must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream_;
     double* part = (double*)h->scratch;                          // 1,024 blocks x 4 doubles of the handle's 256-KB scratch
     sumsq_dd_kernel<<<SUMSQ_BLOCKS, 256, 0, st>>>((const half_t*)X16, X, (long long)split * d, (long long)n * d, part);
@@ -3469,10 +3473,23 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
         }
     }
     std::vector<int> act;
+    size_t n_act_prev = (size_t)R;
     int n_active = R;
     for (int it = 0; it < S.max_iter && n_active > 0; ++it) {
         act.clear();
         for (int j = 0; j < R; ++j) if (rs[j].active) act.push_back(j);
+        if (ls && xch && it > 0 && act.size() != n_act_prev) {
+            // a restart has dropped out: the running ones move up in the densely packed exchange buffer, i.e. a restart is about to pack
+            // into the region another restart's finalize (on ANOTHER stream, possibly the dropped restart's speculative iteration) may
+            // still be reading.  Once per drop-out: every stream waits for every stream
+            for (int j = 0; j < ns; ++j) {
+                SCD_HIP(hipEventRecord(ls->ev[j], ls->st[j]));
+                SCD_HIP(hipStreamWaitEvent(st, ls->ev[j], 0));
+            }
+            SCD_HIP(hipEventRecord(ls->ev[R + 1], st));
+            for (int j = 0; j < ns; ++j) SCD_HIP(hipStreamWaitEvent(ls->st[j], ls->ev[R + 1], 0));
+        }
+        n_act_prev = act.size();
         bool merged = false, refined = false;
         if (merge_ok && act.size() >= 2) {
             // ONE filter launch for every running restart (estep_rbm_kernel): the slots the labels go to are freed first, every

@@ -116,6 +116,12 @@ __global__ void __launch_bounds__(256) kg_prep_kernel(const float* __restrict__ 
 
 // the listed (row, candidate) pairs of batch blockIdx.y: v = min(d2[m / L][row], float32(sum_j (x_j - c_j)^2)) (float64 accumulation, x
 // from the exact fp16 copy: muf_exact_kernel's value), kept in vals[] for the winner's update; potd[m] += v - d2 (float64, <= 0).
+// EXCEPTION to the library's fixed-order-reduction rule (the only one): the per-candidate differences are added with float64 atomics
+// (LDS, then global), so the ORDER of the additions - hence the last bits of potd - may differ from run to run, and the filter path ranks
+// the candidates by sum(delta) where the dense path ranks them by fixed-order full sums.  The values themselves (vals[], d2) are exact
+// and order-free; what can differ is a pick between two candidates whose potentials agree to ~1e-16 relative (2 x 10^-16 x |pot| against
+// gaps of the order of pot / n), which the reference's own float32 potentials cannot resolve either.  The picks of every golden seeding
+// (tests/golden/kmeans_sklearn.npz, 42 seedings incl. the reference-held `_k_init`) are reproduced on both paths.
 __global__ void __launch_bounds__(256) kg_exact_kernel(const half_t* __restrict__ X16, const float* __restrict__ Cn, int d, int L, int M,
                                                        const unsigned* __restrict__ counts_all, const unsigned long long* __restrict__ list_all,
                                                        float* __restrict__ vals_all, long long cap, int g, const float* __restrict__ d2,

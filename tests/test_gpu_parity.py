@@ -1884,6 +1884,25 @@ def test_bench_launcher_four_ranks_tiny_gloo(ops):
     assert d["synthetic_name_accuracy"] > 0.5
 
 
+def test_bench_config_c3_small(ops):
+    """`python bench.py --config c3` (BASELINE configs[2]: GCD / DINO + CLIP encode, raw top-5, ConSSKM with the restarts in lock-step on
+    host threads, partially supervised vote) at a small size: the command runs to its JSON line, the size bounds hold and the planted
+    names are found."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("SCD_HIP_LIB", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c3", "--steps", "1", "--warmup", "1", "--images", "3000", "--n-cluster", "24",
+           "--vocab", "2048", "--batch", "665", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["cluster"] == "ConSSKM" and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["consskm"]["transport_solves_per_fit"] >= 10 and d["consskm"]["cluster_sizes_min_max"][0] >= 50
+    assert d["vote_iters"] >= 1 and d["synthetic_name_accuracy"] > 0.6
+
+
 def test_two_ranks_one_gpu_sharded_kmeans(ops):
     """The same worker as two ranks SHARING this box's one GPU (gloo collectives on device tensors; RCCL refuses a duplicate device):
     the sharded SSKM / K-Means fits - lock-step seeding over the three all-gathers, Lloyd loops behind scd_kmeans_lloyd_run_sharded
