@@ -800,7 +800,13 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_DMA(BASE, P, SLOTLDS, PART, MOD)                                                                      \
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD                        \
                  ::"s"(SLOTLDS), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16), "n"((PART) + (P) * 1024) : "memory", "scc")
-    auto issue_a = [&](int p, int slot) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, W4_A_MOD); };
+#ifndef W4_A_NT_LN1
+#define W4_A_NT_LN1 0    // experiment: non-temporal activation fills in the LayerNorm-folded variants only (QKV, fc1: K = 768, A read once per n-group)
+#endif
+    auto issue_a = [&](int p, int slot) {
+        if constexpr (W4_A_NT_LN1 && LN == 1) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, " nt"); }
+        else { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, W4_A_MOD); }
+    };
     auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, dma_lds + slot * SLOT, WPART, W4_W_MOD); };
     auto issue = [&](const TileIt& it, int kc, int slot) {
         chunk_ptrs(it, kc);
