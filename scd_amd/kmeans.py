@@ -597,7 +597,11 @@ class KMeansEngine:
                 bufs.lab32[:l_num] = per[0]["l_rank"]
             c_inits = torch.stack([p["init_centers"] for p in per])
             x0 = getattr(bufs, "_xch_n", 0)
-            res = bufs.run_multi(c_inits, self.max_iterations, self.tolerance, n_streams=int(os.environ.get("SCD_LLOYD_STREAMS", "4")))
+            # four library-owned streams on one GPU (the restarts' latency-bound launches overlap each other's filters: 11.3 -> 9.4-9.9 ms per
+            # C2 stage); ONE stream under a process group unless asked otherwise - the collective's latency dominates there, and the
+            # multi-stream exchange has only ever run over gloo (tests/dist_rccl_worker.py), never over RCCL with more than one rank
+            n_streams = int(os.environ.get("SCD_LLOYD_STREAMS", "4" if dd is None else "1"))
+            res = bufs.run_multi(c_inits, self.max_iterations, self.tolerance, n_streams=n_streams)
             self.stats["lockstep_fits"] = self.stats.get("lockstep_fits", 0) + 1
             if dd is not None:                  # all-reduces of the fit's Lloyd loops: one per lock-step iteration, whatever n_init is
                 self.stats["lloyd_exchanges"] = self.stats.get("lloyd_exchanges", 0) + getattr(bufs, "_xch_n", 0) - x0

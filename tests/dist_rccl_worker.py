@@ -87,8 +87,10 @@ def main():
     # diverged).  Bit-identical to the single-rank fit, as above
     one = KMeansEngine(k=k, tolerance=5e-2, max_iterations=8, n_init=8, random_state=7)
     one.fit_mix(T(u), T(l), T(lt))
+    os.environ["SCD_LLOYD_STREAMS"] = "4"          # (under a group the default is one stream)
     shd = KMeansEngine(k=k, tolerance=5e-2, max_iterations=8, n_init=8, random_state=7, group=grp)
     shd.fit_mix(T(u[su]), T(l[sl]), T(lt[sl]))
+    del os.environ["SCD_LLOYD_STREAMS"]
     assert shd.stats.get("lockstep_fits", 0) == 1 and shd.stats.get("lloyd_exchanges", 0) <= 8, shd.stats
     full, mine = one.labels_.cpu().numpy(), shd.labels_.cpu().numpy()
     assert np.array_equal(mine[:n_ls], full[:n_l][sl]) and np.array_equal(mine[n_ls:], full[n_l:][su]), "restarts dropping out: sharded labels differ"
