@@ -710,8 +710,11 @@ class ConstrainedEngine(KMeansEngine):
         flow problem is gathered to rank 0 per iteration: _assign)."""
         be = self._be()
         data = kw.get("data")
+        # (the lock-step form stages every running restart's int32 cost matrix in pinned host memory at once: beyond 2 GB - n_init x N_u x K x 4
+        # bytes - the restarts run one after the other)
         if (inits is None or self._dist() is not None or data is None or not hasattr(be, "transport_batch")
-                or not getattr(data.x, "is_cuda", False) or os.environ.get("SCD_CONSSKM_LOCKSTEP", "1") == "0"):
+                or not getattr(data.x, "is_cuda", False) or os.environ.get("SCD_CONSSKM_LOCKSTEP", "1") == "0"
+                or self.n_init * data.n * self.k * 4 > (2 << 30)):
             return super()._run(once, *args, inits=inits, **kw)
         rs = check_random_state(self.random_state)
         per = inits(rs)
