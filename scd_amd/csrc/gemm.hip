@@ -676,6 +676,10 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 #ifndef W4_LATE_TM
 #define W4_LATE_TM 2
 #endif
+#ifndef W4_WSPLIT
+#define W4_WSPLIT 0     // ring-fill schedule experiment: this many of a chunk's eight W fills are issued in the ODD sub-step behind the A fills
+#endif                  // (A every 4 MFMAs instead of every 6), the rest at the very start of the next even one: the chunk's last fill goes out
+                        // ~16 MFMAs earlier, i.e. has ~300 more cycles to land before the barrier that waits for it
 #ifndef W4_ABL_STATS
 #define W4_ABL_STATS 0   // timing probe (results wrong): 1 = the LN = 2 epilogue computes / adds no row statistics
 #endif
@@ -853,6 +857,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     if (!DMA_SPLIT) {
 #pragma unroll
         for (int p = 0; p < W4_TNW; ++p) issue_w(p, 1);
+    } else if (W4_WSPLIT) {
+#pragma unroll
+        for (int p = 0; p < W4_WSPLIT; ++p) issue_w(p, 1);     // (what an odd sub-step would have issued of chunk 1's W part)
     }
     issue_advance();
 #ifndef W4_RD_LN2
@@ -884,7 +891,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     half8 fwA[8], fwB[8], faA[8], faB[8];   // W / A fragments of the even (A) and odd (B) sub-step
 #define W4_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define W4_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
-    if (DMA_SPLIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (DMA_SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + W4_WSPLIT) : "memory");
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -914,7 +921,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // of the refill that the previous odd sub-step began (the other slot), one fill per four MFMAs of the first half
 #if W4_TNW == 8
 #define W4_H_EVEN(i)                                                                                             \
-    if (DMA_SPLIT && (i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);                             \
+    if (DMA_SPLIT && !W4_WSPLIT && (i) < 32 && ((i) & 3) == 2) issue_w(((i) >> 2) & 7, cslot ^ 1);               \
+    if (DMA_SPLIT && W4_WSPLIT && (i) < 4 * (8 - W4_WSPLIT) && ((i) & 3) == 2) issue_w((W4_WSPLIT + ((i) >> 2)) & 7, cslot ^ 1); \
     if ((i) < 48 && (i) % 3 == 0) W4_RD(fwB[((i) / 3) & 7], fw1 + so, (((i) / 3) & 7) * 2048);                   \
     if ((i) < 48 && (i) % 3 == 1) W4_RD(faB[((i) / 3) & 7], fa1 + so, (((i) / 3) & 7) * 2048);
     // odd sub-step: reads the next chunk's first fragments (other slot) under MFMAs 0..47 and starts refilling this slot with
@@ -929,7 +937,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     /* LATE_BAR: the barrier sits after MFMA L0-1, so everything that needs it is packed under MFMAs L0..63 */    \
     if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) < 8) W4_RD(fwA[(((i) - L0) >> 1) & 7], fw0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
     if (LATE_BAR && (i) >= L0 && (((i) - L0) & 1) == 0 && (((i) - L0) >> 1) >= 8 && (((i) - L0) >> 1) < 16) W4_RD(faA[(((i) - L0) >> 1) & 7], fa0 + no, ((((i) - L0) >> 1) & 7) * 2048); \
-    if (LATE_BAR && DMA_SPLIT && (i) >= L0 && ((i) - L0) % LS == LS / 2 && ((i) - L0) / LS < 8) issue_a((((i) - L0) / LS) & 7, cslot);
+    if (LATE_BAR && DMA_SPLIT && !W4_WSPLIT && (i) >= L0 && ((i) - L0) % LS == LS / 2 && ((i) - L0) / LS < 8) issue_a((((i) - L0) / LS) & 7, cslot); \
+    if (LATE_BAR && DMA_SPLIT && W4_WSPLIT && (i) >= L0 && (((i) - L0) & 3) == 1 && ((i) - L0) / 4 < 8) issue_a((((i) - L0) / 4) & 7, cslot); \
+    if (LATE_BAR && DMA_SPLIT && W4_WSPLIT && (i) >= L0 + 32 && (((i) - L0) & 3) == 1 && ((i) - L0 - 32) / 4 < W4_WSPLIT) issue_w((((i) - L0 - 32) / 4) & 7, cslot);
 #else
     // 32 MFMAs per sub-step: 12 fragment reads under the first 24, the W part of the refill (4 instructions per wave) every 8th
 #define W4_H_EVEN(i)                                                                                             \
@@ -960,7 +970,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         if (!(xmode & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_s_barrier();                                                                            \
         asm volatile("" ::: "memory");                                                                           \
-        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_bar += t - t_sub; t_sub = t; } \
+        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_bar += ((xmode & 2048) && !tile_first) ? 0ull : t - t_sub; t_sub = t; } \
+        tile_first = false;                                                                                      \
         /* past this block's last chunk the refill re-reads the current tile's first chunk into the free slot: no branch  \
            around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
         if (g + 2 < chunks) { ga = ga_t + nkt * 64; gw = gw_t + nkt * 64; } else chunk_ptrs(cit, 0);             \
@@ -971,7 +982,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     }
     unsigned long long t_main = 0, t_epi = 0, t_begin = __builtin_readcyclecounter();
     unsigned long long t_even = 0, t_odd = 0, t_bar = 0, t_sub = t_begin;
+    bool tile_first = true;      // (-DSCD_ABLATE, SCD_GEMM_X & 2048: the wait + barrier counter takes a tile's FIRST chunk only - the one behind the previous tile's stores)
     for (int ti = 0; ti < my_tiles; ++ti) {
+        tile_first = true;
         const int bm = cit.bm, bn = cit.n0 + cit.bnl;
         const int nb0 = bn * BN + wn * 128;
         // C / R addresses of the epilogue = a wave-uniform tile base (SGPRs) + ONE 32-bit per-lane element offset (row q16 of the
