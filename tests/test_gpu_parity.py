@@ -2016,8 +2016,8 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
     assert res["1"][2] == float(okm.inertia_)
 
 
-@pytest.mark.parametrize("n,d,k,R,labelled,tol", [(30011, 512, 100, 10, True, 1e-4), (9000, 448, 130, 5, False, 1e-4), (70000, 512, 37, 12, True, 5e-2),
-                                                   (4100, 512, 256, 2, True, 1e-4), (20000, 512, 60, 16, False, 1e30)])
+@pytest.mark.parametrize("n,d,k,R,labelled,tol", [(12011, 512, 100, 10, True, 1e-4), (9000, 448, 130, 5, False, 1e-4), (16000, 512, 37, 12, True, 5e-2),
+                                                   (4100, 512, 256, 2, True, 1e-4), (8000, 512, 60, 16, False, 1e30)])
 def test_lockstep_merged_estep_equals_per_restart_filters(ops, monkeypatch, n, d, k, R, labelled, tol):
     """The restarts' Lloyd loops in lock-step (scd_kmeans_lloyd_run_multi) with ONE filter launch per iteration for all running restarts
     (estep_rbm_kernel: Dp = 512, Kp <= 256; segments of the unit stream, whole restarts per part) against the same loops with one filter
