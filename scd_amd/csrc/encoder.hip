@@ -397,6 +397,11 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
 // LDS image per buffer: K 224 rows x 128 B, chunk c of row r at c ^ ((r>>1)&7); V 224 rows x 128 B, its 64-byte halves
 // swapped when (r>>1)&1, which makes the transposing reads (4 rows x 64 B per 32-lane group) tile the 64 banks.  Rows past
 // T repeat row T-1 (finite values); their scores are masked to -inf, so their P is exactly 0.
+// T197 (T = 197, the ViT-B/16 towers): what the padding to 224 keys costs is left out at compile time - of the last key block only keys
+// 192..196 can be valid, so 12 of its 16 exponentials per lane, its second pair of P V MFMAs (keys 208..223) with their V reads, and the
+// ring fills of K rows >= 200 / V rows >= 208 are not executed (their probabilities are exactly 0 and 0 x finite adds +0 to a sum that
+// starts at +0: the same bits).  The K rows that are not filled hold whatever the LDS held; their scores are never read.
+template <bool T197>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width, int heads, int items, int xmode) {
     constexpr int NB = 7, TP = NB * 32, KV = TP * 128;
@@ -414,13 +419,14 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
             const half_t* kb = qkv + (size_t)img * T * ld + width + head * 64;
             const half_t* vb = kb + width;
 #pragma unroll 4
-            for (int p = 0; p < TP / 8; ++p) {
+            for (int p = 0; p < (T197 ? 26 : TP / 8); ++p) {
                 const int row = p * 8 + drow;
                 const int rowc = row < T ? row : T - 1;
                 const unsigned voff_k = (unsigned)(rowc * ld + ((pc ^ ((row >> 1) & 7)) << 3)) * 2;
                 const unsigned voff_v = (unsigned)(rowc * ld + ((pc ^ (((row >> 1) & 1) << 2)) << 3)) * 2;
                 const unsigned lds = sbase + buf * 2 * KV + p * 1024;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_k), "s"(kb) : "memory");
+                if (!T197 || p < 25)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff_k), "s"(kb) : "memory");
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds + KV), "v"(voff_v), "s"(vb) : "memory");
             }
         };
@@ -483,14 +489,14 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
         // softmax over keys on the raw scores (only the last key block holds padded keys); 1/sqrt(64) folded into exp2
         float mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {   // only the last key block can hold padded keys
+        for (int e = 0; e < (T197 ? 4 : 16); ++e) {   // only the last key block can hold padded keys (T197: its registers 4..15 always do)
             const int key = (NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
             if (key >= T) sacc[NB - 1][e] = -INFINITY;
         }
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) mx = fmaxf(fmaxf(mx, sacc[kb][e]), sacc[kb][e + 1]);   // v_max3_f32
+            for (int e = 0; e < (T197 && kb == NB - 1 ? 4 : 16); e += 2) mx = fmaxf(fmaxf(mx, sacc[kb][e]), sacc[kb][e + 1]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // p = 2^((s - max) * 0.125 * log2 e), two keys per instruction wherever the ISA has a packed form (v_pk_fma_f32,
         // v_pk_add_f32, v_cvt_pk_f16_f32): the kernel is VALU-bound (two consumer waves per SIMD, ~600 VALU instructions per
@@ -505,6 +511,7 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                if (T197 && kb == NB - 1 && e >= 2) { ph[kb][e] = h2v{(_Float16)0.f, (_Float16)0.f}; continue; }   // keys >= 200: p = 0
                 f2v t = {sacc[kb][2 * e], sacc[kb][2 * e + 1]};
                 t = t * cs2 + nmx2;
                 t.x = __builtin_amdgcn_exp2f(t.x);
@@ -523,7 +530,7 @@ attention_persist_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ ou
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < (T197 && kb == NB - 1 ? 1 : 2); ++s) {   // T197: keys 208..223 contribute exactly nothing
                 half8 pf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { pf[2 * j] = ph[kb][4 * s + j].x; pf[2 * j + 1] = ph[kb][4 * s + j].y; }
@@ -916,9 +923,14 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
         static const int attn_persist = getenv("SCD_ATTN_PERSIST") ? atoi(getenv("SCD_ATTN_PERSIST")) : 1;
         if (pad.tokens > 192 && pad.tokens <= 224 && !causal && attn_persist) {
             constexpr int attn_lds = 2 * 2 * 224 * 128 + 7 * 4096;      // K/V double buffer + the consumers' output patches
-            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel, attn_lds); if (rc_) return rc_; }
+            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel<false>, attn_lds); if (rc_) return rc_; }
+            { const int rc_ = scd_set_max_lds((const void*)attention_persist_kernel<true>, attn_lds); if (rc_) return rc_; }
             const int items = bp * d.heads;
-            attention_persist_kernel<<<items < 256 ? items : 256, 512, attn_lds, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
+            static const int attn_t197 = getenv("SCD_ATTN_T197") ? atoi(getenv("SCD_ATTN_T197")) : 1;   // 0: the generic kernel at T = 197 as well (A/B)
+            if (pad.tokens == 197 && attn_t197)
+                attention_persist_kernel<true><<<items < 256 ? items : 256, 512, attn_lds, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
+            else
+                attention_persist_kernel<false><<<items < 256 ? items : 256, 512, attn_lds, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
         } else if (pad.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         else if (pad.tokens <= 32) attention_kernel<1><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         else if (pad.tokens <= 64) attention_kernel<2><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
