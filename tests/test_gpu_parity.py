@@ -879,6 +879,42 @@ def test_encoder_large_launch_equals_small_batches(ops, kind):
         assert torch.equal(small, big[s0:s0 + 13]), s0
 
 
+def test_attention_t197_specialisation_is_bit_identical():
+    """At T = 197 (both ViT-B/16 towers) `attention_persist_kernel<true>` leaves out what the padding to 224 keys costs: 12 of the last
+    key block's 16 exponentials per lane, its second pair of P V MFMAs, the ring fills of K rows >= 200 / V rows >= 208 (whose LDS rows
+    then hold stale data that must never reach a result).  A child process with SCD_ATTN_T197=0 runs the generic kernel: the CLIP
+    (image) and DINO features of the same images are the same bits, for a launch of several items per CU and a ragged small one."""
+    import subprocess
+    import sys
+    import tempfile
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from scd_amd.clip import weights as W
+from scd_amd.clip.model import CLIP, DinoViT
+clip = CLIP(W.synthetic_clip_state_dict(seed=3, cfg=dict(v_layers=3, t_layers=1))).cuda().eval()
+dino = DinoViT(W.synthetic_dino_state_dict(seed=1, layers=3)).cuda()
+g = torch.Generator(device="cuda").manual_seed(11)
+img = torch.randn(330, 3, 224, 224, generator=g, device="cuda", dtype=torch.float16)
+out = {"clip": clip.encode_image(img).cpu(), "dino": dino(img).cpu(), "clip7": clip.encode_image(img[:7]).cpu()}
+assert all(bool(torch.isfinite(v.float()).all()) for v in out.values())
+torch.save(out, sys.argv[1])
+print("done")
+""" % (ROOT,)
+    outs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("0", "1"):
+            env = dict(os.environ, SCD_ATTN_T197=mode)
+            env.pop("SCD_HIP_LIB", None)
+            path = os.path.join(tmp, "f%s.pt" % mode)
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and "done" in r.stdout, r.stderr[-2000:]
+            outs[mode] = torch.load(path)
+    for key in ("clip", "dino", "clip7"):
+        a, b = outs["0"][key], outs["1"][key]
+        assert a.dtype == b.dtype and torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)), key
+
+
 @pytest.mark.parametrize("longest", [9, 32, 33, 64, 65, 76])
 def test_text_tower_trimmed_context_is_bit_identical(ops, longest):
     """encode_text reads only the EOT position of a causal tower (clip model.py encode_text): computing the first
