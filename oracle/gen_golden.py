@@ -468,6 +468,26 @@ class _NoCuda(list):
         return self
 
 
+def gen_topk16():
+    """The reference's own top-k blocks (main_unsup.py:504-531 softmax, main_ptsup.py:526-545 raw) on inputs that are EXACT in fp16 - what
+    the HIP path is given - at the product kernel's shape class (d = 512, three batches of 1024 with a ragged last one).  Only the outputs
+    are stored; the test rebuilds the inputs from the same seeds (oracle/synth.py)."""
+    from oracle import synth
+    n, d, k, v = 2100, 512, 25, 1500
+    x, y, cent = synth.clustered_features(n, d, k, seed=41, center_seed=42, noise=0.9)
+    w = synth.vocabulary(v, d, cent, seed=43, jitter=0.5, dtype=np.float32)
+    x16, w16 = x.astype(np.float16), w.astype(np.float16)
+    ns = dict(torch=torch, F=torch.nn.functional, tqdm=lambda z: z, clip_all_feats=torch.from_numpy(x16.astype(np.float32)),
+              zeroshot_weights=torch.from_numpy(w16.astype(np.float32)), args=types.SimpleNamespace(topk=5))
+    exec(ref_lines("main_unsup.py", 504, 531), ns)
+    ns2 = dict(ns)
+    exec(ref_lines("main_ptsup.py", 526, 545), ns2)
+    np.savez_compressed(os.path.join(OUT, "topk_f16.npz"), shape=np.array([n, d, k, v]), seeds=np.array([41, 42, 43]),
+                        idx_unsup=ns["name_idx_top5"].numpy(), val_unsup=ns["name_logits_top5"].numpy(),
+                        idx_ptsup=ns2["name_idx_top5"].numpy(), val_ptsup=ns2["name_logits_top5"].numpy())
+    print("topk_f16.npz written")
+
+
 def gen_encoders():
     from scd_amd.clip import weights as W
     out = {}
@@ -554,10 +574,10 @@ def main():
         sys.exit(2)
     os.makedirs(OUT, exist_ok=True)
     install_stubs(NxMinCostFlow)
-    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "kinit", "constrained", "naming", "encoders"]
+    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "kinit", "constrained", "naming", "topk16", "encoders"]
     for w in which:
         dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, sklearn=gen_sklearn_kmeans, kinit=gen_sklearn_kinit, constrained=gen_constrained,
-             naming=gen_naming, encoders=gen_encoders)[w]()
+             naming=gen_naming, topk16=gen_topk16, encoders=gen_encoders)[w]()
 
 
 if __name__ == "__main__":

@@ -654,6 +654,21 @@ def test_sim_topk_golden_and_oracle(ops, golden):
     assert (idx[:, 0].cpu().numpy() == g["tk_idx_ptsup"][:, 0]).mean() > 0.99
 
 
+def test_sim_topk_equals_the_reference_blocks_on_f16_inputs(ops, golden):
+    """The reference's own top-k blocks (main_unsup.py:504-531 softmax, main_ptsup.py:526-545 raw logits), run at fixture-generation
+    time on fp16-exact features and names (tests/golden/topk_f16.npz, d = 512: the row-block kernel), against scd_sim_topk on the same
+    values: the reference's index lists on all 2,100 rows (its float32 ranking and the exact one agree on this fixture, near-ties of
+    1e-5 logit units included), same values."""
+    from test_oracle_golden import topk16_case
+    g, f16, w16 = topk16_case(golden)
+    wt = ops.transpose_f16(dev(w16))
+    for mode, ikey, vkey, tol in (("softmax", "idx_unsup", "val_unsup", dict(rtol=2e-4, atol=1e-7)),
+                                  ("raw", "idx_ptsup", "val_ptsup", dict(rtol=1e-5, atol=1e-4))):
+        idx, val = ops.sim_topk(dev(f16), wt, 5, mode)
+        assert np.array_equal(idx.cpu().numpy(), g[ikey])
+        assert np.allclose(val.cpu().numpy(), g[vkey], **tol)
+
+
 @pytest.mark.parametrize("n,v,d,k", [(300, 21000, 512, 5), (129, 1000, 512, 3), (1000, 100, 512, 1), (64, 37, 64, 8),
                                      (33100, 1100, 512, 3), (66000, 1031, 512, 3), (300, 1031, 512, 2)])
 def test_sim_topk_shapes(ops, n, v, d, k):
