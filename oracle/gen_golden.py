@@ -469,22 +469,70 @@ class _NoCuda(list):
 
 
 def gen_topk16():
-    """The reference's own top-k blocks (main_unsup.py:504-531 softmax, main_ptsup.py:526-545 raw) on inputs that are EXACT in fp16 - what
-    the HIP path is given - at the product kernel's shape class (d = 512, three batches of 1024 with a ragged last one).  Only the outputs
-    are stored; the test rebuilds the inputs from the same seeds (oracle/synth.py)."""
+    """The reference's own top-k blocks (main_unsup.py:504-531 softmax, main_ptsup.py:526-545 raw) and both vote loops
+    (main_unsup.py:568-614, main_ptsup.py:588-676) on inputs that are EXACT in fp16 - what the HIP path is given - at the product
+    kernel's shape class (d = 512, three batches of 1024 with a ragged last one).  Only the outputs are stored; the tests rebuild the
+    inputs from the same seeds (oracle/synth.py)."""
+    import clip_lang_util as clu
     from oracle import synth
     n, d, k, v = 2100, 512, 25, 1500
     x, y, cent = synth.clustered_features(n, d, k, seed=41, center_seed=42, noise=0.9)
     w = synth.vocabulary(v, d, cent, seed=43, jitter=0.5, dtype=np.float32)
+    perm, mask_lab = synth.labelled_split(y, k, prop=0.5, seed=44)
+    x, y = x[perm], y[perm]
     x16, w16 = x.astype(np.float16), w.astype(np.float16)
-    ns = dict(torch=torch, F=torch.nn.functional, tqdm=lambda z: z, clip_all_feats=torch.from_numpy(x16.astype(np.float32)),
-              zeroshot_weights=torch.from_numpy(w16.astype(np.float32)), args=types.SimpleNamespace(topk=5))
+    xt, wt = torch.from_numpy(x16.astype(np.float32)), torch.from_numpy(w16.astype(np.float32))
+    nouns = synth.nouns_list(v)
+    ns = dict(torch=torch, F=torch.nn.functional, tqdm=lambda z: z, clip_all_feats=xt, zeroshot_weights=wt,
+              args=types.SimpleNamespace(topk=5))
     exec(ref_lines("main_unsup.py", 504, 531), ns)
     ns2 = dict(ns)
     exec(ref_lines("main_ptsup.py", 526, 545), ns2)
-    np.savez_compressed(os.path.join(OUT, "topk_f16.npz"), shape=np.array([n, d, k, v]), seeds=np.array([41, 42, 43]),
-                        idx_unsup=ns["name_idx_top5"].numpy(), val_unsup=ns["name_logits_top5"].numpy(),
-                        idx_ptsup=ns2["name_idx_top5"].numpy(), val_ptsup=ns2["name_logits_top5"].numpy())
+    out = dict(shape=np.array([n, d, k, v]), seeds=np.array([41, 42, 43, 44]),
+               idx_unsup=ns["name_idx_top5"].numpy(), val_unsup=ns["name_logits_top5"].numpy(),
+               idx_ptsup=ns2["name_idx_top5"].numpy(), val_ptsup=ns2["name_logits_top5"].numpy())
+    # unsupervised vote loop from imperfect initial clusters
+    rs = np.random.RandomState(45)
+    u_preds0 = np.where(rs.rand(n) < 0.8, (y * 7 + 2) % k, rs.randint(0, k, size=n))
+    trace = []
+    src = ref_lines("main_unsup.py", 568, 614) + "    _trace(voted_unique_name_idx, ind, cand_names, u_preds)\n"
+    ns3 = dict(torch=torch, np=np, Counter=Counter, copy=copy, assign_name=clu.assign_name, print=lambda *a, **k: None,
+               name_idx_top5=ns["name_idx_top5"], u_preds=u_preds0.copy(), clip_u_feats=xt, zeroshot_weights=wt, nouns=nouns,
+               num_unlab_classes=k, top_k=5, it=0, cur_voted_names=[0], prev_voted_names=[1],
+               args=types.SimpleNamespace(num_common_vote=10, num_common_linear=2),
+               _trace=lambda vo, ind, cand, up: trace.append((np.array(vo), ind.copy(),
+                                                              np.array([nouns.index(c) for c in cand]), up.copy())))
+    exec(src, ns3)
+    out["vu_preds0"], out["vu_cfg"], out["vu_iters"] = u_preds0, np.array([k, 5, 10, 2]), np.array(len(trace))
+    for i, (vo, ind, cand, up) in enumerate(trace):
+        out["vu_voted_%d" % i], out["vu_ind_%d" % i], out["vu_cand_%d" % i], out["vu_preds_%d" % i] = vo, ind, cand, up
+    print("unsup vote loop iterations:", len(trace))
+    # partially supervised vote loop
+    n_lab_cls = k // 2
+    all_preds0 = np.where(rs.rand(n) < 0.85, y, rs.randint(0, k, size=n))
+    all_preds0[mask_lab] = y[mask_lab]
+    trace2 = []
+    pre = ref_lines("main_ptsup.py", 588, 599) + ref_lines("main_ptsup.py", 602, 603) + \
+        ref_lines("main_ptsup.py", 615, 618) + ref_lines("main_ptsup.py", 625, 625)
+    body = ref_lines("main_ptsup.py", 629, 676) + \
+        "    _trace(voted_unique_name_idx, ind, cand_names, u_preds, unlab_cluster_idx)\n"
+    ns4 = dict(torch=torch, np=np, Counter=Counter, copy=copy, assign_name=clu.assign_name, print=lambda *a, **k: None,
+               name_idx_top5=ns2["name_idx_top5"], name_logits_top5=ns2["name_logits_top5"],
+               mask_lab=mask_lab, all_preds=all_preds0.copy(), clip_u_feats=xt[torch.from_numpy(~mask_lab)],
+               zeroshot_weights=wt, nouns=nouns, cidx_to_cname={c: nouns[c] for c in range(k)},
+               args=types.SimpleNamespace(num_common_vote=10, num_common_linear=2, topk=5, n_cluster=k,
+                                          train_classes=list(range(n_lab_cls))),
+               _trace=lambda vo, ind, cand, up, uc: trace2.append(
+                   (np.array(vo), ind.copy(), np.array([nouns.index(c) for c in cand]), up.copy(), np.array(uc))))
+    exec(pre, ns4)
+    exec(body, ns4)
+    out["vp_mask_lab"], out["vp_all_preds0"] = mask_lab, all_preds0
+    out["vp_cfg"], out["vp_iters"] = np.array([k, n_lab_cls, 5, 10, 2]), np.array(len(trace2))
+    for i, (vo, ind, cand, up, uc) in enumerate(trace2):
+        out["vp_voted_%d" % i], out["vp_ind_%d" % i], out["vp_cand_%d" % i] = vo, ind, cand
+        out["vp_preds_%d" % i], out["vp_unlab_%d" % i] = up, uc
+    print("ptsup vote loop iterations:", len(trace2))
+    np.savez_compressed(os.path.join(OUT, "topk_f16.npz"), **out)
     print("topk_f16.npz written")
 
 

@@ -1263,6 +1263,47 @@ def test_vote_loop_ptsup_matches_reference_trace(ops, golden):
     assert (tr[-1]["u_preds"] == g["vp_preds_%d" % last]).mean() > 0.995
 
 
+def test_vote_loops_equal_the_reference_traces_on_f16_inputs(ops, golden):
+    """Both vote loops of the reference (main_unsup.py:568-614, main_ptsup.py:588-676) exec'd at fixture-generation time on the
+    fp16-exact inputs of tests/golden/topk_f16.npz, against naming.vote_loop_unsup / vote_loop_ptsup on the HIP library: EVERY iteration of
+    both traces - voted names, cluster-to-name assignment, candidate names, re-classified predictions, unlabelled cluster ids - equals the
+    reference's own, starting from the HIP path's own top-k (rows a5-a9 against the reference itself, not only against the oracle)."""
+    import subprocess
+    import sys
+    if os.environ.get("PYTHONHASHSEED") != "0":   # set-of-str order (main_ptsup.py:664) depends on the hash seed of the fixture's run
+        env = dict(os.environ, PYTHONHASHSEED="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                            "test_vote_loops_equal_the_reference_traces_on_f16_inputs"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return
+    from scd_amd import naming
+    from test_oracle_golden import topk16_case
+    g, f16, w16 = topk16_case(golden)
+    nouns = synth.nouns_list(w16.shape[1])
+    wt = ops.transpose_f16(dev(w16))
+    fh = dev(f16)
+    k, topk, ncv, ncl = g["vu_cfg"].tolist()
+    idx, _ = naming.full_vocab_topk(fh, None, 5, True, wt=wt)
+    assert np.array_equal(idx.cpu().numpy(), g["idx_unsup"])
+    cand, up, tr = naming.vote_loop_unsup(idx, g["vu_preds0"], fh, wt, nouns, k, ncv, ncl)
+    assert len(tr) == int(g["vu_iters"])
+    for i, t in enumerate(tr):
+        for key, gk in (("voted", "vu_voted_%d"), ("ind", "vu_ind_%d"), ("cand", "vu_cand_%d"), ("u_preds", "vu_preds_%d")):
+            assert np.array_equal(np.asarray(t[key]), g[gk % i]), (i, key)
+    k, n_lab, topk, ncv, ncl = g["vp_cfg"].tolist()
+    mask_lab = g["vp_mask_lab"]
+    lab_names = [nouns[c] for c in range(n_lab)]
+    idx, _ = naming.full_vocab_topk(fh, None, 5, False, wt=wt)
+    assert np.array_equal(idx.cpu().numpy(), g["idx_ptsup"])
+    m = dev(~mask_lab)
+    cand, up, tr = naming.vote_loop_ptsup(idx[m], g["vp_all_preds0"], mask_lab, fh[m], wt, nouns, lab_names, k, topk, ncv, ncl)
+    assert len(tr) == int(g["vp_iters"])
+    for i, t in enumerate(tr):
+        for key, gk in (("voted", "vp_voted_%d"), ("ind", "vp_ind_%d"), ("cand", "vp_cand_%d"), ("u_preds", "vp_preds_%d"),
+                        ("unlab_cluster_idx", "vp_unlab_%d")):
+            assert np.array_equal(np.asarray(t[key]), g[gk % i]), (i, key)
+
+
 # ----------------------------------------------------------------------------------------------- BASELINE configs[3] / [4] shapes
 @pytest.mark.parametrize("ncv,ncl", [(10, 2), (20, 4)])
 def test_c4_shape_vote_k1000(ops, ncv, ncl):
