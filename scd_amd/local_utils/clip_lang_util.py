@@ -144,7 +144,10 @@ def zeroshot_classifier_sharded(classnames, templates, model, group, names_per_b
     per = (n + world - 1) // world
     mine = classnames[rank * per:(rank + 1) * per]
     local = build(mine, templates, model, names_per_batch) if len(mine) else None          # [D, n_mine]
-    dev = local.device if local is not None else torch.device("cpu")
+    if local is not None:
+        dev = local.device
+    else:   # a rank without names still takes part in the collectives: on the device the backend moves (RCCL: the GPU, gloo: the host)
+        dev = torch.device("cuda", torch.cuda.current_device()) if str(dist.get_backend(group)) == "nccl" else torch.device("cpu")
     dvec = torch.tensor([0 if local is None else local.shape[0]], dtype=torch.int64, device=dev)
     dims = [torch.empty_like(dvec) for _ in range(world)]
     dist.all_gather(dims, dvec, group=group)
