@@ -92,6 +92,21 @@ int main() {
         for (int c = 0; c < k; ++c) if (cnt[c] < smin || cnt[c] > smax) ++fails;
         if (t != total) ++fails;
     }
+    // the batch form (the restarts' problems of one iteration on host threads): every problem's labels and total are the single solve's
+    for (int trial = 0; trial < 12; ++trial) {
+        const int k = 2 + rnd() % 5, batch = 1 + rnd() % 7, threads = 1 + rnd() % 4;
+        const int64_t n = 2 * k + rnd() % 80;
+        const int smin = (int)(n / k) / 2, smax = (int)((n + k - 1) / k) + 3;
+        std::vector<int32_t> cost((size_t)batch * n * k), lab((size_t)batch * n, -1), one(n);
+        for (auto& x : cost) x = rnd() % 1000;
+        std::vector<int64_t> totals(batch, -1);
+        if (scd_transport_solve_batch(cost.data(), n, k, batch, smin, smax, lab.data(), totals.data(), threads) != 0) { ++fails; continue; }
+        for (int b = 0; b < batch; ++b) {
+            int64_t t = 0;
+            if (scd_transport_solve(cost.data() + (size_t)b * n * k, n, k, smin, smax, one.data(), &t) != 0) { ++fails; continue; }
+            if (t != totals[b] || !std::equal(one.begin(), one.end(), lab.begin() + (size_t)b * n)) ++fails;
+        }
+    }
     printf("sanitize_host: %d failures\n", fails);
     return fails ? 1 : 0;
 }

@@ -407,7 +407,7 @@ def test_kpp_lockstep_equals_sequential_restarts(monkeypatch, mixed):
 def test_host_solvers_under_sanitizers(tmp_path):
     """munkres.cpp, munkres_sparse.cpp and transport.cpp compiled for the host with clang's AddressSanitizer + UndefinedBehaviorSanitizer
     and driven by tests/sanitize_host.cpp: random assignment problems against brute force, sparse = dense on vote-shaped matrices,
-    transport labels inside their bounds - and no sanitizer report (cluster_utils.py:234-493, clip_lang_util.py:167-178,
+    transport labels inside their bounds, the threaded batch solver = the single solves (also under ThreadSanitizer) - and no sanitizer report (cluster_utils.py:234-493, clip_lang_util.py:167-178,
     sskm_constrained.py:277-356).  The GPU sanitizers are not available on this pool; the host code is what can be covered."""
     import shutil
     import subprocess
@@ -426,6 +426,16 @@ def test_host_solvers_under_sanitizers(tmp_path):
     subprocess.run(cmd, check=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
+    # the same driver under ThreadSanitizer: scd_transport_solve_batch runs its problems on host threads (round 5)
+    exe_t = str(tmp_path / "sanitize_host_tsan")
+    cmd_t = [c for c in cmd if not c.startswith("-fsanitize=") and c != "-fno-sanitize-recover=undefined"]
+    cmd_t[cmd_t.index(exe)] = exe_t
+    cmd_t.insert(1, "-fsanitize=thread")
+    subprocess.run(cmd_t, check=True, timeout=600)
+    r = subprocess.run([exe_t], capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in r.stderr and "0 failures" not in r.stdout:      # (a kernel that refuses TSan's address-space layout)
+        pytest.skip("ThreadSanitizer cannot run here: " + r.stderr.strip().splitlines()[0])
+    assert r.returncode == 0 and "0 failures" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
 
 
 def test_double_double_add_of_the_sharded_sumsq():
