@@ -180,7 +180,12 @@ int scd_kmeans_lloyd_step_delta(scd_handle h, const float* X_u, const void* prep
  * Caller-owned device rings: lab_ring int32 [3][n_cat] (iteration i's labels in slot i % 3; labels_lab = the n_cat - n_u labelled
  * rows' labels, NULL when there are none), C_ring float [3][k,d], stats_ring double [2][5].  Outputs: best_labels int32 [n_cat] and
  * best_C [k,d] on the device (valid in stream order), result_host (HOST double [4]) = {least inertia, iterations done, iterations
- * with the incremental M-step, iterations launched}.  Returns when the last iteration's statistics have arrived. */
+ * with the incremental M-step, iterations launched}.  Returns when the last iteration's statistics have arrived.
+ * An iteration whose M-step leaves a cluster without rows ends the restart the way the reference's loop does (:140-160, :192-214: that
+ * centre is NaN, `torch.min` then yields NaN at the first NaN column for every row, so no later iteration is ever the best or ends the
+ * loop): the best of the iterations so far is kept - its centres carry NaN rows if it is that iteration - and "iterations done" is
+ * max_iter.  The one configuration in which the reference's loop can recover (exactly one cluster without labelled rows) is the
+ * caller's to route elsewhere (scd_amd/kmeans.py does). */
 int scd_kmeans_lloyd_run(scd_handle h, const float* X_u, const void* prep_u, int64_t n_u, const void* X16_cat, int64_t n_cat, int d,
                          int k, const int32_t* labels_lab, int32_t* lab_ring, int32_t* labels_prev, const float* C_start,
                          float* C_ring, double* sums, int64_t* counts, const double* sums_lab, const int64_t* counts_lab,

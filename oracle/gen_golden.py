@@ -194,6 +194,35 @@ def gen_kmeans():
     np.savez_compressed(os.path.join(OUT, "kmeans_sskm.npz"), **out)
 
 
+def gen_kmeans16():
+    """The reference's K_Means (gcd copy) on inputs that are EXACT in fp16 - what an fp16 encoder hands the product path, the condition
+    under which it runs the MFMA filters, the lock-step restarts and the incremental M-step - at the CLIP and DINO feature widths."""
+    import methods.clustering.faster_mix_k_means_pytorch as sskm
+    out = {}
+    for tag, n, d, k, seed, n_init in [("h", 6000, 512, 30, 5, 4), ("i", 4000, 768, 12, 6, 3)]:
+        x, y, mask_lab = _blob_case(n, d, k, seed)
+        x = x.astype(np.float16).astype(np.float32)
+        l, u = torch.from_numpy(x[mask_lab]), torch.from_numpy(x[~mask_lab])
+        lt = torch.from_numpy(y[mask_lab])
+        km = sskm.K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=n_init,
+                          random_state=seed, n_jobs=None, pairwise_batch_size=1024)
+        km.fit_mix(u, l, lt)
+        out["%s_shape" % tag] = np.array([n, d, k, seed])        # inputs = fp16(synth.blob_case(n, d, k, seed))
+        out["%s_cfg" % tag] = np.array([k, 10, n_init, seed])
+        out["%s_labels" % tag] = km.labels_.numpy()
+        out["%s_centers" % tag] = km.cluster_centers_.numpy()
+        out["%s_inertia" % tag] = np.array(float(km.inertia_))
+        out["%s_n_iter" % tag] = np.array(int(km.n_iter_))
+        km2 = sskm.K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=2,
+                           random_state=seed + 1, n_jobs=None, pairwise_batch_size=512)
+        km2.fit(u)
+        out["%s_fit_labels" % tag] = km2.labels_.numpy()
+        out["%s_fit_centers" % tag] = km2.cluster_centers_.numpy()
+        out["%s_fit_inertia" % tag] = np.array(float(km2.inertia_))
+        print("kmeans16", tag, "inertia", float(km.inertia_), "n_iter", int(km.n_iter_), "fit", float(km2.inertia_))
+    np.savez_compressed(os.path.join(OUT, "kmeans_f16.npz"), **out)
+
+
 def gen_sklearn_kmeans():
     """sklearn.cluster.KMeans as the reference calls it for --cluster KM (main_unsup.py:362), pinned the way SURVEY.md 8c says:
     this container's scikit-learn with explicit init, n_init=1, algorithm='lloyd', so that only the Lloyd arithmetic is compared."""
@@ -622,10 +651,10 @@ def main():
         sys.exit(2)
     os.makedirs(OUT, exist_ok=True)
     install_stubs(NxMinCostFlow)
-    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "kinit", "constrained", "naming", "topk16", "encoders"]
+    which = sys.argv[1:] or ["munkres", "acc", "kmeans", "sklearn", "kinit", "constrained", "naming", "topk16", "kmeans16", "encoders"]
     for w in which:
         dict(munkres=gen_munkres, acc=gen_acc_v2, kmeans=gen_kmeans, sklearn=gen_sklearn_kmeans, kinit=gen_sklearn_kinit, constrained=gen_constrained,
-             naming=gen_naming, topk16=gen_topk16, encoders=gen_encoders)[w]()
+             naming=gen_naming, topk16=gen_topk16, kmeans16=gen_kmeans16, encoders=gen_encoders)[w]()
 
 
 if __name__ == "__main__":

@@ -202,6 +202,15 @@ class K_Means:
 
     # E-step on the unlabelled rows -> (labels int64, float32 inertia contribution)
     def assign(self, x, centers):
+        # A NaN centre (a cluster the previous M-step left empty: the mean of no rows, faster_mix...:147-150, :199-203): the
+        # reference's `torch.min(dist, dim=1)` (:140, :192) propagates NaN - every row's minimum is NaN, found at the FIRST NaN
+        # column - so every row goes to the lowest-numbered empty cluster and the iteration's inertia is NaN: it is never the
+        # best one, its NaN centre shift never ends the loop, and (unless exactly one cluster can be empty at all) every later
+        # iteration is the same.  The restart keeps the best of the iterations up to the one that emptied a cluster and reports
+        # max_iterations.  (The E-step OPERATION below keeps NaN centres out of the argmin; this is the LOOP's semantics.)
+        nan_rows = np.isnan(np.asarray(centers, dtype=F64)).any(axis=1)
+        if nan_rows.any():
+            return np.full(len(x), int(np.argmax(nan_rows)), dtype=np.int64), F32(np.nan)
         # inertia contribution = float32(sum of the float64 row minima); the reference sums the float32
         # minima in float32 (faster_mix...:193) - both are within 1e-7 of each other
         lab, _, d = estep(x, centers)

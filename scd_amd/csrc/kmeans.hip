@@ -3294,7 +3294,7 @@ struct LloydShared {
 struct LloydRestart {
     scd_handle h; int32_t* lab_ring; int32_t* labels_prev; const float* C_start; float* C_ring; double* sums; int64_t* counts;
     double* stats_ring; int32_t* best_labels; float* best_C; double* result_host; void* ws_e; void* ws_m; hipStream_t st;
-    bool have_best = false, best_in_ring = false, active = true;
+    bool have_best = false, best_in_ring = false, active = true, died = false;
     int best_it = -1;
     float best = 0.f;
     double refined_seen = -1., changed_seen = -1., changed_prev = -1.;      // counts of the iterations the host has seen last (-1: none yet)
@@ -3397,13 +3397,19 @@ static int lr_settle(LloydRestart& r, const LloydShared& S, int i, bool* converg
         r.best_it = i;
         r.best_in_ring = true;
     }
-    *converged = host[2] < S.tol;
+    // An M-step that left a cluster empty ends the restart (faster_mix_k_means_pytorch.py:140-160, 192-214): the reference's centre of that
+    // cluster is NaN, `torch.min` then returns NaN at the first NaN column for EVERY row, so every later iteration has a NaN inertia (never
+    // the best) and a NaN shift (never below the tolerance) - the restart runs to max_iterations and keeps the best of the iterations up
+    // to this one.  (Callers route the one configuration in which such a loop can recover - exactly one cluster without labelled rows -
+    // to the Python-driven loop.)  The iteration launched on speculation is dropped, as after convergence.
+    if (host[5] > 0.0) r.died = true;
+    *converged = host[2] < S.tol || r.died;
     return SCD_OK;
 }
 static int lr_end(LloydRestart& r, const LloydShared& S) {
     if (r.best_in_ring) { const int rc0 = lr_save_best(r, S); if (rc0) return rc0; }
     r.result_host[0] = (double)r.best;
-    r.result_host[1] = (double)r.n_done;
+    r.result_host[1] = (double)(r.died ? S.max_iter : r.n_done);      // (the reference's dead loop runs on to max_iterations)
     r.result_host[2] = (double)r.delta_steps;
     r.result_host[3] = (double)r.launched;
     return SCD_OK;

@@ -177,6 +177,7 @@ class KMeansEngine:
         if max_iterations < 1:
             raise ValueError("max_iterations must be >= 1 (got %r)" % (max_iterations,))
         self.stats = {"estep_calls": 0, "refined_rows": 0}
+        self._one_novel = False      # fit_mix with exactly one cluster without labelled rows (see _lloyd_pipelined)
 
     # ------------------------------------------------------------------ helpers
     def _be(self):
@@ -400,11 +401,26 @@ class KMeansEngine:
         dd = self._dist()
         if not self.constrained and cat.is_cuda:
             return self._lloyd_pipelined(data_u, cat, cat16, labels, l_num, centers, bufs)
+        return self._lloyd_sequential(data_u, cat, labels, l_num, centers, cat16)
+
+    def _lloyd_sequential(self, data_u, cat, labels, l_num, centers, cat16=None):
+        """One iteration at a time, the host reading every iteration's statistics: the constrained engine, host backends, and the loop
+        that follows the reference through an EMPTIED cluster step by step.  The reference's centre of a cluster without rows is NaN
+        (the mean of no rows, faster_mix_k_means_pytorch.py:147-150, :199-203) and its `torch.min(dist, dim=1)` (:140, :192) then returns
+        NaN at the first NaN column for every row: all unlabelled rows go to the lowest-numbered empty cluster, the iteration's inertia
+        is NaN (never the best), its centre shift NaN (never below the tolerance)."""
+        be = self._be()
+        dd = self._dist()
         best = (None, None, None)
         it = 0
+        dead = -1                                    # lowest-numbered cluster the previous M-step left empty
         for it in range(self.max_iterations):
             old = centers
-            u_lab, u_inertia = self._assign(data_u, old, it)
+            if dead >= 0 and not self.constrained:
+                u_lab = torch.full((len(cat) - l_num,), dead, dtype=labels.dtype, device=labels.device)
+                u_inertia = np.float32("nan")
+            else:
+                u_lab, u_inertia = self._assign(data_u, old, it)
             labels[l_num:] = u_lab.to(labels.dtype)
             lab32 = labels.to(torch.int32).contiguous()
             sums, counts, inertia2 = be.mstep(cat, lab32, old, self.k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, self.k, l_num)
@@ -416,11 +432,16 @@ class KMeansEngine:
                 counts = packed[kd:kd + self.k].round().to(torch.int64)
                 inertia2 = packed[kd + self.k:]
             centers, shift = be.finalize(sums, counts, old, data_u)
-            host = torch.cat([inertia2, shift.reshape(1)]).cpu().numpy()          # the only per-iteration D2H
+            empty = counts == 0
+            first_empty = torch.where(empty.any(), empty.to(torch.int64).argmax(), torch.full((), -1, dtype=torch.int64, device=counts.device))
+            host = torch.cat([inertia2, shift.reshape(1), first_empty.reshape(1).to(inertia2.dtype)]).cpu().numpy()   # the only per-iteration D2H
             ui = np.float32(host[1]) if u_inertia is None else np.float32(u_inertia)
             inertia = np.float32(ui + np.float32(host[0]))
+            if dead >= 0 and not self.constrained:
+                inertia = np.float32("nan")
             if best[1] is None or inertia < best[1]:
                 best = (labels.clone(), inertia, centers.clone())
+            dead = int(host[3])
             if host[2] < self.tolerance:
                 break
         return best[0], best[1], best[2], it + 1
@@ -443,6 +464,11 @@ class KMeansEngine:
         # without a process group the three calls of an iteration go out as ONE (scd_kmeans_lloyd_step): the Python call overhead
         # of an iteration (185 us) otherwise exceeds its device time (105 us)
         fused = None
+        if self._one_novel:
+            # exactly one cluster without labelled rows: the one configuration in which the reference's loop can RECOVER from an emptied
+            # cluster (every row goes to it for one iteration, after which no centre is NaN any more).  Unreachable in practice - its seed
+            # is a row that stays with it - and followed step by step rather than built into the fast loops
+            return self._lloyd_sequential(data_u, cat, labels, l_num, centers, cat16)
         if (dd is not None and bufs is not None and getattr(bufs, "inc", False) and getattr(bufs, "dd", None) is not None
                 and os.environ.get("SCD_LLOYD_RUN", "1") != "0"):
             # a row shard whose ranks ALL qualify for the exact incremental M-step: the loop below behind one C call per restart
@@ -471,6 +497,7 @@ class KMeansEngine:
         # one-block-per-CU tail takes ~100 us for a few thousand rows where the refine launch takes 20.  The cue is the count the
         # host has seen last (iteration i - 2 when launching iteration i: the host runs one iteration behind the device)
         refined_seen = [None]
+        died = [False]
         # the incremental M-step (LloydBuffers.step_delta) pays while few labels move; same cue, the count of iteration i - 2
         changed_seen = [None, None]        # [seen last, the one before]
         n_u = data_u.n if hasattr(data_u, "n") else len(cat) - l_num
@@ -485,6 +512,11 @@ class KMeansEngine:
             inertia = np.float32(np.float32(host[1]) + np.float32(host[0]))
             if best[1] is None or inertia < best[1]:
                 best = (p[1], inertia, p[2].clone() if fused is not None else p[2])
+            if np.isnan(host[2]):
+                # a NaN shift = a NaN centre = a cluster this iteration's M-step left empty: the reference's loop is dead from here on
+                # (_lloyd_sequential's account; it runs on to max_iterations without ever improving or converging)
+                died[0] = True
+                return True
             return bool(host[2] < self.tolerance)
 
         for it in range(self.max_iterations):
@@ -533,6 +565,8 @@ class KMeansEngine:
         if pending is not None:
             n_done = pending[0] + 1
             settle(pending)
+        if died[0]:
+            n_done = self.max_iterations
         return best[0].to(labels.dtype), best[1], best[2], n_done
 
     # ------------------------------------------------------------------ reference API
@@ -585,7 +619,7 @@ class KMeansEngine:
         per = inits(rs) if inits is not None else [{} for _ in range(self.n_init)]
         bufs = kw.get("bufs")
         dd = self._dist()
-        if (inits is not None and len(per) > 1 and not self.constrained and bufs is not None and getattr(bufs, "inc", False)
+        if (inits is not None and len(per) > 1 and not self.constrained and not self._one_novel and bufs is not None and getattr(bufs, "inc", False)
                 and hasattr(bufs, "run_multi") and (dd is None or getattr(bufs, "dd", None) is not None)
                 and os.environ.get("SCD_LLOYD_RUN", "1") != "0" and os.environ.get("SCD_LLOYD_LOCKSTEP", "1") != "0"):
             # the restarts' Lloyd loops in lock-step behind ONE call (scd_kmeans_lloyd_run_multi): iteration i of every restart still running
@@ -627,6 +661,7 @@ class KMeansEngine:
                 self.n_iter_ = n_iters
 
     def fit(self, X):
+        self._one_novel = False
         self._agree_shards(X)
         data = self._be().prepare(X)
         per = self._per_fit(data, data.x)
@@ -640,6 +675,10 @@ class KMeansEngine:
     def fit_mix(self, u_feats, l_feats, l_targets):
         self._agree_shards(u_feats)
         data = self._be().prepare(u_feats)
+        classes = torch.unique(torch.as_tensor(l_targets).to(data.x.device))
+        if self._dist() is not None:                 # the labelled rows are sharded too: the class set is the union (as in _class_means)
+            classes = torch.unique(self._dist().allgather_cat(classes)[0])
+        self._one_novel = not self.constrained and self.k - int(classes.numel()) == 1
         l = l_feats.to(device=data.x.device, dtype=torch.float32).contiguous()
         cat = torch.cat((l, data.x)).contiguous()
         per = self._per_fit(data, cat)

@@ -483,32 +483,49 @@ def test_lloyd_step_full_size_properties(ops):
 
 
 # ----------------------------------------------------------------------------------------------- k-means end to end
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "h", "i"])
 def test_sskm_matches_reference_golden(ops, golden, tag):
+    """The reference's own K_Means runs (faster_mix_k_means_pytorch.py:91-275, gcd copy): "a".."c" on float32 blobs, "h" / "i" (round
+    5) on the same construction rounded to fp16 at the CLIP / DINO widths - the production regime: exact fp16 copy, MFMA filters for the
+    seeding and the E-step, the restarts' Lloyd loops in lock-step, the incremental exact M-step.  Labels EQUAL the reference's."""
     from scd_amd.gcd.methods.clustering.faster_mix_k_means_pytorch import K_Means
-    g = golden("kmeans_sskm.npz")
+    from test_oracle_golden import kmeans_golden_case
+    g, x, y, mask_lab, n_init = kmeans_golden_case(golden, tag)
     n, d, k, seed = g[tag + "_shape"].tolist()
-    x, y, mask_lab = synth.blob_case(n, d, k, seed)
     u, l, lt = dev(x[~mask_lab]), dev(x[mask_lab]), dev(y[mask_lab])
-    km = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=3, random_state=seed, n_jobs=None,
+    km = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=n_init, random_state=seed, n_jobs=None,
                  pairwise_batch_size=1024)
     km.fit_mix(u, l, lt)
+    if tag in ("h", "i"):
+        assert km.stats.get("lockstep_fits", 0) >= 1, km.stats      # the fp16-exact regime did take the lock-step C loop
     assert km.labels_.dtype == torch.int64 and km.labels_.is_cuda
     assert np.array_equal(km.labels_.cpu().numpy(), g[tag + "_labels"])             # the reference's own labels
-    assert np.allclose(km.cluster_centers_.cpu().numpy(), g[tag + "_centers"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(km.cluster_centers_.cpu().numpy(), g[tag + "_centers"], rtol=1e-5, atol=1e-6, equal_nan=True)
     assert abs(float(km.inertia_) - float(g[tag + "_inertia"])) <= 1e-5 * float(g[tag + "_inertia"])
     assert km.n_iter_ == int(g[tag + "_n_iter"])
     # and bit-for-bit against the oracle (same float64 decision semantics)
-    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=3, random_state=seed)
+    okm = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=n_init, random_state=seed)
     okm.fit_mix(x[~mask_lab], x[mask_lab], y[mask_lab])
     assert np.array_equal(km.labels_.cpu().numpy(), okm.labels_)
-    assert np.array_equal(km.cluster_centers_.cpu().numpy(), okm.cluster_centers_)
+    assert np.array_equal(km.cluster_centers_.cpu().numpy(), okm.cluster_centers_, equal_nan=True)
     assert float(km.inertia_) == float(okm.inertia_)
+    # plain fit.  In "h" and "i" the winning restart comes out of an iteration whose M-step left clusters EMPTY: the reference's centres of
+    # those are NaN, its torch.min then sends every row to the first of them with a NaN inertia, and the restart keeps the best of the
+    # iterations up to that one while it runs on to max_iterations - labels, NaN centre rows and n_iter_ are the reference's
     km2 = K_Means(k=k, tolerance=1e-4, max_iterations=10, init="k-means++", n_init=2, random_state=seed + 1,
                   pairwise_batch_size=512)
     km2.fit(u)
     assert np.array_equal(km2.labels_.cpu().numpy(), g[tag + "_fit_labels"])
+    assert np.allclose(km2.cluster_centers_.cpu().numpy(), g[tag + "_fit_centers"], rtol=1e-5, atol=1e-6, equal_nan=True)
     assert abs(float(km2.inertia_) - float(g[tag + "_fit_inertia"])) <= 1e-5 * float(g[tag + "_fit_inertia"])
+    okm2 = ko.K_Means(k=k, tolerance=1e-4, max_iterations=10, n_init=2, random_state=seed + 1)
+    okm2.fit(x[~mask_lab])
+    assert np.array_equal(km2.labels_.cpu().numpy(), okm2.labels_) and km2.n_iter_ == okm2.n_iter_
+    assert np.array_equal(km2.cluster_centers_.cpu().numpy(), okm2.cluster_centers_, equal_nan=True)
+    if tag == "h":      # the restart that emptied two clusters in its second iteration still wins with that iteration
+        assert bool(np.isnan(g[tag + "_fit_centers"]).any()) and km2.n_iter_ == 10
+    if tag == "i":      # the restart that died loses to the one that converged (this build's earlier rule - a NaN centre simply never
+        assert not np.isnan(g[tag + "_fit_centers"]).any() and km2.n_iter_ == 3      # wins a row - let it run on and win with 1393.6)
 
 
 def _record_transport(monkeypatch):
@@ -1193,7 +1210,7 @@ def test_sklearn_kmeans_lloyd_matches_sklearn(ops, golden, tag):
     assert km.labels_.dtype == np.int32 and np.array_equal(km.labels_, g[tag + "_labels"])
     assert km.n_iter_ == int(g[tag + "_n_iter"])
     assert abs(km.inertia_ - float(g[tag + "_inertia"])) <= 1e-5 * float(g[tag + "_inertia"])
-    assert np.allclose(km.cluster_centers_, g[tag + "_centers"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(km.cluster_centers_, g[tag + "_centers"], rtol=1e-5, atol=1e-6, equal_nan=True)
     olab, oin, ocent, oit = ko.sklearn_lloyd(x, g[tag + "_init"])
     assert np.array_equal(km.labels_, olab) and np.array_equal(km.cluster_centers_, ocent) and km.n_iter_ == oit
 
@@ -2062,13 +2079,17 @@ def test_c4_shape_sskm_k1000(ops):
         assert torch.equal(seq, lock[j])
 
 
-@pytest.mark.parametrize("n,d,k,labelled", [(20000, 512, 40, True), (30000, 768, 100, False), (6000, 64, 7, True)])
-def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch):
+@pytest.mark.parametrize("n,d,k,labelled,blobs", [(20000, 512, 40, True, 40), (30000, 768, 100, False, 100), (16000, 768, 60, False, 100),
+                                                  (6000, 64, 7, True, 7)])
+def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, blobs, monkeypatch):
     """On fp16-exact rows the float64 cluster sums are exact, so updating them with the rows whose label changed
     (scd_kmeans_lloyd_step_delta) must give the SAME centres, labels, float32 inertia and iteration count as a fresh M-step per
-    iteration - and both equal the float64 oracle's run (faster_mix_k_means_pytorch.py:187-214)."""
+    iteration - and both equal the float64 oracle's run (faster_mix_k_means_pytorch.py:187-214).
+    The 30,000 x 768 case (k = the number of blobs, no labelled rows) is the one in which EVERY restart empties a cluster within its first
+    iterations: every loop variant must end such a restart where the reference's NaN arithmetic does (:140-160), keeping the best of
+    the iterations so far and reporting max_iterations - before any incremental step has run."""
     from scd_amd.kmeans import KMeansEngine
-    x, y, _ = synth.clustered_features(n, d, k, seed=61, center_seed=62, noise=0.8)
+    x, y, _ = synth.clustered_features(n, d, blobs, seed=61, center_seed=62, noise=0.8)
     x = x.astype(np.float16).astype(np.float32)
     mask = (y < k // 2) & (np.random.RandomState(7).rand(n) < 0.5) if labelled else np.zeros(n, dtype=bool)
     res = {}
@@ -2092,7 +2113,10 @@ def test_incremental_mstep_is_bit_identical(ops, n, d, k, labelled, monkeypatch)
         lockstep = st.pop("lockstep_fits", 0)
         assert lockstep == (1 if mode in ("1", "streams", "nomerge") else 0)
         res[mode] = (km.labels_.cpu().numpy(), km.cluster_centers_.cpu().numpy(), float(km.inertia_), km.n_iter_, st)
-    assert res["1"][4].get("delta_steps", 0) > 0 and res["0"][4].get("delta_steps", 0) == 0
+    dying = (n, k, labelled) == (30000, 100, False)
+    assert (res["1"][4].get("delta_steps", 0) > 0) == (not dying) and res["0"][4].get("delta_steps", 0) == 0
+    if dying:
+        assert res["1"][3] == 10 and bool(np.isnan(res["1"][1]).any()) and res["1"][4]["estep_calls"] <= 3 * 4
     # (an empty cluster's centre is NaN in the reference and here: equal_nan)
     assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1], equal_nan=True)
     assert res["1"][2] == res["0"][2] and res["1"][3] == res["0"][3]
