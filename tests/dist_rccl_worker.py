@@ -81,6 +81,20 @@ def main():
     assert shd.stats.get("sharded_runs", 0) == 2
     assert np.array_equal(shd.labels_.cpu().numpy(), one.labels_.cpu().numpy()[su]) and torch.equal(shd.cluster_centers_, one.cluster_centers_)
     assert float(shd.inertia_) == float(one.inertia_) and shd.n_iter_ == one.n_iter_, (float(shd.inertia_), float(one.inertia_), shd.n_iter_, one.n_iter_)
+    # a restart that EMPTIES clusters (the unlabelled rows of tests/golden/kmeans_f16.npz case "h": its second restart does so in its second
+    # iteration and still wins): the reference's NaN arithmetic ends it there (faster_mix_k_means_pytorch.py:140-160) - the ranks take that
+    # decision from the exchanged counts, stop together, keep the NaN centre rows and report max_iterations, as the single-rank fit
+    xh, yh, mh = synth.blob_case(6000, 512, 30, 5)
+    uh = xh.astype(np.float16).astype(np.float32)[~mh]
+    sh = shard(len(uh), rank, world)
+    one = KMeansEngine(k=30, max_iterations=10, n_init=2, random_state=6)
+    one.fit(T(uh))
+    shd = KMeansEngine(k=30, max_iterations=10, n_init=2, random_state=6, group=grp)
+    shd.fit(T(uh[sh]))
+    assert bool(torch.isnan(one.cluster_centers_).any()) and one.n_iter_ == 10, "the case no longer empties a cluster"
+    assert np.array_equal(shd.labels_.cpu().numpy(), one.labels_.cpu().numpy()[sh]), "emptied clusters: sharded labels differ"
+    assert np.array_equal(shd.cluster_centers_.cpu().numpy(), one.cluster_centers_.cpu().numpy(), equal_nan=True)
+    assert float(shd.inertia_) == float(one.inertia_) and shd.n_iter_ == one.n_iter_ == 10
     # restarts that converge at DIFFERENT iterations (a loose tolerance, eight restarts over the library's four streams): the running
     # restarts move up in the densely packed exchange buffer when one drops out - round 5 found a stream race there (a restart packed into a
     # region another stream's finalize was still reading; the ranks then disagreed about who was still running and the collective sizes
