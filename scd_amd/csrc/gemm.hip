@@ -804,6 +804,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_DMA(BASE, P, SLOTLDS, PART, MOD)                                                                      \
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD                        \
                  ::"s"(SLOTLDS), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16), "n"((PART) + (P) * 1024) : "memory", "scc")
+#ifndef W4_RES_NT
+#define W4_RES_NT 0      // experiment: the residual rows of proj / fc2 (read once, private to the tile) fetched non-temporally
+#endif
+#if W4_RES_NT
+#define W4_RLOAD(P) __builtin_nontemporal_load((const half8*)(P))
+#else
+#define W4_RLOAD(P) (*(const half8*)(P))
+#endif
 #ifndef W4_A_NT_LN1
 #define W4_A_NT_LN1 0    // experiment: non-temporal activation fills in the LayerNorm-folded variants only (QKV, fc1: K = 768, A read once per n-group)
 #endif
@@ -1004,7 +1012,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     {                                                                                                            \
         if (HAS_RES) {                                                                                           \
             _Pragma("unroll") for (int e = 0; e < RD - 1; ++e) _Pragma("unroll") for (int p = 0; p < 4; ++p) rq[e][p] = \
-                *(const half8*)(Rt + (size_t)((e * 16 + p * 4) * N) + lane_el);                                  \
+                W4_RLOAD(Rt + (size_t)((e * 16 + p * 4) * N) + lane_el);                                       \
         }                                                                                                        \
         if (HAS_BIAS && W4_ABL_PRE) {                                                                            \
             _Pragma("unroll") for (int tn = 0; tn < 8; ++tn) { bq[tn][0] = 0.f; bq[tn][1] = 0.f; bq[tn][2] = 0.f; bq[tn][3] = 0.f; sq[tn] = bq[tn]; } \
@@ -1159,7 +1167,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                 if (HAS_RES && tm < 8 && tm + RD - 1 < 8) {
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        rq[(tm + RD - 1) % RD][p] = *(const half8*)(Rt + (size_t)(((tm + RD - 1) * 16 + p * 4) * N) + lane_el);
+                        rq[(tm + RD - 1) % RD][p] = W4_RLOAD(Rt + (size_t)(((tm + RD - 1) * 16 + p * 4) * N) + lane_el);
                 }
                 if (tm < 8) {
 #pragma unroll
