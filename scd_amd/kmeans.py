@@ -397,8 +397,6 @@ class KMeansEngine:
 
     def _lloyd(self, data_u, cat, labels, l_num, centers, cat16=None, bufs=None):
         """Iterations shared by fit_once / fit_mix_once (sskm_constrained.py:110-138)."""
-        be = self._be()
-        dd = self._dist()
         if not self.constrained and cat.is_cuda:
             return self._lloyd_pipelined(data_u, cat, cat16, labels, l_num, centers, bufs)
         return self._lloyd_sequential(data_u, cat, labels, l_num, centers, cat16)
