@@ -502,12 +502,20 @@ def gen_topk16():
     (main_unsup.py:568-614, main_ptsup.py:588-676) on inputs that are EXACT in fp16 - what the HIP path is given - at the product
     kernel's shape class (d = 512, three batches of 1024 with a ragged last one).  Only the outputs are stored; the tests rebuild the
     inputs from the same seeds (oracle/synth.py)."""
+    out = ref_topk_votes_f16(2100, 512, 25, 1500, (41, 42, 43, 44, 45))
+    np.savez_compressed(os.path.join(OUT, "topk_f16.npz"), **out)
+    print("topk_f16.npz written")
+
+
+def ref_topk_votes_f16(n, d, k, v, seeds, noise=0.9, jitter=0.5):
+    """The reference's top-k blocks and vote loops on fp16-exact synthetic inputs (gen_topk16; tools/ref_fuzz_naming.py runs it over many
+    seeds against the oracle)."""
     import clip_lang_util as clu
     from oracle import synth
-    n, d, k, v = 2100, 512, 25, 1500
-    x, y, cent = synth.clustered_features(n, d, k, seed=41, center_seed=42, noise=0.9)
-    w = synth.vocabulary(v, d, cent, seed=43, jitter=0.5, dtype=np.float32)
-    perm, mask_lab = synth.labelled_split(y, k, prop=0.5, seed=44)
+    s0, s1, s2, s3, s4 = seeds
+    x, y, cent = synth.clustered_features(n, d, k, seed=s0, center_seed=s1, noise=noise)
+    w = synth.vocabulary(v, d, cent, seed=s2, jitter=jitter, dtype=np.float32)
+    perm, mask_lab = synth.labelled_split(y, k, prop=0.5, seed=s3)
     x, y = x[perm], y[perm]
     x16, w16 = x.astype(np.float16), w.astype(np.float16)
     xt, wt = torch.from_numpy(x16.astype(np.float32)), torch.from_numpy(w16.astype(np.float32))
@@ -517,11 +525,11 @@ def gen_topk16():
     exec(ref_lines("main_unsup.py", 504, 531), ns)
     ns2 = dict(ns)
     exec(ref_lines("main_ptsup.py", 526, 545), ns2)
-    out = dict(shape=np.array([n, d, k, v]), seeds=np.array([41, 42, 43, 44]),
+    out = dict(shape=np.array([n, d, k, v]), seeds=np.array([s0, s1, s2, s3]),
                idx_unsup=ns["name_idx_top5"].numpy(), val_unsup=ns["name_logits_top5"].numpy(),
                idx_ptsup=ns2["name_idx_top5"].numpy(), val_ptsup=ns2["name_logits_top5"].numpy())
     # unsupervised vote loop from imperfect initial clusters
-    rs = np.random.RandomState(45)
+    rs = np.random.RandomState(s4)
     u_preds0 = np.where(rs.rand(n) < 0.8, (y * 7 + 2) % k, rs.randint(0, k, size=n))
     trace = []
     src = ref_lines("main_unsup.py", 568, 614) + "    _trace(voted_unique_name_idx, ind, cand_names, u_preds)\n"
@@ -561,8 +569,7 @@ def gen_topk16():
         out["vp_voted_%d" % i], out["vp_ind_%d" % i], out["vp_cand_%d" % i] = vo, ind, cand
         out["vp_preds_%d" % i], out["vp_unlab_%d" % i] = up, uc
     print("ptsup vote loop iterations:", len(trace2))
-    np.savez_compressed(os.path.join(OUT, "topk_f16.npz"), **out)
-    print("topk_f16.npz written")
+    return out
 
 
 def gen_encoders():
