@@ -14,9 +14,54 @@
 #include "gemm.h"
 #include <stdlib.h>
 
+// Exact (erf) GELU, nn.GELU of the DINO / GCD tower (gcd/models/vision_transformer.py:48-64), branch-free and in QuickGELU's shape:
+//   x Phi(x) = x / (1 + exp(-L(x))),   L = logit Phi = log(Phi(x) / Phi(-x)) ~ x (c0 + c1 x^2 + ... + c6 x^12)
+// L is odd, smooth and grows like x^2 / 2; the coefficients are the weighted minimax fit (linear program on |x| <= 9, weight
+// d gelu / d L = x Phi (1 - Phi)) whose polynomial is monotone, so nothing is clamped: beyond the fitted range the sigmoid saturates
+// faster than Phi does and the error stays below |x| Phi(-|x|) < 1e-8.  One v_exp_f32 and one v_rcp_f32 per value like QuickGELU plus
+// seven packed fmas per PAIR; in fp32 arithmetic max |error| 6.0e-7 over [-12, 12], within 2 fp16 ulps of the correctly rounded value
+// everywhere (0.5 x (1 + erff(x / sqrt 2)), torch's own form, is also 2: it cancels in the negative tail).  libdevice's erff is two
+// divergent branches (|z| < 1, >= 1), ~36 VALU instructions per value for a wave that holds both sides: round 6 measured the fc1
+// launch of the DINO tower with it (docs/design/round6.md).  SCD_GELU_K* = -c * log2(e) (the exponent goes to v_exp_f32 = 2^x).
+#define SCD_GELU_K0 (-2.30220745f)
+#define SCD_GELU_K1 (-0.104839488f)
+#define SCD_GELU_K2 (9.69095658e-05f)
+#define SCD_GELU_K3 (0.000158966471f)
+#define SCD_GELU_K4 (-1.14071321e-05f)
+#define SCD_GELU_K5 (3.83554556e-07f)
+#define SCD_GELU_K6 (-5.212611e-09f)
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float s = x * x;
+    float p = fmaf(s, SCD_GELU_K6, SCD_GELU_K5);
+    p = fmaf(p, s, SCD_GELU_K4);
+    p = fmaf(p, s, SCD_GELU_K3);
+    p = fmaf(p, s, SCD_GELU_K2);
+    p = fmaf(p, s, SCD_GELU_K1);
+    p = fmaf(p, s, SCD_GELU_K0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
+typedef float float2p __attribute__((ext_vector_type(2)));
+// the same arithmetic on a register pair (packed-fp32 multiplies / fmas; the fmas contract exactly as fmaf does above)
+__device__ __forceinline__ float2p gelu_erf_pair(float2p x) {
+#define SCD_P2(c) ((float2p){c, c})
+    const float2p s = x * x;
+    float2p p = __builtin_elementwise_fma(s, SCD_P2(SCD_GELU_K6), SCD_P2(SCD_GELU_K5));
+    p = __builtin_elementwise_fma(p, s, SCD_P2(SCD_GELU_K4));
+    p = __builtin_elementwise_fma(p, s, SCD_P2(SCD_GELU_K3));
+    p = __builtin_elementwise_fma(p, s, SCD_P2(SCD_GELU_K2));
+    p = __builtin_elementwise_fma(p, s, SCD_P2(SCD_GELU_K1));
+    p = __builtin_elementwise_fma(p, s, SCD_P2(SCD_GELU_K0));
+    float2p e = x * p;
+    e.x = __builtin_amdgcn_exp2f(e.x); e.y = __builtin_amdgcn_exp2f(e.y);
+    e += SCD_P2(1.0f);
+    e.x = __builtin_amdgcn_rcpf(e.x); e.y = __builtin_amdgcn_rcpf(e.y);
+    return x * e;
+#undef SCD_P2
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == SCD_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
-    if (act == SCD_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == SCD_ACT_GELU) return gelu_erf(x);
     return x;
 }
 
@@ -1101,9 +1146,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
                             e01.x = __builtin_amdgcn_rcpf(e01.x); e01.y = __builtin_amdgcn_rcpf(e01.y);
                             e23.x = __builtin_amdgcn_rcpf(e23.x); e23.y = __builtin_amdgcn_rcpf(e23.y);
                             v01 *= e01; v23 *= e23;
-                        } else if (ACT != SCD_ACT_NONE) {
-                            v01.x = act_apply(v01.x, ACT); v01.y = act_apply(v01.y, ACT);
-                            v23.x = act_apply(v23.x, ACT); v23.y = act_apply(v23.y, ACT);
+                        } else if (ACT == SCD_ACT_GELU) {
+                            v01 = gelu_erf_pair(v01); v23 = gelu_erf_pair(v23);
                         }
                         const half2v h01 = __builtin_convertvector(v01, half2v), h23 = __builtin_convertvector(v23, half2v);
                         const half4 o = {h01.x, h01.y, h23.x, h23.y};

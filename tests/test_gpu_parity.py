@@ -65,6 +65,32 @@ def test_gemm_matches_fp32(ops, m, n, k, variant):
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err     # fp16 output rounding
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (128, 128, 128)])
+def test_gelu_epilogue_within_two_fp16_ulps_of_erf(ops, m, n, k):
+    # the exact-GELU epilogue on its own: W = I, so the accumulator IS the fp16 input; every fp16 value of [-12, 12] (and the
+    # specials around it) goes through and is compared with erf-GELU evaluated in float64 and rounded once.  256-tile (four-wave
+    # kernel, value pairs) and 128-tile (scalar form) kernels.  nn.GELU: gcd/models/vision_transformer.py:48-64.
+    from scipy.special import erfc
+    vals = np.arange(-(1 << 15), 1 << 15, dtype=np.int32).astype(np.int16).view(np.float16)
+    vals = vals[np.isfinite(vals) & (np.abs(vals.astype(np.float32)) <= 12.0)]
+    per = m * k
+    eye = torch.eye(k)[:n] if n <= k else torch.cat([torch.eye(k), torch.zeros(n - k, k)])
+    worst = 0
+    for lo in range(0, len(vals), per):
+        chunk = np.zeros(per, dtype=np.float16)
+        part = vals[lo:lo + per]
+        chunk[:len(part)] = part
+        a = torch.from_numpy(chunk.reshape(m, k)).cuda()
+        c = ops.gemm_f16(a, eye.half().cuda(), torch.zeros(n).cuda(), None, 2).cpu().numpy()[:, :min(n, k)]
+        x = chunk.reshape(m, k)[:, :min(n, k)].astype(np.float64)
+        ref = np.where(x >= 0, x - 0.5 * x * erfc(x / np.sqrt(2.0)), 0.5 * x * erfc(-x / np.sqrt(2.0))).astype(np.float16)
+        d = np.abs(c.view(np.int16).astype(np.int64) - ref.view(np.int16).astype(np.int64))
+        d[(c == 0) & (ref == 0)] = 0            # -0 against +0
+        worst = max(worst, int(d.max()))
+        assert np.abs(c.astype(np.float64) - x * 0.5 * erfc(-x / np.sqrt(2.0))).max() <= 5e-4 * 12    # absolute: fp16 rounding only
+    assert worst <= 2, worst
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (768, 512, 192), (2560, 1280, 320), (256, 2304, 64), (5120, 256, 1024), (1792, 768, 768)])
 @pytest.mark.parametrize("variant", ["plain", "bias_qgelu", "bias_res"])
 def test_gemm_four_wave_edge_shapes(ops, m, n, k, variant):
