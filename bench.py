@@ -606,6 +606,7 @@ def main():
             line["config"]["cluster"] = "ConSSKM"
             line["consskm"] = {"fit_ms_per_step": line["stage_ms_per_step"].get("kmeans"), "transport_solves_per_fit": km.stats.get("transport_solves"),
                                "host_threads": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+                               "phase_ms_last_fit": km.stats.get("phase_ms"),       # SCD_CONSSKM_PROFILE=1 only (a device sync per iteration)
                                "cluster_sizes_min_max": [int(np.bincount(out["labels"][int(mask_lab.sum()):], minlength=n_cls).min()),
                                                          int(np.bincount(out["labels"][int(mask_lab.sum()):], minlength=n_cls).max())],
                                "note": "the restarts' flow problems of an iteration are solved on host threads (scd_transport_solve_batch); "

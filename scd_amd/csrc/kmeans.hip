@@ -1749,32 +1749,68 @@ extern "C" int scd_kmeans_min_update(scd_handle h, const float* X, const float* 
     return scd_kmeans_min_update_multi(h, X, c_new, n, d, 1, d2_inout, n, stream_);
 }
 
-// full [n,k] exact distances: each wave keeps 4 rows in registers and sweeps the centres
-__global__ void __launch_bounds__(256) dist_kernel(const float* __restrict__ X, const float* __restrict__ C, long long n,
-                                                   int d, int k, int mode, float* out, int32_t* cost) {
+// full [n,k] exact distances (pairwise_distance, sskm_constrained.py:189-224; the ConSSKM cost matrix, :277-287): float64 difference
+// form, rounded once to float32.  A block takes 64 rows x 32 centres: the rows' values go through LDS transposed ([j][row], so a wave
+// reads one j of its 64 rows conflict-free), a lane owns one row and CG = 8 centres of its wave, the centres' values arrive through
+// scalar loads (wave-uniform addresses) - no cross-lane reduction anywhere.  Round 6: the one-wave-per-4-rows kernel it replaces spent
+// 661 us per 9,000 x 120 x 768 launch, most of it in the 6-step float64 butterflies behind every (row, centre) pair; 92 launches per
+// ConSSKM fit were 61 ms of the 149-ms fit (profiles/r06_bench_c3_kernel_stats.csv).
+template <int CG>
+__global__ void __launch_bounds__(256) dist_tile_kernel(const float* __restrict__ X, const float* __restrict__ C, long long n,
+                                                        int d, int k, int mode, float* __restrict__ out, int32_t* __restrict__ cost) {
+    __shared__ float xs[64][65];
     const int lane = threadIdx.x & 63;
-    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (row0 >= n) return;
-    for (int c = 0; c < k; ++c) {
-        const float* cc = C + (size_t)c * d;
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int j = lane; j < d; j += 64) {
-            const double cv = (double)cc[j];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int c0 = (int)blockIdx.y * (4 * CG) + wave * CG;
+    double acc[CG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long row = row0 + q < n ? row0 + q : n - 1;
-                const double a = (double)X[row * d + j] - cv;
-                s[q] = fma(a, a, s[q]);
+    for (int q = 0; q < CG; ++q) acc[q] = 0.0;
+    const float* cq[CG];
+#pragma unroll
+    for (int q = 0; q < CG; ++q) cq[q] = C + (size_t)(c0 + q < k ? c0 + q : k - 1) * d;
+    // staging: thread -> (j = tid % 64, rows tid / 64 + 4 i): coalesced along j in HBM, stride-65 (conflict-free) in LDS
+    const int sj = threadIdx.x & 63, sr = threadIdx.x >> 6;
+    const float* xrow[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xrow[i] = X + (row0 + sr + 4 * i < n ? row0 + sr + 4 * i : n - 1) * d + sj;
+    for (int j0 = 0; j0 < d; j0 += 64) {
+        const int jn = d - j0 < 64 ? d - j0 : 64;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[sj][sr + 4 * i] = sj < jn ? xrow[i][j0] : 0.f;
+        __syncthreads();
+        if (c0 >= k) continue;
+        if (jn == 64) {
+#pragma unroll 8
+            for (int jj = 0; jj < 64; ++jj) {
+                const double xv = (double)xs[jj][lane];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const double a = xv - (double)cq[q][j0 + jj];
+                    acc[q] = fma(a, a, acc[q]);
+                }
+            }
+        } else {
+            for (int jj = 0; jj < jn; ++jj) {
+                const double xv = (double)xs[jj][lane];
+#pragma unroll
+                for (int q = 0; q < CG; ++q) {
+                    const double a = xv - (double)cq[q][j0 + jj];
+                    acc[q] = fma(a, a, acc[q]);
+                }
             }
         }
+    }
+    const long long row = row0 + lane;
+    if (row < n) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double t = wave_sum_f64(s[q]);
-            if (lane == 0 && row0 + q < n) {
-                const float d2 = (float)t;
+        for (int q = 0; q < CG; ++q) {
+            if (c0 + q < k) {
+                const float d2 = (float)acc[q];
                 const float rt = sqrtf(d2);           // correctly rounded
-                out[(row0 + q) * k + c] = mode ? rt : d2;
-                if (cost) cost[(row0 + q) * k + c] = (int32_t)rintf(rt * 1000.0f);
+                out[row * k + c0 + q] = mode ? rt : d2;
+                if (cost) cost[row * k + c0 + q] = (int32_t)rintf(rt * 1000.0f);
             }
         }
     }
@@ -1784,7 +1820,9 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
                                int32_t* cost_out, void* stream_) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_dist");
     SCD_REQUIRE(h && X && C && out && n > 0 && d > 0 && k > 0, "scd_kmeans_dist: bad arguments");
-    dist_kernel<<<(unsigned)scd_cdiv(n, 16), 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
+    SCD_REQUIRE(scd_cdiv(n, 64) < (1ll << 31) && scd_cdiv(k, 32) < 65536, "scd_kmeans_dist: n = %lld, k = %d exceed the launch grid", (long long)n, k);
+    const dim3 grid((unsigned)scd_cdiv(n, 64), (unsigned)scd_cdiv(k, 32));
+    dist_tile_kernel<8><<<grid, 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }

@@ -18,50 +18,140 @@
 // The number of searches is the total imbalance of the nearest-centre assignment (tens at the reference's 50 / 1000 bounds on 9,000
 // points) instead of one per point.  The total cost is THE optimum (unique); the labels are one optimum - they need not be OR-Tools'
 // on integer cost ties.  Deterministic: lowest index wins every tie (nearest centre, cheapest member, next node of the search).
+// Round 6: the same sequence of decisions, laid out for the host's vector units (a solve at 9,000 x 120: 12-14 ms -> ~2 ms on one core).
+// The k x k table holds int32 differences when every cost is below 2^30 (always, for round(1000 * distance)); a point's row update, the
+// rebuild of a row from its member list, the nearest-centre scan and the relax / select loops of the dense Dijkstra are branch-free loops
+// over k that the compiler vectorises (AVX2 / AVX-512 clones picked at load time, the plain build of the same source otherwise: integer
+// arithmetic, so every clone computes the same numbers).  A centre that loses a member rebuilds its whole row instead of searching the
+// affected columns one at a time: the table is a pure function of the member sets (minimum difference, lowest point index among equals),
+// so the values are the ones the column searches produced.
 #include "common.h"
 #include <vector>
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <exception>
+#include <string>
+
+// hipcc parses host code in the device pass as well; function multiversioning exists for the host target only.  Under ThreadSanitizer
+// the clones are off: their load-time resolvers run before the sanitizer's runtime is up (tests/test_cpu_abi_and_host.py builds that way)
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define SCD_NO_CLONES 1
+#endif
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__) || defined(SCD_NO_CLONES)
+#define SCD_HOST_SIMD
+#else
+#define SCD_HOST_SIMD __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+
+// the 64-bit loops over k run in vectors of 8 with no interleaving (the default, 4 x 8 lanes, leaves k = 120 a scalar remainder of 24);
+// the 32-bit row updates measured faster as the compiler lays them out by itself
+#define SCD_LOOP8 _Pragma("clang loop vectorize_width(8) interleave_count(1)")
 
 namespace {
 
+constexpr int64_t INF64 = INT64_MAX / 4;
+
+template <class T> struct Lim;
+template <> struct Lim<int32_t> { static constexpr int32_t INF = INT32_MAX; };
+template <> struct Lim<int64_t> { static constexpr int64_t INF = INF64; };
+
+// Selection key of a reached, unsettled node: (distance << 20) | node, so that ONE min-reduction finds the nearest node and the lowest
+// index among equals; KEY_NONE for settled / unreached nodes.  Used when no distance can reach 2^42 (transport_solve_one checks).
+constexpr int KEY_BITS = 20;
+constexpr int64_t KEY_NONE = INT64_MAX;
+static inline int64_t pack_key(int64_t d, int v) { return (int64_t)(((uint64_t)d << KEY_BITS) | (uint64_t)v); }
+SCD_HOST_SIMD int64_t min_key(const int64_t* __restrict__ key, int nn) {
+    int64_t best = KEY_NONE;
+    SCD_LOOP8
+    for (int v = 0; v < nn; ++v) best = key[v] < best ? key[v] : best;
+    return best;
+}
+
+// (multiversioned functions cannot be templates: the two table types are overloads stamped out by a macro)
+// row_add: row `r` / `rp` of centre a takes in member p (cost row c): r[b] = min over members of c[b] - c[a], rp[b] the lowest member
+// attaining it.  relax_row: Dijkstra, leaving a settled centre u: dist[v] = min(dist[v], du + r[v] - pi[v]) for the centres not yet
+// settled (reduced cost r[v] + pi[u] - pi[v] >= 0); returns the smallest selection key of the centres after the update (the next
+// node to settle, up to G's own key: one pass per settled node).
+#define SCD_ROW_FUNCS(T)                                                                                                                   \
+    SCD_HOST_SIMD void row_add(T* __restrict__ r, int32_t* __restrict__ rp, const int32_t* __restrict__ c, int a, int32_t p, int k) {      \
+        const T ca = c[a];                                                                                                                 \
+        for (int b = 0; b < k; ++b) {                                                                                                      \
+            const T dlt = (T)c[b] - ca;                                                                                                    \
+            const bool m = (dlt < r[b]) | ((dlt == r[b]) & (p < rp[b]));                                                                   \
+            r[b] = m ? dlt : r[b];                                                                                                         \
+            rp[b] = m ? p : rp[b];                                                                                                         \
+        }                                                                                                                                  \
+    }                                                                                                                                      \
+    SCD_HOST_SIMD int64_t relax_row(int64_t* __restrict__ dist, int64_t* __restrict__ key, int32_t* __restrict__ pred,                     \
+                                    const T* __restrict__ r, const int64_t* __restrict__ pi, const int8_t* __restrict__ done, int64_t du,  \
+                                    int u, int k) {                                                                                        \
+        int64_t best = KEY_NONE;                                                                                                           \
+        SCD_LOOP8                                                                                                                          \
+        for (int v = 0; v < k; ++v) {                                                                                                      \
+            const int64_t nd = du + (int64_t)r[v] - pi[v];                                                                                 \
+            const bool m = (nd < dist[v]) & (done[v] == 0) & (v != u);                                                                     \
+            const int64_t kv = m ? pack_key(nd, v) : key[v];                                                                               \
+            dist[v] = m ? nd : dist[v];                                                                                                    \
+            key[v] = kv;                                                                                                                   \
+            pred[v] = m ? u : pred[v];                                                                                                     \
+            best = kv < best ? kv : best;                                                                                                  \
+        }                                                                                                                                  \
+        return best;                                                                                                                       \
+    }
+SCD_ROW_FUNCS(int32_t)
+SCD_ROW_FUNCS(int64_t)
+#undef SCD_ROW_FUNCS
+// nearest centre of one point, lowest index among ties; also the row's largest cost
+SCD_HOST_SIMD int row_argmin(const int32_t* __restrict__ c, int k, int32_t* mx_io) {
+    int32_t mn = c[0], mx = c[0];
+    for (int b = 1; b < k; ++b) { mn = c[b] < mn ? c[b] : mn; mx = c[b] > mx ? c[b] : mx; }
+    if (mx > *mx_io) *mx_io = mx;
+    int a = 0;
+    while (c[a] != mn) ++a;
+    return a;
+}
+// the unsettled node with the smallest finite distance, lowest index among equals (-1: none)
+SCD_HOST_SIMD int select_min(const int64_t* __restrict__ dist, const int8_t* __restrict__ done, int nn) {
+    int64_t best = INF64;
+    for (int v = 0; v < nn; ++v) {
+        const int64_t dv = done[v] ? INF64 : dist[v];
+        best = dv < best ? dv : best;
+    }
+    if (best >= INF64) return -1;
+    int u = 0;
+    while (done[u] || dist[u] != best) ++u;
+    return u;
+}
+
+template <class T>
 struct Solver {
     const int32_t* cost;
     int64_t n;
-    int k, lo, hi;
+    int k;
     std::vector<int32_t> assign;            // point -> centre
     std::vector<int32_t> pos;               // point -> position in its centre's member list
     std::vector<std::vector<int32_t>> mem;  // centre -> members
-    std::vector<int64_t> best;              // [k][k]: min over members p of a of c[p][b] - c[p][a]   (INF: a is empty)
+    std::vector<T> best;                    // [k][k]: min over members p of a of c[p][b] - c[p][a]   (INF: a is empty)
     std::vector<int32_t> bestp;             // the member attaining it (lowest index among ties)
-    static constexpr int64_t INF = INT64_MAX / 4;
 
-    void row_add(int a, int32_t p) {
-        const int32_t* c = cost + (int64_t)p * k;
-        int64_t* r = best.data() + (size_t)a * k;
+    void add(int a, int32_t p) { row_add(best.data() + (size_t)a * k, bestp.data() + (size_t)a * k, cost + (int64_t)p * k, a, p, k); }
+    // a member has left a (mem[a] no longer holds it): the row from the members that remain
+    void rebuild(int a) {
+        T* r = best.data() + (size_t)a * k;
         int32_t* rp = bestp.data() + (size_t)a * k;
-        const int64_t ca = c[a];
-        for (int b = 0; b < k; ++b) {
-            const int64_t dlt = (int64_t)c[b] - ca;
-            if (dlt < r[b] || (dlt == r[b] && p < rp[b])) { r[b] = dlt; rp[b] = p; }
-        }
-    }
-    // member p has left a (mem[a] no longer holds it): only the columns p was the cheapest member for are searched again
-    void row_remove(int a, int32_t p) {
-        int64_t* r = best.data() + (size_t)a * k;
-        int32_t* rp = bestp.data() + (size_t)a * k;
-        for (int b = 0; b < k; ++b) {
-            if (rp[b] != p) continue;
-            int64_t bd = INF;
-            int32_t bp = -1;
-            for (int32_t q : mem[a]) {
-                const int32_t* c = cost + (int64_t)q * k;
-                const int64_t dlt = (int64_t)c[b] - c[a];
-                if (dlt < bd || (dlt == bd && q < bp)) { bd = dlt; bp = q; }
+        for (int b = 0; b < k; ++b) { r[b] = Lim<T>::INF; rp[b] = -1; }
+        const auto& m = mem[a];
+        const size_t nm = m.size();
+        constexpr size_t AHEAD = 6;                                   // member rows sit at random places of the cost matrix
+        for (size_t i = 0; i < nm; ++i) {
+            if (i + AHEAD < nm) {
+                const char* nx = (const char*)(cost + (int64_t)m[i + AHEAD] * k);
+                for (int o = 0; o < k * 4; o += 64) __builtin_prefetch(nx + o);
             }
-            r[b] = bd;
-            rp[b] = bp;
+            row_add(r, rp, cost + (int64_t)m[i] * k, a, m[i], k);
         }
     }
     void attach(int32_t p, int a) {
@@ -79,32 +169,21 @@ struct Solver {
     }
 };
 
-}  // namespace
-
-static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
-                               int64_t* total_cost_out) {
-    SCD_REQUIRE(cost && labels_out && n > 0 && k > 0 && size_min >= 0 && size_max >= size_min,
-                "scd_transport_solve: bad arguments");
-    if ((int64_t)k * size_min > n || (int64_t)k * size_max < n) {
-        scd_set_error("There was an issue with the min cost flow input.");   // message of sskm_constrained.py:350
-        return SCD_EINFEASIBLE;
-    }
-    SCD_REQUIRE(n < INT32_MAX, "scd_transport_solve: more than 2^31 points");
-    Solver s;
-    s.cost = cost; s.n = n; s.k = k; s.lo = size_min; s.hi = size_max;
+// steps 1 and 2 on tables of type T; `a0` = every point's nearest centre (lowest index among ties)
+template <class T>
+int repair(const int32_t* cost, int64_t n, int k, int size_min, int size_max, const int32_t* a0, bool packed, int32_t* labels_out,
+           int64_t* total_cost_out) {
+    Solver<T> s;
+    s.cost = cost; s.n = n; s.k = k;
     s.assign.assign(n, -1);
     s.pos.assign(n, 0);
     s.mem.resize(k);
-    s.best.assign((size_t)k * k, Solver::INF);
+    s.best.assign((size_t)k * k, Lim<T>::INF);
     s.bestp.assign((size_t)k * k, -1);
-    // 1. nearest centre (lowest index among ties)
+    // 1. nearest centre
     for (int64_t p = 0; p < n; ++p) {
-        const int32_t* c = cost + p * k;
-        int a = 0;
-        for (int b = 1; b < k; ++b)
-            if (c[b] < c[a]) a = b;
-        s.attach((int32_t)p, a);
-        s.row_add(a, (int32_t)p);
+        s.attach((int32_t)p, a0[p]);
+        s.add(a0[p], (int32_t)p);
     }
     // 2. repair the balances.  Node k is G, the free sink.  cnt(a) = members of a.
     const int G = k;
@@ -115,9 +194,9 @@ static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_m
         if (cnt(a) < size_min) under += size_min - cnt(a);
         if (cnt(a) > size_max) over += cnt(a) - size_max;
     }
-    std::vector<int64_t> pi(nn, 0), dist(nn);
-    std::vector<int> pred(nn);
-    std::vector<char> done(nn);
+    std::vector<int64_t> pi(nn, 0), dist(nn), key(nn);
+    std::vector<int32_t> pred(nn);
+    std::vector<int8_t> done(nn);
     std::vector<int> path;
     std::vector<int32_t> movers;
     const int64_t max_aug = under + over + 8;
@@ -136,36 +215,42 @@ static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_m
                 if (cnt(a) > size_max) src = a;
         // deficit nodes: centres below size_min; G when over > under
         auto is_deficit = [&](int v) { return v == G ? over > under : cnt(v) < size_min; };
-        for (int v = 0; v < nn; ++v) { dist[v] = Solver::INF; pred[v] = -1; done[v] = 0; }
+        for (int v = 0; v < nn; ++v) { dist[v] = INF64; key[v] = KEY_NONE; pred[v] = -1; done[v] = 0; }
         dist[src] = 0;
+        key[src] = pack_key(0, src);
         int t = -1;
+        int64_t knext = src == G ? KEY_NONE : key[src];   // smallest key of the centres 0..k-1 when `fresh` (the last relax pass left it), else unknown
+        bool fresh = true;
         for (;;) {
-            int u = -1;
-            for (int v = 0; v < nn; ++v)
-                if (!done[v] && dist[v] < Solver::INF && (u < 0 || dist[v] < dist[u])) u = v;
+            int u;
+            if (packed) {
+                int64_t kmin = fresh ? knext : min_key(key.data(), k);
+                kmin = key[G] < kmin ? key[G] : kmin;
+                u = kmin == KEY_NONE ? -1 : (int)(kmin & ((1 << KEY_BITS) - 1));
+            } else {
+                u = select_min(dist.data(), done.data(), nn);
+            }
+            fresh = false;
             if (u < 0) break;
             done[u] = 1;
+            key[u] = KEY_NONE;
             if (u != src && is_deficit(u)) { t = u; break; }
             const int64_t du = dist[u] + pi[u];
             if (u == G) {
                 for (int v = 0; v < k; ++v)                       // G -> v: v gives up a unit it was free to hold
                     if (!done[v] && cnt(v) > size_min) {
                         const int64_t nd = du - pi[v];
-                        if (nd < dist[v]) { dist[v] = nd; pred[v] = G; }
+                        if (nd < dist[v]) { dist[v] = nd; key[v] = pack_key(nd, v); pred[v] = G; }
                     }
                 continue;
             }
             if (!done[G] && cnt(u) < size_max) {                  // u -> G: u keeps the unit it has just received
                 const int64_t nd = du - pi[G];
-                if (nd < dist[G]) { dist[G] = nd; pred[G] = u; }
+                if (nd < dist[G]) { dist[G] = nd; key[G] = pack_key(nd, G); pred[G] = u; }
             }
             if (cnt(u) == 0) continue;
-            const int64_t* r = s.best.data() + (size_t)u * k;
-            for (int v = 0; v < k; ++v) {
-                if (v == u || done[v]) continue;
-                const int64_t nd = du + r[v] - pi[v];             // reduced cost r[v] + pi[u] - pi[v] >= 0
-                if (nd < dist[v]) { dist[v] = nd; pred[v] = u; }
-            }
+            knext = relax_row(dist.data(), key.data(), pred.data(), s.best.data() + (size_t)u * k, pi.data(), done.data(), du, u, k);
+            fresh = true;
         }
         if (t < 0) {
             scd_set_error("There was an issue with the min cost flow input.");
@@ -194,17 +279,17 @@ static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_m
             s.detach(p);
             s.attach(p, b);
         }
-        // rows: a centre that lost a member searches the columns that member was cheapest for (its member list is final here: a
-        // member that arrived in the same augmentation is in it); every centre that gained a member takes it in
+        // rows: a centre that lost a member is rebuilt from its member list (final here: a member that arrived in the same
+        // augmentation is in it); a centre that only gained a member takes it in
         for (size_t i = 0; i + 1 < path.size(); ++i) {
             const int a = path[i], b = path[i + 1];
             if (a == G || b == G) continue;
-            s.row_remove(a, movers[i]);
+            s.rebuild(a);
         }
         for (size_t i = 0; i + 1 < path.size(); ++i) {
             const int a = path[i], b = path[i + 1];
             if (a == G || b == G) continue;
-            s.row_add(b, movers[i]);
+            s.add(b, movers[i]);
         }
         // the balances follow from the member counts (a centre's flow to G is min(cnt - size_min, size_max - size_min) by construction)
         under = over = 0;
@@ -227,44 +312,96 @@ static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_m
     return SCD_OK;
 }
 
+}  // namespace
+
+static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
+                               int64_t* total_cost_out) {
+    SCD_REQUIRE(cost && labels_out && n > 0 && k > 0 && size_min >= 0 && size_max >= size_min,
+                "scd_transport_solve: bad arguments");
+    if ((int64_t)k * size_min > n || (int64_t)k * size_max < n) {
+        scd_set_error("There was an issue with the min cost flow input.");   // message of sskm_constrained.py:350
+        return SCD_EINFEASIBLE;
+    }
+    SCD_REQUIRE(n < INT32_MAX, "scd_transport_solve: more than 2^31 points");
+    // nearest centres into labels_out (the repair reads them before it writes the final labels); the largest cost picks the table type
+    int32_t mx = 0, mn = 0;
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t* c = cost + p * k;
+        labels_out[p] = row_argmin(c, k, &mx);
+        if (c[labels_out[p]] < mn) mn = c[labels_out[p]];
+    }
+    std::vector<int32_t> a0(labels_out, labels_out + n);
+    // a search's distances are sums of at most k + 1 reduced costs, each below 2 (mx + 1) in magnitude: packed selection keys while
+    // that stays below 2^42
+    const bool small = mn >= 0 && mx < (1 << 30);
+    const bool packed = small && k + 1 < (1 << KEY_BITS) && (int64_t)(k + 2) * 2 * ((int64_t)mx + 1) < ((int64_t)1 << 42);
+    if (small) return repair<int32_t>(cost, n, k, size_min, size_max, a0.data(), packed, labels_out, total_cost_out);
+    return repair<int64_t>(cost, n, k, size_min, size_max, a0.data(), false, labels_out, total_cost_out);
+}
+
+// no exception crosses the C boundary or ends a worker thread (std::terminate): an allocation failure becomes a status
+static int transport_solve_guarded(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
+                                   int64_t* total_cost_out) {
+    try {
+        return transport_solve_one(cost, n, k, size_min, size_max, labels_out, total_cost_out);
+    } catch (const std::bad_alloc&) {
+        scd_set_error("scd_transport_solve: out of host memory (n = %lld, k = %d)", (long long)n, k);
+        return SCD_EINVAL;
+    } catch (const std::exception& e) {
+        scd_set_error("scd_transport_solve: %s", e.what());
+        return SCD_EINVAL;
+    }
+}
+
 extern "C" int scd_transport_solve(const int32_t* cost, int64_t n, int k, int size_min, int size_max, int32_t* labels_out,
                                    int64_t* total_cost_out) {
-    return transport_solve_one(cost, n, k, size_min, size_max, labels_out, total_cost_out);
+    return transport_solve_guarded(cost, n, k, size_min, size_max, labels_out, total_cost_out);
 }
 
 // `batch` independent problems of one shape (the ConSSKM E-steps of the restarts of one fit, sskm_constrained.py:165-176: the restarts
 // share nothing but X), solved on up to `threads` host threads.  Problem b reads cost + b * n * k and writes labels_out + b * n,
 // totals_out[b].  Each problem's result is what scd_transport_solve gives for it (one problem never spans threads), so the batch is
-// deterministic whatever the thread count.  Returns the status of the lowest-numbered problem that failed.
+// deterministic whatever the thread count.  Returns the status of the lowest-numbered problem that failed, with that problem's own
+// message (a worker's message lives in its thread: it is copied into a per-problem slot and restated on the calling thread).
 extern "C" int scd_transport_solve_batch(const int32_t* cost, int64_t n, int k, int batch, int size_min, int size_max,
                                          int32_t* labels_out, int64_t* totals_out, int threads) {
     SCD_REQUIRE(cost && labels_out && batch > 0 && n > 0 && k > 0, "scd_transport_solve_batch: bad arguments");
-    std::vector<int> rc((size_t)batch, SCD_OK);
-    auto one = [&](int b) {
-        int64_t tot = 0;
-        rc[b] = transport_solve_one(cost + (size_t)b * n * k, n, k, size_min, size_max, labels_out + (size_t)b * n, &tot);
-        if (totals_out) totals_out[b] = tot;
-    };
-    const int nt = std::max(1, std::min(threads, batch));
-    if (nt == 1) {
-        for (int b = 0; b < batch; ++b) one(b);
-    } else {
-        std::atomic<int> next(0);
-        auto work = [&]() {
-            for (int b = next.fetch_add(1); b < batch; b = next.fetch_add(1)) one(b);
+    try {
+        std::vector<int> rc((size_t)batch, SCD_OK);
+        std::vector<std::string> msg((size_t)batch);
+        auto one = [&](int b) {
+            int64_t tot = 0;
+            rc[b] = transport_solve_guarded(cost + (size_t)b * n * k, n, k, size_min, size_max, labels_out + (size_t)b * n, &tot);
+            if (rc[b] != SCD_OK) {
+                try { msg[b] = scd_last_error(); } catch (...) {}
+            }
+            if (totals_out) totals_out[b] = tot;
         };
-        std::vector<std::thread> pool;
-        pool.reserve(nt - 1);
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
-    }
-    for (int b = 0; b < batch; ++b)
-        if (rc[b] != SCD_OK) {
-            // the worker's message lives in ITS thread: restate it here
-            if (rc[b] == SCD_EINFEASIBLE) scd_set_error("There was an issue with the min cost flow input.");
-            else scd_set_error("scd_transport_solve_batch: problem %d failed (status %d)", b, rc[b]);
-            return rc[b];
+        const int nt = std::max(1, std::min(threads, batch));
+        if (nt == 1) {
+            for (int b = 0; b < batch; ++b) one(b);
+        } else {
+            std::atomic<int> next(0);
+            auto work = [&]() {
+                for (int b = next.fetch_add(1); b < batch; b = next.fetch_add(1)) one(b);
+            };
+            std::vector<std::thread> pool;
+            pool.reserve(nt - 1);
+            try {
+                for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+            } catch (...) {}                       // fewer threads than asked for: the ones that started (and this one) do the work
+            work();
+            for (auto& th : pool) th.join();
         }
-    return SCD_OK;
+        for (int b = 0; b < batch; ++b)
+            if (rc[b] != SCD_OK) {
+                if (batch > 1 && rc[b] != SCD_EINFEASIBLE) scd_set_error("scd_transport_solve_batch: problem %d: %s", b, msg[b].c_str());
+                else scd_set_error("%s", msg[b].empty() ? "There was an issue with the min cost flow input." : msg[b].c_str());
+                return rc[b];
+            }
+        return SCD_OK;
+    } catch (const std::exception& e) {
+        scd_set_error("scd_transport_solve_batch: %s", e.what());
+        return SCD_EINVAL;
+    }
 }

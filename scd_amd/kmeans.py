@@ -14,6 +14,8 @@ shard totals.  The compute backend is injectable (`backend=`) so that the collec
 gloo on CPU; the default and only product backend is scd_amd.ops (HIP).
 """
 import os
+import threading
+import time
 
 import numpy as np
 import torch
@@ -691,6 +693,41 @@ class KMeansEngine:
         self.cluster_centers_ = self.cluster_centers_.type_as(u_feats) if torch.is_floating_point(u_feats) else self.cluster_centers_
 
 
+_STAGING = {}            # (R, n_u, k) -> [host_cost, host_lab, in_use]: pinned staging of the lock-step ConSSKM fit, kept between fits
+_STAGING_LOCK = threading.Lock()
+_POOL = {}
+
+
+def _pinned_staging(R, n_u, k):
+    """Pinned host buffers for the restarts' cost matrices and labels.  Allocating 43 MB of pinned memory costs milliseconds per fit
+    (C3: ten restarts x 9,000 x 120 int32), so one set per shape is kept and handed to one fit at a time; a second fit of the same
+    shape running concurrently gets buffers of its own."""
+    key = (R, n_u, k)
+    with _STAGING_LOCK:
+        ent = _STAGING.get(key)
+        if ent is not None and not ent[2]:
+            ent[2] = True
+            return ent[0], ent[1], lambda: ent.__setitem__(2, False)
+    hc = torch.empty((R, n_u, k), dtype=torch.int32).pin_memory()
+    hl = torch.empty((R, n_u), dtype=torch.int32).pin_memory()
+    with _STAGING_LOCK:
+        if key not in _STAGING:
+            if len(_STAGING) >= 4:
+                _STAGING.clear()
+            ent = _STAGING[key] = [hc, hl, True]
+            return hc, hl, lambda: ent.__setitem__(2, False)
+    return hc, hl, lambda: None
+
+
+def _solver_pool(R):
+    """Host threads of the lock-step fit's flow problems (one per restart), created once per process."""
+    from concurrent.futures import ThreadPoolExecutor
+    p = _POOL.get("p")
+    if p is None or p._max_workers < R:
+        p = _POOL["p"] = ThreadPoolExecutor(max_workers=max(R, 1), thread_name_prefix="scd-transport")
+    return p
+
+
 class ConstrainedEngine(KMeansEngine):
     """sskm_constrained.K_Means: the E-step is the min-cost-flow assignment (:116, :226-274).
     The flow problem has global capacity constraints, so it does not shard: with `group` set the int32 costs are
@@ -782,34 +819,75 @@ class ConstrainedEngine(KMeansEngine):
         centers = [c for c in c_init]
         best = [(None, None, None)] * R
         active = list(range(R))
-        host_cost = torch.empty((R, n_u, k), dtype=torch.int32).pin_memory()
-        host_lab = torch.empty((R, n_u), dtype=torch.int32).pin_memory()
+        host_cost, host_lab, release = _pinned_staging(R, n_u, k)
         n_iters = [0] * R
+        prof = os.environ.get("SCD_CONSSKM_PROFILE", "0") == "1"     # phase wall times into self.stats (adds a device sync per iteration)
+        ph = self.stats.setdefault("phase_ms", {"cost_d2h": 0.0, "solve_wait": 0.0, "mstep": 0.0}) if prof else None
+        pool = _solver_pool(R)
+
+        def solve(a, ev):
+            # a host thread per running restart: waits for ITS cost matrix only (the other restarts' distance kernels and copies are
+            # still in flight), then solves; both the event wait and the C call release the GIL
+            ev.synchronize()
+            be.transport_batch(host_cost[a:a + 1].numpy(), self.size_min, self.size_max, labels_out=host_lab[a:a + 1].numpy())
+
+        try:
+            return self._lockstep_iterations(be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, active, n_iters, host_cost, host_lab,
+                                             pool, solve, prof, ph)
+        finally:
+            release()
+
+    def _lockstep_iterations(self, be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, active, n_iters, host_cost, host_lab, pool, solve,
+                             prof, ph):
+        R = len(centers)
         for it in range(self.max_iterations):
             a_n = len(active)
-            d_sqrts = []
+            d_sqrts, futs = [], []
+            t0 = time.perf_counter()
             for a, j in enumerate(active):
                 d_sqrt, cost = be.dist(data_u, centers[j], sqrt=True, with_cost=True)
                 host_cost[a].copy_(cost, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                futs.append(pool.submit(solve, a, ev))
                 d_sqrts.append(d_sqrt)
-            torch.cuda.current_stream(dev).synchronize()
-            be.transport_batch(host_cost[:a_n].numpy(), self.size_min, self.size_max, labels_out=host_lab[:a_n].numpy())
+            if prof:
+                torch.cuda.current_stream(dev).synchronize()
+            t1 = time.perf_counter()
             self.stats["transport_solves"] = self.stats.get("transport_solves", 0) + a_n
-            lab_dev = host_lab[:a_n].to(dev, non_blocking=True)
             stats, new_c = [], []
-            for a, j in enumerate(active):
-                u_lab = lab_dev[a]
-                # distances[:] = D[arange, labels] ** 2 in float32, inertia = sum (sskm_constrained.py:271-272)
-                picked = d_sqrts[a].gather(1, u_lab.to(torch.int64).reshape(-1, 1)).reshape(-1)
-                tot = be.sum_f32((picked * picked).contiguous())
-                labels[j][l_num:] = u_lab.to(torch.int64)
-                lab32 = labels[j].to(torch.int32).contiguous()
-                old = centers[j]
-                sums, counts, inertia2 = be.mstep(cat, lab32, old, k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, k, l_num)
-                c_new, shift = be.finalize(sums, counts, old, data_u)
-                new_c.append(c_new)
-                stats.append(torch.cat([inertia2.to(torch.float64), shift.reshape(1).to(torch.float64), tot.reshape(1).to(torch.float64)]))
+            wait_s = 0.0
+            try:
+                for a, j in enumerate(active):                   # restart order: restart a's M-step runs while the later solves finish
+                    tw = time.perf_counter()
+                    futs[a].result()                             # (a failed solve raises here, as the batch call did)
+                    wait_s += time.perf_counter() - tw
+                    u_lab = host_lab[a].to(dev, non_blocking=True)
+                    # distances[:] = D[arange, labels] ** 2 in float32, inertia = sum (sskm_constrained.py:271-272)
+                    picked = d_sqrts[a].gather(1, u_lab.to(torch.int64).reshape(-1, 1)).reshape(-1)
+                    tot = be.sum_f32((picked * picked).contiguous())
+                    labels[j][l_num:] = u_lab.to(torch.int64)
+                    lab32 = labels[j].to(torch.int32).contiguous()
+                    old = centers[j]
+                    sums, counts, inertia2 = be.mstep(cat, lab32, old, k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, k, l_num)
+                    c_new, shift = be.finalize(sums, counts, old, data_u)
+                    new_c.append(c_new)
+                    stats.append(torch.cat([inertia2.to(torch.float64), shift.reshape(1).to(torch.float64), tot.reshape(1).to(torch.float64)]))
+            except BaseException:
+                for f in futs:                                   # no solver may still be writing the staging buffers when they are released
+                    f.cancel()
+                for f in futs:
+                    if not f.cancelled():
+                        try:
+                            f.result()
+                        except BaseException:
+                            pass
+                raise
             host = torch.stack(stats).cpu().numpy()            # the iteration's only read-back: [A, 4]
+            if prof:
+                ph["cost_d2h"] += (t1 - t0) * 1e3
+                ph["solve_wait"] += wait_s * 1e3
+                ph["mstep"] += (time.perf_counter() - t1 - wait_s) * 1e3
             still = []
             for a, j in enumerate(active):
                 centers[j] = new_c[a]

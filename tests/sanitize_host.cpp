@@ -11,7 +11,8 @@
 #include <vector>
 #include "scd_hip.h"
 
-static char g_err[512];
+static thread_local char g_err[512];
+extern "C" const char* scd_last_error(void) { return g_err; }
 void scd_set_error(const char* fmt, ...) {      // api.cpp's definition lives beside the HIP entry points; the solvers only report through it
     va_list ap;
     va_start(ap, fmt);
@@ -89,6 +90,29 @@ int main() {
             ++cnt[lab[i]];
             t += cost[i * k + lab[i]];
         }
+        for (int c = 0; c < k; ++c) if (cnt[c] < smin || cnt[c] > smax) ++fails;
+        if (t != total) ++fails;
+        // the same problem with every cost moved up by 2^30 takes the 64-bit tables (and the unpacked node selection): the differences
+        // are the same, so the labels must be, and the total moves by n * 2^30
+        std::vector<int32_t> big(cost), lab2(n, -1);
+        for (auto& x : big) x += 1 << 30;
+        int64_t total2 = 0;
+        if (scd_transport_solve(big.data(), n, k, smin, smax, lab2.data(), &total2) != 0) { ++fails; continue; }
+        if (lab2 != lab || total2 != total + n * ((int64_t)1 << 30)) ++fails;
+    }
+    // wider problems (k past one vector of the row loops, many augmentations): bounds, total, and the batch = single solves
+    for (int trial = 0; trial < 6; ++trial) {
+        const int k = 17 + rnd() % 120;
+        const int64_t n = 6 * k + rnd() % 500;
+        const int smin = (int)(n / k) - 1, smax = (int)(n / k) + 2;
+        std::vector<int32_t> cost((size_t)n * k), lab(n, -1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int c = 0; c < k; ++c) cost[i * k + c] = 1000 + (c < k / 4 ? 0 : 3000) + rnd() % 2000;     // a few popular centres
+        int64_t total = 0;
+        if (scd_transport_solve(cost.data(), n, k, smin, smax, lab.data(), &total) != 0) { ++fails; continue; }
+        std::vector<int> cnt(k, 0);
+        int64_t t = 0;
+        for (int64_t i = 0; i < n; ++i) { ++cnt[lab[i]]; t += cost[i * k + lab[i]]; }
         for (int c = 0; c < k; ++c) if (cnt[c] < smin || cnt[c] > smax) ++fails;
         if (t != total) ++fails;
     }

@@ -31,5 +31,28 @@ for r in list(csv.DictReader(open(sys.argv[1])))[:12]:
 PY
     rm -rf $o
   done ;;
+c3_ab)     # bench.py --config c3 on the default library and the given builds, then once more with the ConSSKM phase profile
+  for lib in default "$@"; do
+    if [ $lib = default ]; then unset SCD_HIP_LIB; else export SCD_HIP_LIB=$R/scd_amd/lib/libscd_hip_$lib.so; fi
+    timeout -k 10 400 python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $out/c3_$lib.json 2> $out/c3.err || { tail -n 20 $out/c3.err; exit 1; }
+    python - <<PY
+import json
+d=json.load(open("$out/c3_$lib.json"))
+print("lib %-10s %9.1f images/s  stages %s  fit %s ms" % ("$lib", d["value"], d["stage_ms_per_step"], d["consskm"]["fit_ms_per_step"]))
+PY
+  done
+  unset SCD_HIP_LIB
+  SCD_CONSSKM_PROFILE=1 timeout -k 10 400 python bench.py --config c3 --steps 2 --warmup 1 --no-cpu-baseline > $out/c3_phases.json 2> $out/c3.err || { tail -n 20 $out/c3.err; exit 1; }
+  python -c "import json; d=json.load(open('$out/c3_phases.json')); print('phases of the last fit', d['consskm']['phase_ms_last_fit'], 'fit', d['consskm']['fit_ms_per_step'])" ;;
+c3_tests)
+  timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "transport or consskm or constrained or c3 or ptsup or dist" > $out/c3_tests.txt 2>&1; rc=$?
+  echo "[c3_tests] rc=$rc"; tail -n 3 $out/c3_tests.txt; [ $rc -eq 0 ] || { tail -n 40 $out/c3_tests.txt; exit 1; } ;;
+bench_prof)   # kernel stats of the TIMED region of `bench.py ARGS` (marker kernels): tools/gpu_r06.sh bench_prof TAG ARGS...
+  tag=$1; shift
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 500 rocprofv3 --kernel-trace -d $out/prof_$tag --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $out/prof_$tag.log 2>&1
+  rc=$?; echo "[rocprof bench $tag] rc=$rc"; if [ $rc -ne 0 ]; then tail -n 20 $out/prof_$tag.log; exit 1; fi
+  python3 $R/tools/trace_window_stats.py $out/prof_$tag $out/r06_bench_${tag}_kernel_stats.csv | cut -c1-170 | head -n 24
+  rm -rf $out/prof_$tag ;;
 *) echo "unknown step $step"; exit 2 ;;
 esac
