@@ -41,6 +41,17 @@ CONFIGS["c3"] = dict(images=12000, n_cluster=120,
                      workload="Stanford Dogs partially supervised (BASELINE configs[2]): 12,000 images (~3,000 labelled), GCD/DINO ViT-B/16 "
                               "+ CLIP ViT-B/16 encode, V=%d vocab raw top-5, ConSSKM k=120 size 50/1000 (10 restarts x 10 iters, "
                               "main_ptsup.py defaults) + partially supervised vote loop")
+# --config c1 = BASELINE configs[0]: CUB-200 unsupervised on CACHED features (5,994 rows, ~4,500 unlabelled; DINO 768-d for the clustering, CLIP
+# 512-d for the naming), V = 1,000 names, the shipped `--cluster KM`, K = 200: no encoder in the step - what the k-means / vote path costs
+# when it is the whole step.  --config c5 = BASELINE configs[4]: ImageNet-100 + a 100,000-name open vocabulary whose classifier is BUILT inside
+# the timed step (text tower over V x 80 prompts; N > 1: name shards + one all-gather) + textual-enhancement re-ranking.
+CONFIGS["c1"] = dict(images=5994, n_cluster=200, vocab=1000,
+                     workload="CUB-200 unsupervised on cached features (BASELINE configs[0]): 5,994 rows (~4,500 unlabelled), cached DINO 768-d + CLIP "
+                              "512-d features, V=%d vocab softmax top-3, sklearn-style KMeans (--cluster KM, n_init=10) k=200 + vote loop; no encoder")
+CONFIGS["c5"] = dict(images=IMAGES_PER_GPU, n_cluster=N_CLASSES, vocab=100000,
+                     workload="ImageNet-100 + open vocabulary (BASELINE configs[4]): text-tower build of the V=%d-name classifier (80 prompts per "
+                              "name, sharded over the ranks + all-gather) INSIDE the step + CLIP ViT-B/16 encode + textual-enhancement top-3 "
+                              "(100 * mean(f, t) @ W) + SSKM k=100 (10 restarts x 10 iters) + vote loop")
 PEAK_F16_TFLOPS = 2500.0       # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 2 * 17563453440        # CLIP ViT-B/16 visual tower
@@ -57,7 +68,7 @@ def parse():
     # 665*197 rows = 512 GEMM row tiles: every GEMM fills the 256 CUs exactly; six of those per launch (3,072 row tiles) amortise
     # the ramp-up / tail of the ~60 launches per batch: +1.5-1.9 % over 665 on the same box, features bit-identical (tools/bigbatch_check.py)
     p.add_argument("--batch", type=int, default=3990)
-    p.add_argument("--vocab", type=int, default=VOCAB)
+    p.add_argument("--vocab", type=int, default=None, help="names in the vocabulary (default = the config's: 21,000; c1 1,000; c5 100,000)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-only", action="store_true", help="print the cpu_baseline object and exit (no GPU work; how the main run obtains it)")
     p.add_argument("--cluster", choices=["SSKM", "KM"], default="SSKM",
@@ -66,8 +77,15 @@ def parse():
     a = p.parse_args()
     if a.cluster == "KM" and a.gpus > 1:
         p.error("--cluster KM is a single-process fit (as in the reference, main_unsup.py:362): use --gpus 1")
+    if a.config == "c5" and a.cluster != "SSKM":
+        p.error("--config c5 runs the SSKM path")
     if a.config == "c3" and (a.gpus > 1 or a.cluster != "SSKM"):
         p.error("--config c3 is the 1-GPU partially supervised path with its own clustering (ConSSKM): no --gpus / --cluster")
+    if a.config == "c1" and a.gpus > 1:
+        p.error("--config c1 is the 1-GPU cached-feature path (5,994 rows): --gpus 1")
+    if a.config == "c1" and a.cluster == "SSKM" and "--cluster" not in sys.argv:
+        a.cluster = "KM"                       # the shipped flag of scripts/evaluate_unsupervised.sh; --cluster SSKM still selects SSKM
+    a.vocab = a.vocab or CONFIGS[a.config].get("vocab", VOCAB)
     a.images = a.images or CONFIGS[a.config]["images"]
     a.n_cluster = a.n_cluster or CONFIGS[a.config]["n_cluster"]
     return a
@@ -245,10 +263,10 @@ def dominant_kernel_roofline(ms, launches, flop):
     # HBM-side traffic per launch cannot be read without the profiler: it is taken from this round's committed PMC passes
     # (profiles/r05_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/gpu_r05_final.sh)
     # at the default launch size (3,990 images = 786,432 rows); another --batch scales it by its rows per launch
-    traffic = None
+    traffic, pmf = None, ""
     try:
-        pmf = os.path.join(ROOT, "profiles", "r05_pmc_fc1.json")
-        with open(pmf if os.path.exists(pmf) else os.path.join(ROOT, "profiles", "r04_pmc_fc1.json")) as f:
+        pmf = next(p for p in (os.path.join(ROOT, "profiles", "r0%d_pmc_fc1.json" % r) for r in (6, 5, 4)) if os.path.exists(p))
+        with open(pmf) as f:
             pm = json.load(f)
         rows_per_launch = flop / max(launches, 1) / (2.0 * 3072 * 768)
         traffic = round(pm["traffic_bytes_per_launch"] * rows_per_launch / pm["rows"])
@@ -256,6 +274,7 @@ def dominant_kernel_roofline(ms, launches, flop):
         pass
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "replayed from %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command), scaled by rows per launch; not measured in this run" % os.path.basename(pmf) if traffic is not None else None,
             "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded> (ViT fc1, n=3072 k=768)", "launches": launches,
             "avg_launch_us": round(ms * 1e3 / max(launches, 1), 1)}
 
@@ -300,7 +319,8 @@ def secondary_rooflines(out, wt, dev, km_fit=False):
         _, ref = dat.estep(cen, return_refined=True)
         t = timeit(lambda: dat.estep(cen, expect_few=few))
         kern = "estep_rb_kernel" if (d == 512 and 128 < k <= 2048) else ("estep_stream_kernel" if k <= 128 else "estep_mfma_kernel")
-        name = "scd_kmeans_estep call (centre prep + %s + refine), N=%d D=%d K=%d, %s" % (kern, n, d, k, tag)
+        resident = "Infinity-Cache resident operand (%d MB <= 256 MB: repeated calls do not stream from HBM)" % (by >> 20) if by <= (256 << 20) else "operand streams from HBM"
+        name = "scd_kmeans_estep call (centre prep + %s + refine), N=%d D=%d K=%d, %s; %s" % (kern, n, d, k, tag, resident)
         if k > 300:            # with 16-bit MFMA operands the E-step is matrix-bound beyond K ~ 300
             fl_e = 2.0 * n * k * d
             return {"kernel": name, "bound": "mfma", "achieved": round(fl_e / t / 1e12, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
@@ -336,8 +356,8 @@ def secondary_rooflines(out, wt, dev, km_fit=False):
         late = np.array([smp[j] for j in range(len(smp)) if j % 10 >= 2]) if len(smp) == 30 else smp
         t = float(late.mean())
         res.append({"kernel": "estep_stream_kernel inside the Lloyd loop (HIP events around every launch of an SSKM fit, 3 restarts x 10 "
-                              "iterations; iterations >= 2 of a restart: %d launches), N=%d D=%d K=%d, clustered synthetic features"
-                              % (len(late), n, d, k),
+                              "iterations; iterations >= 2 of a restart: %d launches), N=%d D=%d K=%d, clustered synthetic features; %s"
+                              % (len(late), n, d, k, "Infinity-Cache resident operand" if by <= (256 << 20) else "operand streams from HBM"),
                     "bound": "hbm", "achieved": round(by / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(by / t / 8e12, 4),
                     "kernel_us": round(t * 1e6, 1), "kernel_us_median": round(float(np.median(late)) * 1e6, 1),
                     "kernel_us_all_launches": round(float(smp.mean()) * 1e6, 1),
@@ -462,6 +482,90 @@ def cpu_baseline_child():
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def main_c1(args, dev):
+    """BASELINE configs[0]: the cached-feature path (no encoder).  One JSON line; `roofline` is the E-step call of the fit's shape (the
+    path's HBM-bound kernel), `secondary_rooflines` carries the fit itself - the step is launch- and latency-bound, and says so."""
+    from scd_amd import ops, pipeline
+    n, k, v = args.images, args.n_cluster, args.vocab
+    g = torch.Generator(device=dev).manual_seed(2024)
+    y = torch.randint(0, k, (n,), generator=g, device=dev)
+    # cached "DINO" features: float32 [n, 768], L2-normalised rows around class centres (extract_feature + F.normalize, main_unsup.py:114-147)
+    cen = torch.nn.functional.normalize(torch.randn(k, 768, generator=g, device=dev), dim=-1)
+    xf = torch.nn.functional.normalize(cen[y] + (0.9 / 768 ** 0.5) * torch.randn(n, 768, generator=g, device=dev), dim=-1).contiguous()
+    # cached CLIP features fp16 [n, 512] around the planted prototypes; vocabulary: rows < K the (jittered) prototypes, the rest random names
+    proto = torch.nn.functional.normalize(torch.randn(k, 512, generator=g, device=dev), dim=-1)
+    cf = torch.nn.functional.normalize(proto[y] + (0.9 / 512 ** 0.5) * torch.randn(n, 512, generator=g, device=dev), dim=-1).to(torch.float16).contiguous()
+    w = torch.randn(v, 512, generator=g, device=dev)
+    w[:k] = proto + 0.05 * torch.randn(k, 512, generator=g, device=dev) / 512 ** 0.5
+    wt = ops.freeze_vocab(ops.l2norm_rows(w.contiguous()).to(torch.float16).contiguous())
+    nouns = ["name_%05d" % i for i in range(v)]
+    mask_lab = pipeline.labelled_split(y, k, seed=5)
+    l_targets = y[torch.as_tensor(mask_lab, device=dev)]
+    stage_ms = {}
+
+    def step(timed):
+        timers = [] if timed else None
+        out = pipeline.run_cached(xf, cf, mask_lab, wt, nouns, k, topk=3, num_common_vote=10, num_common_linear=2, timers=timers,
+                                  cluster=args.cluster, l_targets=l_targets)
+        if timed:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(timers[:-1], timers[1:]):
+                stage_ms[n1] = stage_ms.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+    for _ in range(args.warmup):
+        out = step(False)
+    torch.cuda.synchronize()
+    power = PowerSampler(dev.index or 0)
+    power.start()
+    ops.trace_mark(False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    ops.trace_mark(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    power = power.stop()
+    u_true = y.cpu().numpy()[~mask_lab]
+    name_hits = float(np.mean(np.array([int(nm.split("_")[1]) for nm in out["cand_names"]])[out["u_preds"]] == u_true))
+    # the E-step call on the fit's rows and final centres (HIP events, 50 calls): the HBM-bound kernel of this path
+    xu = out["u_feats"].contiguous()
+    cent = torch.as_tensor(out["kmeans"].cluster_centers_).to(dev).to(torch.float32).contiguous()
+    data = ops.KMeansData(xu)
+    for _ in range(5):
+        data.estep(cent)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        data.estep(cent)
+    e1.record()
+    torch.cuda.synchronize()
+    t_e = e0.elapsed_time(e1) * 1e-3 / 50
+    nu, d = xu.shape
+    dp = (d + 127) // 128 * 128
+    by = nu * dp * 2 + 4 * nu + ((k + 127) // 128 * 128) * dp * 2
+    sclk = (power or {}).get("sclk_mhz_median")
+    line = {"metric": "images/sec end-to-end (encode+sim+k-means) on 224^2 synth, 21k vocab", "value": round(n * args.steps / dt, 2), "unit": "images/sec",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": CONFIGS["c1"]["workload"] % v if args.cluster == "KM" else (CONFIGS["c1"]["workload"] % v).replace(
+                           "sklearn-style KMeans (--cluster KM, n_init=10)", "SSKM (10 restarts x 10 iters)"),
+                       "cluster": args.cluster, "images_per_gpu": n, "vocab": v, "n_cluster": k, "encode_batch": None,
+                       "weights": "none: cached features (synthetic, seeded)", "parallelism": "dp1"},
+            "stage_ms_per_step": {kk: round(vv / args.steps, 3) for kk, vv in stage_ms.items()}, "encode_tflops": None,
+            "vote_iters": out["vote_iters"], "synthetic_name_accuracy": round(name_hits, 4),
+            "roofline": {"bound": "hbm", "achieved": round(by / t_e / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / t_e / (PEAK_HBM_GBS * 1e9), 4),
+                         "traffic": None, "kernel": "scd_kmeans_estep call (centre prep + filter + refine), N=%d D=%d K=%d, this run's rows / final centres; "
+                                                    "Infinity-Cache resident operand (%.1f MB): a latency-bound launch, not a streaming one" % (nu, d, k, by / 2 ** 20),
+                         "launches": 50, "avg_launch_us": round(t_e * 1e6, 1),
+                         "note": "the c1 step is launch- and latency-bound (4,500 rows: every kernel is a few microseconds; the fit is %d k-means++ rounds and "
+                                 "Lloyd iterations driven from C): no kernel of it approaches a roofline, the stage times are the measurement" % k},
+            "board_power": power, "sclk_mhz_median": sclk, "encode_cycles_per_image": None,
+            "km_fit": {"n_iter_kept_start": int(getattr(out["kmeans"], "n_iter_", 0)), "fit_ms_per_step": round(stage_ms.get("kmeans", 0.0) / args.steps, 3)},
+            "secondary_rooflines": []}
+    line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_child()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -489,6 +593,8 @@ def main():
     import scd_amd.clip as clip
     from scd_amd import pipeline
     n_cls = args.n_cluster
+    if args.config == "c1":
+        return main_c1(args, dev)
     clip.allow_synthetic()          # random-init weights + hash tokenizer: there is no checkpoint offline (`data: synthetic`)
     model, _ = clip.load("ViT-B/16", device="cuda")
     images, y, base = pipeline.synthetic_images(args.images, n_cls, seed=rank, device=dev)
@@ -529,6 +635,29 @@ def main():
         wt[torch.as_tensor(syn_rows, device=dev)] = torch.nn.functional.normalize(syn, dim=-1).to(wt.dtype)
         lab_names = [nouns[name_row[c]] for c in range(n_cls // 2)]                       # the labelled classes' names are known (:597-603)
 
+    build_vocab, text_feats = None, None
+    if args.config == "c5":
+        # open vocabulary: the classifier of all V names is built by the text tower INSIDE every step (80 prompts per name, the reference's
+        # zeroshot_classifier call; N > 1: contiguous name shards per rank + one all-gather, clip_lang_util.zeroshot_classifier_sharded);
+        # the first K rows then take the planted prototypes so that the vote has true names to find.  Textual enhancement: per-image
+        # closed-set text features (the reference's `closed_text_feats`, loaded from disk there) = jittered class prototypes, resident
+        from scd_amd.local_utils import clip_lang_util as clu
+        protos = wt[:n_cls].clone()
+
+        def build_vocab():
+            if world > 1:
+                w = clu.zeroshot_classifier_sharded(nouns, clu.imagenet_templates, model, group, names_per_batch=256)
+            else:
+                w = clu.zeroshot_classifier(nouns, clu.imagenet_templates, model, names_per_batch=256)
+            wtb = _ops.transpose_f16(w)
+            wtb[:n_cls] = protos
+            return _ops.freeze_vocab(wtb)
+        gt = torch.Generator(device=dev).manual_seed(900 + rank)
+        text_feats = torch.nn.functional.normalize(protos.float()[y] + 0.5 * torch.randn((args.images, protos.shape[1]), generator=gt, device=dev)
+                                                   / protos.shape[1] ** 0.5, dim=-1).to(torch.float16).contiguous()
+    from scd_amd import ops as _ops
+    wt = _ops.freeze_vocab(wt)          # written for the last time above: the similarity filter's vocabulary norm once, not per call
+
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -545,7 +674,8 @@ def main():
                                      num_common_linear=2, size_min=50, size_max=1000, batch=args.batch, seed=i, timers=timers)
         else:
             out = pipeline.run(model, images, mask_lab, l_targets, wt, nouns, n_cls, topk=3, num_common_vote=10,
-                               num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers, cluster=args.cluster)
+                               num_common_linear=2, batch=args.batch, seed=i, group=group, timers=timers, cluster=args.cluster,
+                               build_vocab=build_vocab, text_feats=text_feats)
         if timed:
             torch.cuda.synchronize()
             for (n0, e0), (n1, e1) in zip(timers[:-1], timers[1:]):
@@ -556,10 +686,11 @@ def main():
         out = step(i, False)
     barrier()
     model.visual.enc.timing(True)
+    if args.config == "c5":
+        model._text.timing(True)        # the text tower's fc1 launches, bracketed by HIP events like the image tower's
     power = PowerSampler(local_rank) if rank == 0 else None       # a host thread reading sysfs: nothing enters the stream
     if power:
         power.start()
-    from scd_amd import ops as _ops
     _ops.trace_mark(False)              # an empty marker kernel in front of the timed steps and one behind them: a kernel trace of this
     t0 = time.perf_counter()            # command can be cut down to the timed region (tools/trace_window_stats.py); ~2 us each
     for i in range(args.steps):
@@ -601,6 +732,13 @@ def main():
             "roofline": roof,
             "board_power": power,
         }
+        # clock-normalised encode cost: boxes of this pool hold 1.69-1.88 GHz at the same 1,400-W cap, so images/s moves by +-3 % box to
+        # box with the same binary; shader cycles per image (median sclk over the timed steps x encode seconds / images) does not
+        sclk = (power or {}).get("sclk_mhz_median")
+        line["sclk_mhz_median"] = sclk
+        line["encode_cycles_per_image"] = round(sclk * 1e6 * enc_s / args.images) if (sclk and enc_s > 0) else None
+        if args.config == "c3":
+            line["encode_cycles_per_image_note"] = "two towers (DINO / GCD + CLIP) per image"
         if args.config == "c3":
             km = out["kmeans"]
             line["config"]["cluster"] = "ConSSKM"
@@ -613,7 +751,21 @@ def main():
                                        "the step's images/s counts each image once although two towers encode it"}
             line["secondary_rooflines"] = []
         else:
-            line["secondary_rooflines"] = secondary_rooflines(out, wt, dev, km_fit=(args.cluster == "KM"))
+            line["secondary_rooflines"] = secondary_rooflines(out, out.get("wt", wt), dev, km_fit=(args.cluster == "KM"))
+        if args.config == "c5":
+            # the text tower (row a4): GEMM FLOPs actually executed after the context trimming = 3 x its fc1 launches' FLOPs (per row and
+            # layer QKV 3 w^2 + proj w^2 + fc1 4 w^2 + fc2 4 w^2 multiply-adds, fc1 is a third; attention and the pooling not counted) over
+            # the "text_tower" stage's time (tokenisation on the host runs behind the device work and is inside it)
+            t_ms, t_n, t_fl = model._text.timing(False)
+            tt_s = stage_ms.get("text_tower", 0.0) / 1e3 / args.steps
+            prompts = len(nouns) * 80 // world
+            line["secondary_rooflines"].insert(0, {
+                "kernel": "CLIP text tower inside the step: zeroshot_classifier%s over %d names x 80 prompts per rank (trimmed context, four length groups per 256 names)"
+                          % ("_sharded + all-gather" if world > 1 else "", len(nouns) // world),
+                "bound": "mfma", "achieved": round(3.0 * t_fl / args.steps / max(tt_s, 1e-9) / 1e12, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(3.0 * t_fl / args.steps / max(tt_s, 1e-9) / (PEAK_F16_TFLOPS * 1e12), 4), "stage_ms": round(tt_s * 1e3, 1),
+                "prompts_per_s": round(prompts / max(tt_s, 1e-9)), "gemm_gflop_per_prompt_executed": round(3.0 * t_fl / args.steps / max(prompts, 1) / 1e9, 3),
+                "fc1_launches_per_step": t_n // max(args.steps, 1), "fc1_kernel_frac_of_peak": round(t_fl / max(t_ms, 1e-9) / 1e9 / PEAK_F16_TFLOPS, 4)})
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_child()
         print(json.dumps(line), flush=True)
     if world > 1:

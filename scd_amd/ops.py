@@ -109,23 +109,49 @@ def mean2_f16(a, b):
 
 
 # ----------------------------------------------------------------------------- similarity
-_vocab_norms = {}        # id(wt) -> (weakref, data_ptr, _version, shape, device tensor with max ||w||^2)
+_frozen_vocabs = {}      # id(wt) -> (weakref, data_ptr, _version, shape, norm tensor, stream pointer, event): ops.freeze_vocab
+
+
+def _vocab_norm_now(wt):
+    out = torch.empty(1, dtype=torch.int32, device=wt.device)
+    check(_L().scd_sim_vocab_norm(handle(), ptr(wt), wt.shape[0], wt.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+def freeze_vocab(wt):
+    """The caller's promise that the name-major fp16 vocabulary `wt` will not be written any more (by anybody: torch, a kernel of this
+    library writing through the raw pointer, another stream): its max ||w||^2 - the data-dependent part of the similarity filter's
+    error bound - is computed once, here, and every later sim_topk on the tensor reuses it.  Without the promise the norm is computed
+    per call (12 us beside a 2.7-ms call at C2): torch's `_version` does not see raw-pointer writes, and a stale, too small norm would
+    certify rows it must not.  `unfreeze_vocab` takes the promise back.  Returns wt."""
+    _need_cuda(wt)
+    assert wt.dtype == torch.float16 and wt.is_contiguous() and wt.dim() == 2
+    ev = torch.cuda.Event()
+    norm = _vocab_norm_now(wt)
+    ev.record()
+    if len(_frozen_vocabs) > 64:
+        for kk in [kk for kk, e in _frozen_vocabs.items() if e[0]() is None]:
+            del _frozen_vocabs[kk]
+    _frozen_vocabs[id(wt)] = (weakref.ref(wt), wt.data_ptr(), wt._version, tuple(wt.shape), norm, torch.cuda.current_stream().cuda_stream, ev)
+    return wt
+
+
+def unfreeze_vocab(wt):
+    _frozen_vocabs.pop(id(wt), None)
 
 
 def vocab_norm(wt):
-    """max_v ||w_v||^2 of a name-major fp16 vocabulary, computed once per tensor (scd_sim_vocab_norm) and reused by every sim_topk call on
-    it while the tensor is unchanged (same storage address, same shape, and torch's in-place write counter `_version` has not moved)."""
-    key = id(wt)
-    ent = _vocab_norms.get(key)
+    """max_v ||w_v||^2 of a name-major fp16 vocabulary (scd_sim_vocab_norm): the frozen tensor's stored value (ops.freeze_vocab; a
+    consumer on another stream first waits for the event recorded behind its computation), a fresh one otherwise.  An in-place torch
+    write after the freeze (`_version`) ends the promise as well."""
+    ent = _frozen_vocabs.get(id(wt))
     if ent is not None and ent[0]() is wt and ent[1] == wt.data_ptr() and ent[2] == wt._version and ent[3] == tuple(wt.shape):
+        if ent[5] != torch.cuda.current_stream().cuda_stream:
+            ent[6].wait()                     # the current stream waits for the norm's kernel
         return ent[4]
-    out = torch.empty(1, dtype=torch.int32, device=wt.device)
-    check(_L().scd_sim_vocab_norm(handle(), ptr(wt), wt.shape[0], wt.shape[1], ptr(out), stream_ptr()))
-    if len(_vocab_norms) > 64:
-        for kk in [kk for kk, e in _vocab_norms.items() if e[0]() is None]:
-            del _vocab_norms[kk]
-    _vocab_norms[key] = (weakref.ref(wt), wt.data_ptr(), wt._version, tuple(wt.shape), out)
-    return out
+    if ent is not None:
+        del _frozen_vocabs[id(wt)]
+    return _vocab_norm_now(wt)
 
 
 def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
@@ -143,8 +169,8 @@ def sim_topk(f, wt, k, mode="raw", scale=100.0, return_fallback=False):
     nb = _L().scd_sim_topk_ws_bytes(n, d, v, k)
     ws = _ws(nb, f.device)
     m = SIM_SOFTMAX if mode == "softmax" else SIM_RAW
-    if wt is wt_in and v >= 4096:
-        # a vocabulary tensor handed in as it is stored (the full vocabulary of main_unsup.py:504-531, reused by every call): its norm once
+    if wt is wt_in and id(wt) in _frozen_vocabs:
+        # a vocabulary the caller froze (ops.freeze_vocab: the full vocabulary of main_unsup.py:504-531, reused by every call): its norm once
         check(_L().scd_sim_topk_prenorm(handle(), ptr(f), ptr(wt), n, d, v, float(scale), k, m, ptr(idx), ptr(val), ptr(fb),
                                         ptr(ws), nb, ptr(vocab_norm(wt)), stream_ptr()))
     else:

@@ -28,24 +28,41 @@ def encode_images(model, images, batch, out=None):
 
 
 def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2,
-        batch=3990, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None, cluster="SSKM"):
-    """One pass over `images` (this rank's shard).  Returns dict(feats, labels, cand_names, u_preds, name_idx)."""
+        batch=3990, kmeans_iters=10, n_init=10, seed=0, group=None, timers=None, cluster="SSKM", build_vocab=None, text_feats=None):
+    """One pass over `images` (this rank's shard).  Returns dict(feats, labels, cand_names, u_preds, name_idx).
+    build_vocab: a callable returning the name-major classifier W^T - the open-vocabulary build of BASELINE configs[4] (text tower over
+    the names, clip_lang_util.zeroshot_classifier[_sharded]) then runs INSIDE the pass ("text_tower" stage) instead of `wt` being
+    handed in.  text_feats [n, 512] fp16: per-image closed-set text features for the textual-enhancement re-ranking - top-k and the vote
+    loop's re-classification then use 100 * (f @ W + t @ W) / 2 = 100 * mean(f, t) @ W (the formula the reference keeps commented at
+    main_unsup.py:518,523,604,609); the clustering still sees the image features."""
     def mark(name):
         if timers is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             timers.append((name, ev))
     mark("start")
+    if build_vocab is not None:
+        wt = build_vocab()
+        mark("text_tower")
     feats = encode_images(model, images, batch)
     mark("encode")
-    name_idx, name_val = naming.full_vocab_topk(feats, None, topk, True, wt=wt)
+    if text_feats is not None:
+        nfeats = ops.mean2_f16(feats, text_feats)          # the naming feature; `feats` stays the clustering feature
+        name_idx, name_val = ops.sim_topk(nfeats, wt, topk, "softmax", 100.0)
+    else:
+        nfeats = feats
+        name_idx, name_val = naming.full_vocab_topk(feats, None, topk, True, wt=wt)
     mark("sim_topk")
     # `all_feats[~mask_lab]`, `all_feats[mask_lab]`, `name_idx[~mask_lab]` (main_unsup.py:318-321,561): the row numbers come from the
     # host mask (two small uploads), the selections are one launch each - no torch kernel in the step
     mask_h = np.asarray(mask_lab.cpu() if torch.is_tensor(mask_lab) else mask_lab, dtype=bool)
     iu = torch.from_numpy(np.flatnonzero(~mask_h)).to(feats.device)
     il = torch.from_numpy(np.flatnonzero(mask_h)).to(feats.device)
-    fu, u_feats, nidx_u = ops.select_rows(feats, iu, name_idx)
+    if nfeats is feats:
+        fu, u_feats, nidx_u = ops.select_rows(feats, iu, name_idx)
+    else:
+        fu, _, nidx_u = ops.select_rows(nfeats, iu, name_idx, want32=False)
+        _, u_feats, _ = ops.select_rows(feats, iu, None, want16=False)
     _, l_feats, _ = ops.select_rows(feats, il, None, want16=False)
     if cluster == "KM":
         # the shipped default of scripts/evaluate_unsupervised.sh: `KMeans(n_clusters, random_state=0).fit(u_feats).labels_` (:362)
@@ -56,7 +73,7 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
         u_preds = torch.from_numpy(km.labels_).to(feats.device)
         cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote, num_common_linear, max_iter=50)
         mark("vote")
-        return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace), kmeans=km)
+        return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace), kmeans=km, wt=wt)
     km = SemiSupKMeans(k=n_cluster, tolerance=1e-4, max_iterations=kmeans_iters, init='k-means++', n_init=n_init,
                        random_state=seed, n_jobs=None, pairwise_batch_size=1024, mode=None, group=group)
     km.fit_mix(u_feats, l_feats, torch.as_tensor(l_targets, device=feats.device))
@@ -70,7 +87,42 @@ def run(model, images, mask_lab, l_targets, wt, nouns, n_cluster, topk=3, num_co
                                                      num_common_linear, group, max_iter=50)
     mark("vote")
     return dict(feats=feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace),
-                kmeans=km)
+                kmeans=km, wt=wt)
+
+
+def run_cached(cluster_feats, clip_feats, mask_lab, wt, nouns, n_cluster, topk=3, num_common_vote=10, num_common_linear=2, timers=None,
+               cluster="KM", l_targets=None, seed=0):
+    """The pass of BASELINE configs[0] (CUB-200 unsupervised on cached features, main_unsup.py:298-364 with `extract_feature` replaced
+    by the cache files it writes): no encoder at all - full-vocabulary top-k of the cached CLIP features, the clustering of the cached
+    DINO features' unlabelled rows (`--cluster KM`, the shipped flag: `KMeans(n_clusters, random_state=0).fit(u_feats)`, :362; or SSKM)
+    and the vote loop (:568-614).  cluster_feats float32 [n, 768], clip_feats fp16 [n, 512], both resident in HBM."""
+    def mark(name):
+        if timers is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            timers.append((name, ev))
+    mark("start")
+    name_idx, _ = naming.full_vocab_topk(clip_feats, None, topk, True, wt=wt)
+    mark("sim_topk")
+    mask_h = np.asarray(mask_lab.cpu() if torch.is_tensor(mask_lab) else mask_lab, dtype=bool)
+    iu = torch.from_numpy(np.flatnonzero(~mask_h)).to(clip_feats.device)
+    fu, _, nidx_u = ops.select_rows(clip_feats, iu, name_idx, want32=False)
+    u_feats = cluster_feats.index_select(0, iu)
+    if cluster == "KM":
+        from .cluster import KMeans
+        km = KMeans(n_clusters=n_cluster, random_state=0).fit(u_feats)
+        u_preds = torch.from_numpy(km.labels_).to(clip_feats.device)
+    else:
+        il = torch.from_numpy(np.flatnonzero(mask_h)).to(clip_feats.device)
+        km = SemiSupKMeans(k=n_cluster, tolerance=1e-4, max_iterations=10, init='k-means++', n_init=10, random_state=seed, n_jobs=None,
+                           pairwise_batch_size=1024, mode=None)
+        km.fit_mix(u_feats, cluster_feats.index_select(0, il), torch.as_tensor(l_targets, device=clip_feats.device))
+        u_preds = km.labels_[int(mask_h.sum()):]
+    mark("kmeans")
+    cand, preds, trace = naming.vote_loop_unsup(nidx_u, u_preds, fu, wt, nouns, n_cluster, num_common_vote, num_common_linear, max_iter=50)
+    mark("vote")
+    return dict(feats=clip_feats, labels=km.labels_, cand_names=cand, u_preds=preds, name_idx=name_idx, vote_iters=len(trace), kmeans=km, wt=wt,
+                u_feats=u_feats)
 
 
 def run_ptsup(model, feat_model, images, mask_lab, l_targets, wt, nouns, lab_names, n_cluster, topk=2, num_common_vote=5,
@@ -242,7 +294,7 @@ def synthetic_vocab(model, base, v, seed, device, jitter=0.05):
     k = protos.shape[0]
     w[:k] = protos + jitter * torch.randn(k, protos.shape[1], generator=g, device=device) / protos.shape[1] ** 0.5
     wt = ops.l2norm_rows(w.contiguous()).to(torch.float16).contiguous()
-    return wt, ["name_%05d" % i for i in range(v)]
+    return ops.freeze_vocab(wt), ["name_%05d" % i for i in range(v)]         # (not written again: its filter norm once, not per call)
 
 
 def labelled_split(y, n_classes, prop=0.5, seed=5):

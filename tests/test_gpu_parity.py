@@ -734,18 +734,25 @@ def test_sim_topk_shapes(ops, n, v, d, k):
 
 
 def test_sim_topk_vocabulary_norm_is_computed_once_and_follows_the_tensor(ops):
-    """ops.sim_topk hands the vocabulary's max ||w||^2 (the data-dependent part of the filter's error bound) to scd_sim_topk_prenorm and
-    computes it once per vocabulary tensor (scd_sim_vocab_norm); an in-place change of the tensor (torch's `_version`) or a new tensor
-    gets a fresh one - a stale, too small norm would certify rows it must not.  Indices equal the oracle's before and after the change,
-    and equal the plain scd_sim_topk call's (main_unsup.py:504-531)."""
+    """ops.sim_topk hands the vocabulary's max ||w||^2 (the data-dependent part of the filter's error bound) to scd_sim_topk_prenorm.
+    It is computed per call unless the caller froze the tensor (ops.freeze_vocab: once, reused); an in-place change of a frozen tensor
+    (torch's `_version`) ends the promise and gets a fresh one - a stale, too small norm would certify rows it must not.  Indices
+    equal the oracle's before and after the change, and equal the plain scd_sim_topk call's (main_unsup.py:504-531)."""
     n, v, d, k = 700, 5000, 512, 3
     rs = np.random.RandomState(17)
     f = (rs.randn(n, d) / np.sqrt(d)).astype(np.float16)
     w = (rs.randn(d, v) / np.sqrt(d)).astype(np.float16)
     wt = ops.transpose_f16(dev(w))
+    assert ops.vocab_norm(wt) is not ops.vocab_norm(wt)            # not frozen: a fresh norm per call
+    ops.freeze_vocab(wt)
     idx1, val1 = ops.sim_topk(dev(f), wt, k, "softmax")
     norm1 = ops.vocab_norm(wt)
-    assert ops.vocab_norm(wt) is norm1                             # cached
+    assert ops.vocab_norm(wt) is norm1                             # frozen: computed once
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                  # a consumer on another stream waits for the norm's event
+        idx_s, _ = ops.sim_topk(dev(f), wt, k, "softmax")
+    side.synchronize()
+    assert torch.equal(idx_s, idx1)
     idx2, val2 = ops.sim_topk(dev(f), wt, k, "softmax")
     oi, ov = no.sim_topk(f, w, k, "softmax")
     assert np.array_equal(idx1.cpu().numpy(), oi) and torch.equal(idx1, idx2) and torch.equal(val1, val2)
@@ -2035,6 +2042,51 @@ def test_bench_config_c3_small(ops):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["cluster"] == "ConSSKM" and d["n_gpus"] == 1 and d["value"] > 0
     assert d["consskm"]["transport_solves_per_fit"] >= 10 and d["consskm"]["cluster_sizes_min_max"][0] >= 50
+    assert d["vote_iters"] >= 1 and d["synthetic_name_accuracy"] > 0.6
+
+
+def test_bench_config_c1(ops):
+    """`python bench.py --config c1` (BASELINE configs[0]: cached DINO + CLIP features, V = 1,000, the shipped `--cluster KM` with K = 200,
+    vote loop; no encoder) at its full size - it is 5,994 rows: the command runs to its JSON line, the stages are all there, the planted
+    names are found and the line carries the E-step's HBM roofline object (main_unsup.py:362,504-531,568-614)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("SCD_HIP_LIB", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["cluster"] == "KM" and d["config"]["images_per_gpu"] == 5994 and d["config"]["vocab"] == 1000 and d["config"]["n_cluster"] == 200
+    assert set(d["stage_ms_per_step"]) == {"sim_topk", "kmeans", "vote"} and d["value"] > 0
+    assert abs(d["value"] - 5994 / (d["ms_per_step"] / 1e3)) <= 1e-2 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["vote_iters"] >= 1
+    assert d["synthetic_name_accuracy"] > 0.6
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_config_c5_small(ops, gpus):
+    """`python bench.py --config c5` (BASELINE configs[4]: the open-vocabulary classifier built by the text tower INSIDE the step - 80
+    prompts per name; two ranks: name shards + all-gather over gloo on the shared GPU -, textual-enhancement top-k and vote) at a small
+    size: the JSON line carries the text tower's stage and its executed-FLOP rate, and the planted names are found
+    (clip_lang_util.py:96-108, main_unsup.py:518,523)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SCD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SCD_HIP_LIB", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--images", "1500",
+           "--n-cluster", "12", "--vocab", "1536", "--batch", "665", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["config"]["vocab"] == 1536 and "text_tower" in d["stage_ms_per_step"] and d["stage_ms_per_step"]["text_tower"] > 0
+    tt = d["secondary_rooflines"][0]
+    assert "text tower" in tt["kernel"] and tt["bound"] == "mfma" and 0 < tt["frac"] < 1 and tt["fc1_launches_per_step"] > 0
+    assert 0.05 < tt["gemm_gflop_per_prompt_executed"] < 5.96          # trimmed: below the full-length 5.96 GFLOP per prompt (SURVEY 8d)
     assert d["vote_iters"] >= 1 and d["synthetic_name_accuracy"] > 0.6
 
 

@@ -54,5 +54,20 @@ bench_prof)   # kernel stats of the TIMED region of `bench.py ARGS` (marker kern
   rc=$?; echo "[rocprof bench $tag] rc=$rc"; if [ $rc -ne 0 ]; then tail -n 20 $out/prof_$tag.log; exit 1; fi
   python3 $R/tools/trace_window_stats.py $out/prof_$tag $out/r06_bench_${tag}_kernel_stats.csv | cut -c1-170 | head -n 24
   rm -rf $out/prof_$tag ;;
+pytest)    # tools/gpu_r06.sh pytest TAG -k EXPR
+  tag=$1; shift
+  timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > $out/pytest_$tag.txt 2>&1; rc=$?
+  echo "[pytest $tag] rc=$rc"; tail -n 3 $out/pytest_$tag.txt; [ $rc -eq 0 ] || { tail -n 60 $out/pytest_$tag.txt; exit 1; } ;;
+bench)     # tools/gpu_r06.sh bench TAG ARGS...  -> $out/bench_TAG.json
+  tag=$1; shift
+  timeout -k 10 900 python bench.py "$@" > $out/bench_$tag.json 2> $out/bench_$tag.err || { tail -n 30 $out/bench_$tag.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("$out/bench_$tag.json"))
+print("[$tag] %.1f images/s, %.2f ms/step, stages %s, sclk %s, cycles/img %s" % (d["value"], d["ms_per_step"], d["stage_ms_per_step"], d.get("sclk_mhz_median"), d.get("encode_cycles_per_image")))
+print("   roofline", {k: v for k, v in d["roofline"].items() if k not in ("kernel", "note", "traffic_source")})
+for s in d.get("secondary_rooflines", []): print("   ", {k: v for k, v in s.items() if k not in ("kernel", "note")}, s["kernel"][:50])
+PY
+  ;;
 *) echo "unknown step $step"; exit 2 ;;
 esac
