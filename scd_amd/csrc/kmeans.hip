@@ -2387,32 +2387,41 @@ extern "C" int scd_kpp_searchsorted(scd_handle h, const float* d2, int64_t n, co
 // VALU work with one row per thread) and HALF of every chunk's columns (waves 0-1: columns 0-15, waves 2-3: 16-31: N / 64 waves
 // as with one row per thread, so the SIMDs stay evenly loaded).  A row's sum is (its low-half columns in ascending order) +
 // (its high-half columns in ascending order), whatever R and RB.
+// J = rows per thread: 2 (256-row blocks) or 1 (128-row blocks, for inputs whose 256-row blocks would not fill the chip: the same
+// sums in the same order, twice the blocks).
 constexpr int MU_COLS = 32, MU_LD = 36, MU_ROWS = 256;
-template <int RB, bool VEC>
+template <int RB, bool VEC, int J>
+// blockIdx.y = trial l of a greedy k-means++ round (gridDim.y = 1 otherwise): centres Cn + l * lc, output d2 + l * lo.  d2in: the current
+// distances when the result goes elsewhere (out = min(d2in, dist): the trials of a round all start from the same d2), null = in place.
 __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
-                                                          int r0, int R, float* __restrict__ d2, long long ld, long long ldc) {
-    __shared__ __attribute__((aligned(16))) float xs[MU_ROWS * MU_LD];       // reused for the high-half partials at the end
+                                                          int r0, int R, float* d2, long long ld, long long ldc, const float* d2in,
+                                                          long long lc, long long lo) {
+    Cn += (size_t)blockIdx.y * lc;
+    d2 += (size_t)blockIdx.y * lo;
+    const float* din = d2in ? d2in : d2;
+    constexpr int NROW = 128 * J;
+    __shared__ __attribute__((aligned(16))) float xs[NROW * MU_LD];          // reused for the high-half partials at the end
     __shared__ __attribute__((aligned(16))) double cs[RB * MU_COLS];
-    static_assert(128 * 2 * RB * 8 <= MU_ROWS * MU_LD * 4, "partials must fit the x tile");
+    static_assert(128 * J * RB * 8 <= NROW * MU_LD * 4, "partials must fit the x tile");
     const int t = threadIdx.x, p = t & 127, half = t >> 7;
-    const long long row0 = (long long)blockIdx.x * MU_ROWS;
+    const long long row0 = (long long)blockIdx.x * NROW;
     const int nch = (d + MU_COLS - 1) / MU_COLS;
     constexpr int NC = (RB * MU_COLS + 255) / 256;
-    float4 pre[8];
-    float prs[VEC ? 1 : 32];
+    float4 pre[4 * J];
+    float prs[VEC ? 1 : 16 * J];
     float prc[NC];
     auto fetch = [&](int ch) {
         const int c0 = ch * MU_COLS;
         if (VEC) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4 * J; ++i) {
                 const long long r = row0 + (t >> 3) + 32 * i;
                 const int c = c0 + (t & 7) * 4;
                 pre[i] = (r < n && c < d) ? *(const float4*)(X + r * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
+            for (int i = 0; i < 16 * J; ++i) {
                 const long long r = row0 + (t >> 5) + 8 * i;
                 const int c = c0 + (t & 31);
                 prs[VEC ? 0 : i] = (r < n && c < d) ? X[r * d + c] : 0.f;
@@ -2424,9 +2433,9 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
             prc[i] = (e < RB * MU_COLS && r < R && c < d) ? Cn[(size_t)r * ldc + c] : 0.f;
         }
     };
-    double acc[2][RB];
+    double acc[J][RB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[j][r] = 0.0;
     fetch(0);
@@ -2434,10 +2443,10 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
         __syncthreads();
         if (VEC) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(float4*)(xs + ((t >> 3) + 32 * i) * MU_LD + (t & 7) * 4) = pre[i];
+            for (int i = 0; i < 4 * J; ++i) *(float4*)(xs + ((t >> 3) + 32 * i) * MU_LD + (t & 7) * 4) = pre[i];
         } else {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) xs[((t >> 5) + 8 * i) * MU_LD + (t & 31)] = prs[VEC ? 0 : i];
+            for (int i = 0; i < 16 * J; ++i) xs[((t >> 5) + 8 * i) * MU_LD + (t & 31)] = prs[VEC ? 0 : i];
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i)
@@ -2447,9 +2456,9 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int col = 16 * half + 4 * q;
-            double x[2][4];
+            double x[J][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < J; ++j) {
                 const float4 xv = *(const float4*)(xs + (p + 128 * j) * MU_LD + col);
                 x[j][0] = (double)xv.x; x[j][1] = (double)xv.y; x[j][2] = (double)xv.z; x[j][3] = (double)xv.w;
             }
@@ -2458,7 +2467,7 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
                 const double2 c01 = *(const double2*)(cs + r * MU_COLS + col);
                 const double2 c23 = *(const double2*)(cs + r * MU_COLS + col + 2);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < J; ++j) {
                     double a = x[j][0] - c01.x; acc[j][r] = fma(a, a, acc[j][r]);
                     a = x[j][1] - c01.y; acc[j][r] = fma(a, a, acc[j][r]);
                     a = x[j][2] - c23.x; acc[j][r] = fma(a, a, acc[j][r]);
@@ -2468,24 +2477,24 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
         }
     }
     __syncthreads();
-    double* part = (double*)xs;                       // [128][2][RB]
+    double* part = (double*)xs;                       // [128][J][RB]
     if (half) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-            for (int r = 0; r < RB; ++r) part[(p * 2 + j) * RB + r] = acc[j][r];
+            for (int r = 0; r < RB; ++r) part[(p * J + j) * RB + r] = acc[j][r];
     }
     __syncthreads();
     if (!half) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < J; ++j) {
             const long long row = row0 + p + 128 * j;
             if (row < n) {
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
                     if (r0 + r < R) {
-                        float* q = d2 + (size_t)(r0 + r) * ld + row;
-                        *q = fminf(*q, (float)(acc[j][r] + part[(p * 2 + j) * RB + r]));
+                        const size_t at = (size_t)(r0 + r) * ld + row;
+                        d2[at] = fminf(din[at], (float)(acc[j][r] + part[(p * J + j) * RB + r]));
                     }
             }
         }
@@ -2494,18 +2503,27 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
 
 template <int RB>
 static int minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st,
-                         long long ldc) {
-    const unsigned g = (unsigned)scd_cdiv(n, MU_ROWS);
-    if ((d & 3) == 0) minupd_tile_kernel<RB, true><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc);
-    else minupd_tile_kernel<RB, false><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc);
+                         long long ldc, const float* d2in, int L, long long lc, long long lo) {
+    if (scd_cdiv(n, MU_ROWS) * L < 256) {             // fewer 256-row blocks than CUs: 128-row blocks (same bits)
+        const dim3 g((unsigned)scd_cdiv(n, 128), (unsigned)L);
+        if ((d & 3) == 0) minupd_tile_kernel<RB, true, 1><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
+        else minupd_tile_kernel<RB, false, 1><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
+        return SCD_OK;
+    }
+    const dim3 g((unsigned)scd_cdiv(n, MU_ROWS), (unsigned)L);
+    if ((d & 3) == 0) minupd_tile_kernel<RB, true, 2><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
+    else minupd_tile_kernel<RB, false, 2><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
     return SCD_OK;
 }
-// c_new row r at Cn + r * ldc
-static int minupd_all(const float* X, const float* c_new, long long n, int d, int R, float* d2, long long ld, long long ldc, hipStream_t st) {
+// c_new row r at Cn + r * ldc.  L > 1: the L trials of a greedy round in one launch per restart group - trial l's centres at
+// c_new + l * lc, its result d2 + l * lo = min(d2in, distances), d2in shared by the trials (round 6: at 4,500 rows a launch is 18 blocks,
+// and seven of them one after the other were 73 % of the CUB-shaped step).
+static int minupd_all(const float* X, const float* c_new, long long n, int d, int R, float* d2, long long ld, long long ldc, hipStream_t st,
+                      const float* d2in = nullptr, int L = 1, long long lc = 0, long long lo = 0) {
     int r0 = 0;
-    while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 10; }
-    while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 4; }
-    while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2, ld, st, ldc); r0 += 1; }
+    while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 10; }
+    while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 4; }
+    while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 1; }
     return SCD_OK;
 }
 

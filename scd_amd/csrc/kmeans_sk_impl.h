@@ -241,6 +241,15 @@ __global__ void kg_tiles_pot_kernel(const double* __restrict__ bsum, int nb, int
     for (int b = 0; b < nb; ++b) t += bsum[(size_t)r * nb + b];
     out[(size_t)r * stride] = t;
 }
+// potd[r * L + l] = sum_b bsum2[l * R + r][b], tiles in index order: all trials of a round in one launch
+__global__ void __launch_bounds__(256) kg_tiles_pot_all_kernel(const double* __restrict__ bsum2, int nb, int R, int L, double* __restrict__ potd) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= R * L) return;
+    const int l = m / R, r = m % R;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += bsum2[(size_t)m * nb + b];
+    potd[(size_t)r * L + l] = t;
+}
 __global__ void __launch_bounds__(256) kg_fill_kernel(float* __restrict__ p, long long n_elems, float v) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_elems; i += (long long)gridDim.x * 256) p[i] = v;
 }
@@ -248,7 +257,7 @@ __global__ void __launch_bounds__(256) kg_fill_kernel(float* __restrict__ p, lon
 struct KgLayout {
     long long ld, cap;
     int g, dp, nbat, Mp, nb;
-    size_t o_d2, o_bsum, o_cand, o_potd, o_cn, o_c16, o_info, o_rn2, o_counts, o_list, o_vals, o_tmp, total;
+    size_t o_d2, o_bsum, o_bsum2, o_cand, o_potd, o_cn, o_c16, o_info, o_rn2, o_counts, o_list, o_vals, o_tmp, total;
 };
 static KgLayout kg_layout(int64_t n, int d, int R, int L, bool filt) {
     KgLayout y;
@@ -264,6 +273,7 @@ static KgLayout kg_layout(int64_t n, int d, int R, int L, bool filt) {
     auto take = [&](size_t bytes) { const size_t at = o; o += scd_align(bytes); return at; };
     y.o_d2 = take(4 * (size_t)R * y.ld);
     y.o_bsum = take(8 * (size_t)R * y.nb);
+    y.o_bsum2 = take(8 * (size_t)R * L * y.nb);            // per-tile sums of the L trials' distance vectors (dense path)
     y.o_cand = take(8 * (size_t)y.Mp);
     y.o_potd = take(8 * (size_t)y.Mp);
     y.o_cn = take(4 * (size_t)y.Mp * d);
@@ -296,6 +306,7 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
     char* w = (char*)ws;
     float* d2 = (float*)(w + y.o_d2);
     double* bsum = (double*)(w + y.o_bsum);
+    double* bsum2 = (double*)(w + y.o_bsum2);
     long long* cand = (long long*)(w + y.o_cand);
     double* potd = (double*)(w + y.o_potd);
     float* Cn = (float*)(w + y.o_cn);
@@ -348,18 +359,13 @@ extern "C" int scd_kpp_greedy_lockstep(scd_handle h, const float* X, const void*
             kg_exact_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>((const half_t*)X16, Cn, d, L, M, counts, list, vals, y.cap, y.g, d2, y.ld, potd);
             kg_apply_kernel<<<dim3(y.g, y.nbat), 256, 0, st>>>(counts, list, vals, y.cap, y.g, potd, R, L, d2, y.ld, cand, Cn, d, slot, ldc, picks_t);
         } else {
-            SCD_HIP(hipMemcpyAsync(tmp, d2, 4 * (size_t)R * y.ld, hipMemcpyDeviceToDevice, st));
-            for (int l = 1; l < L; ++l) SCD_HIP(hipMemcpyAsync(tmp + (size_t)l * R * y.ld, tmp, 4 * (size_t)R * y.ld, hipMemcpyDeviceToDevice, st));
-            for (int l = 0; l < L; ++l) {
-                float* tl = tmp + (size_t)l * R * y.ld;
-                minupd_all(X, Cn + (size_t)l * d, n, d, R, tl, y.ld, (long long)L * d, st);
-            }
-            // potentials: potd[r * L + l] = float64 sum of tmp[l][r]: per-tile sums over the whole chip, then the tiles in order
-            // (one 1024-thread block per row took 108 us per trial at 95,000 rows)
-            for (int l = 0; l < L; ++l) {
-                kpp_tile_sum_multi_kernel<<<dim3(y.nb, R), 1024, 0, st>>>(tmp + (size_t)l * R * y.ld, n, y.ld, bsum, y.nb);
-                kg_tiles_pot_kernel<<<1, 64, 0, st>>>(bsum, y.nb, R, potd + l, L);
-            }
+            // the L trials of the round in ONE distance launch per restart group (blockIdx.y = trial): tmp[l][r] = min(d2[r], distances
+            // to trial l's candidate of restart r) - d2 is read, not copied L times (round 6: 4 L + 4 launches per round -> 7)
+            minupd_all(X, Cn, n, d, R, tmp, y.ld, (long long)L * d, st, d2, L, d, (long long)R * y.ld);
+            // potentials: potd[r * L + l] = float64 sum of tmp[l][r]: per-tile sums over the whole chip (rows l * R + r of tmp), then the
+            // tiles in index order (one 1024-thread block per row took 108 us per trial at 95,000 rows)
+            kpp_tile_sum_multi_kernel<<<dim3(y.nb, R * L), 1024, 0, st>>>(tmp, n, y.ld, bsum2, y.nb);
+            kg_tiles_pot_all_kernel<<<(unsigned)scd_cdiv(M, 256), 256, 0, st>>>(bsum2, y.nb, R, L, potd);
             kg_select_kernel<<<dim3(64, R), 256, 0, st>>>(tmp, n, y.ld, potd, R, L, d2, cand, Cn, d, slot, ldc, picks_t);
         }
     }
