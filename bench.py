@@ -261,7 +261,7 @@ def dominant_kernel_roofline(ms, launches, flop):
     sec = ms / 1e3
     tf = flop / max(sec, 1e-12) / 1e12
     # HBM-side traffic per launch cannot be read without the profiler: it is taken from this round's committed PMC passes
-    # (profiles/r05_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/gpu_r05_final.sh)
+    # (profiles/r05_pmc_fc1.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of this script, tools/history/gpu_r05_final.sh)
     # at the default launch size (3,990 images = 786,432 rows); another --batch scales it by its rows per launch
     traffic, pmf = None, ""
     try:

@@ -35,7 +35,7 @@ def _digest(paths):
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs if f.endswith(".h")]      # csrc/*.h and csrc/ablate/*.h
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "scd_hip.h"))
     return hdrs
 

@@ -455,228 +455,8 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #ifdef SCD_ABLATE   // A/B kernel (SCD_GEMM_MFMA=16): not in the default build
-// ------------------------------------------------------------------------------------------------
-// Same block tile / ring / schedule as gemm_dma_kernel<256>, but on v_mfma_f32_16x16x32_f16 (the shape on which gfx950
-// sustains the higher clock under load): a 32-deep sub-step is ONE k-step of 8(m) x 4(n) 16x16 tiles = 32 MFMAs per wave.
-// Fragment (A or B operand): lane l reads row (l&15), 16-B chunk (l>>4) of a 64-B LDS row.  Chunk swizzle
-// pc = chunk ^ ((-(row>>2)) & 3): every ds_read_b128 lane group then touches 16 distinct 16-B slots.
-// MFMA group 0 = m-tiles 0-3, group 1 = m-tiles 4-7; the A fragments of group 1 are read while group 0 computes, and
-// the W + A(0-3) fragments of the next sub-step while group 1 computes.
-
-template <int ACT, bool HAS_BIAS, bool HAS_RES>
-__global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W,
-                                                            const float* __restrict__ bias, const half_t* __restrict__ R,
-                                                            half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-                                                            int xmode, int ng) {
-    constexpr int BM = 256, NSLOT = 4, SLOT = 32768;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int c16 = lane & 15, q16 = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int nk = K >> 5;
-    const int tiles_m = total_tiles / tiles_n;
-    const int per_group = tiles_m * ng;
-    auto tile_mn = [&](int t, int& bm, int& bn) {
-        const int g = t / per_group;
-        const int local = t - g * per_group;
-        const int n0 = g * ng;
-        const int w = tiles_n - n0 < ng ? tiles_n - n0 : ng;
-        bm = local / w;
-        bn = n0 + local - bm * w;
-    };
-    const int nxcd = gridDim.x >= 8 ? 8 : 1;
-    const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
-    const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
-    const int tb = c0 + slot_id;
-    const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
-    const int steps = my_tiles * nk;
-    if (steps <= 0) return;
-    const int tstride = per_xcd;
-
-    auto swz = [](int row) { return (0 - (row >> 2)) & 3; };
-    const int lrow = lane >> 2, pc = lane & 3;
-    int a_off[2], w_off[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int rowl = wave * 32 + p * 16 + lrow;
-        a_off[p] = rowl * K + ((pc ^ swz(rowl)) << 3);
-        w_off[p] = a_off[p];
-    }
-    auto issue = [&](int tile, int kt, int slot) {
-        int bm, bn;
-        tile_mn(tile, bm, bn);
-        if (xmode & 4) { bm = 0; bn = 0; }
-        const half_t* ga = A + (size_t)bm * BM * K + kt * 32;
-        const half_t* gw = W + (size_t)bn * 256 * K + kt * 32;
-        char* sa = smem + slot * SLOT + wave * 2048;
-        char* sw = sa + 16384;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            __builtin_amdgcn_global_load_lds((const void*)(ga + a_off[p]), (lds_ptr_t)(sa + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const void*)(gw + w_off[p]), (lds_ptr_t)(sw + p * 1024), 16, 0, 0);
-        }
-    };
-    // fragment byte offsets inside a sub-tile: rows (base + 16*t + c16), chunk q16
-    int offw[4], offa[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = wn * 64 + t * 16 + c16;
-        offw[t] = 16384 + row * 64 + ((q16 ^ swz(row)) << 4);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int row = wm * 128 + t * 16 + c16;
-        offa[t] = row * 64 + ((q16 ^ swz(row)) << 4);
-    }
-
-    f32x4v acc[4][8];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[tn][tm][q] = 0.f;
-
-    int tile = tb, kt = 0, ntile = tb, nkt = 0;
-#pragma unroll
-    for (int pre = 0; pre < NSLOT - 1; ++pre) {
-        if (pre < steps) issue(ntile, nkt, pre);
-        if (++nkt == nk) { nkt = 0; ntile += tstride; }
-    }
-    int store_age = 8;
-    half8 rpre[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rpre[p][q] = (half_t)0.f;
-
-    half8 fw[4], fa_lo[4], fa_hi[4], fwn[4];
-    if (steps >= NSLOT - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        fw[t] = *(const half8*)(smem + offw[t]);
-        fa_lo[t] = *(const half8*)(smem + offa[t]);
-    }
-    int cslot = 0;
-    for (int s = 0; s < steps; ++s) {
-        const char* cur = smem + cslot * SLOT;
-        const int nslot = cslot + 1 == NSLOT ? 0 : cslot + 1;
-        if (HAS_RES && kt == nk - 2) {
-            int bm, bn;
-            tile_mn(tile, bm, bn);
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 8 + (lane >> 3)) * N + bn * 256 + wn * 64 + (lane & 7) * 8);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fa_hi[t] = *(const half8*)(cur + offa[4 + t]);          // m-tiles 4-7 of this sub-step
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa_lo[tm], acc[tn][tm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (s + 1 < steps) {
-            if (s + NSLOT - 2 >= steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (store_age < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        ++store_age;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + NSLOT - 1 < steps && !((xmode & 1) && s >= 2)) {
-            int ls = cslot + NSLOT - 1;
-            if (ls >= NSLOT) ls -= NSLOT;
-            issue(ntile, nkt, ls);
-        }
-        if (++nkt == nk) { nkt = 0; ntile += tstride; }
-        if (s + 1 < steps) {
-            const char* nx = smem + nslot * SLOT;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fwn[t] = *(const half8*)(nx + offw[t]);
-                fa_lo[t] = *(const half8*)(nx + offa[t]);
-            }
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-                acc[tn][4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa_hi[tm], acc[tn][4 + tm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fw[t] = fwn[t];
-        cslot = nslot;
-        if (++kt == nk) {
-            // epilogue: D tile (tn, tm): lane (c16 = m column, q16) holds n = tn*16 + q16*4 + 0..3.  Per 32-row m block
-            // (two m-tiles) the values go through a per-wave LDS patch [32 m][64 n] fp16 (128-B rows, chunk XOR row&7)
-            // and leave as whole 128-byte row segments.
-            int bm, bn;
-            tile_mn(tile, bm, bn);
-            char* ep = smem + NSLOT * SLOT + wave * 4096;
-            const int nb0 = bn * 256 + wn * 64;
-            f32x4v bq[4];
-            if (HAS_BIAS) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);
-                    bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                half8 rcur[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) rcur[p] = rpre[p];
-                if (HAS_RES && i < 3) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        rpre[p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (i + 1) * 32 + p * 8 + (lane >> 3)) * N + nb0 + (lane & 7) * 8);
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = h * 16 + c16;
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) {
-                        half4 o;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            float v = acc[tn][2 * i + h][q4];
-                            if (HAS_BIAS) v += bq[tn][q4];
-                            o[q4] = (half_t)act_apply(v, ACT);
-                            acc[tn][2 * i + h][q4] = 0.f;
-                        }
-                        *(half4*)(ep + row * 128 + (((tn * 2 + (q16 >> 1)) ^ (row & 7)) << 4) + (q16 & 1) * 8) = o;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int rr = p * 8 + (lane >> 3), cc = lane & 7;
-                    half8 hv = *(const half8*)(ep + rr * 128 + ((cc ^ (rr & 7)) << 4));
-                    const size_t off = ((size_t)bm * BM + wm * 128 + i * 32 + rr) * N + nb0 + cc * 8;
-                    if (HAS_RES) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) hv[q] = (half_t)((float)hv[q] + (float)rcur[p][q]);
-                    }
-                    if (!(xmode & 2)) *(half8*)(C + off) = hv;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            kt = 0;
-            tile += tstride;
-            store_age = 0;
-        }
-    }
-}
-
-#endif  // SCD_ABLATE
+#include "ablate/gemm_dma16_kernel.h"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Four-wave kernel: 256x256 block tile, one wave per SIMD, each wave a 128(m) x 128(n) sub-tile whose 256 accumulator
@@ -700,41 +480,8 @@ __global__ void __launch_bounds__(512, 2) gemm_dma16_kernel(const half_t* __rest
 // the accumulators between AGPRs and VGPRs around every group), C = 0 on a tile's first sub-step instead of zeroing,
 // ds_read_b128 with counted lgkmcnt (for asm operands hipcc only emits lgkmcnt(0)); s_nop covers the MFMA -> v_accvgpr_read
 // hazard the compiler cannot see.
-#ifndef W4_DMA_SPLIT
-#define W4_DMA_SPLIT 1
-#endif
-#ifndef W4_LATE_BAR
-#define W4_LATE_BAR 1
-#endif
-#ifndef W4_TN_MAJOR
-#define W4_TN_MAJOR 0   // MFMA order inside a sub-step: 0 = m-tile outer (eight MFMAs share the A fragment), 1 = n-tile outer
-#endif
-#ifndef W4_PROBE_VALU
-#define W4_PROBE_VALU 0
-#endif
-#ifndef W4_TNW
-#define W4_TNW 8   // timing probe only (-DW4_TNW=4): the wave computes 4 of its 8 n-tiles - the main loop of a 256 x 128 block tile; results are wrong
-#endif
-#ifndef W4_DEFER_STORES
-#define W4_DEFER_STORES 1
-#endif
-#ifndef W4_LATE_TM
-#define W4_LATE_TM 2
-#endif
-#ifndef W4_WSPLIT
-#define W4_WSPLIT 0     // ring-fill schedule experiment: this many of a chunk's eight W fills are issued in the ODD sub-step behind the A fills
-#endif                  // (A every 4 MFMAs instead of every 6), the rest at the very start of the next even one: the chunk's last fill goes out
-                        // ~16 MFMAs earlier, i.e. has ~300 more cycles to land before the barrier that waits for it
-#ifndef W4_ABL_STATS
-#define W4_ABL_STATS 0   // timing probe (results wrong): 1 = the LN = 2 epilogue computes / adds no row statistics
-#endif
-#ifndef W4_ABL_PRE
-#define W4_ABL_PRE 0     // timing probe (results wrong): 1 = no bias / column-sum loads in front of the epilogue (zeros)
-#endif
-#ifndef W4_LN_ABL
-#define W4_LN_ABL 0   // timing probes of the LayerNorm fold (results are wrong): 1 = no row-statistics loads / conversions (rstd = 1, mean = 0), 2 = no fold arithmetic either
-#endif
-__device__ unsigned long long g_w4_dbg[256 * 4];   // SCD_GEMM_X & 64: per block {main-loop cycles, epilogue cycles, tiles, total}
+#include "ablate/w4_knobs.h"      // the schedule constants of this kernel (shipped values) and the experiment hooks of rounds 3-5
+#include "ablate/w4_probes.h"     // cycle-counter probes: real code with -DSCD_ABLATE, empty otherwise
 
 // LN = 1: a LayerNorm over A's rows is folded into this GEMM.  W already carries gamma (W' = W * gamma[k]), bias carries
 //         beta (b' = b + W beta), colsum[n] = sum_k W'[n][k], and ln_rs[m] = {rstd, -mean * rstd} of the raw input rows, which
@@ -840,25 +587,13 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     // M0 = the slot's LDS base (one SGPR per slot, formed once) + an immediate: one SALU instruction per fill.  (As "s"(base + slot
     // offset + 1024 p) hipcc rebuilt the address with xor / add / mov + its own s_nop in front of every fill: five scalar
     // instructions in the lone wave's stream per fill, sixteen fills per chunk.)
-#ifndef W4_A_MOD
-#define W4_A_MOD ""      // cache-policy bits of the activation fills (" nt", " sc1", ...): experiment hook
-#endif
-#ifndef W4_W_MOD
-#define W4_W_MOD ""
-#endif
 #define W4_DMA(BASE, P, SLOTLDS, PART, MOD)                                                                      \
     asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD                        \
                  ::"s"(SLOTLDS), "v"(((P) & 1) ? voff1 : voff0), "s"((BASE) + ((P) >> 1) * k16), "n"((PART) + (P) * 1024) : "memory", "scc")
-#ifndef W4_RES_NT
-#define W4_RES_NT 0      // experiment: the residual rows of proj / fc2 (read once, private to the tile) fetched non-temporally
-#endif
 #if W4_RES_NT
 #define W4_RLOAD(P) __builtin_nontemporal_load((const half8*)(P))
 #else
 #define W4_RLOAD(P) (*(const half8*)(P))
-#endif
-#ifndef W4_A_NT_LN1
-#define W4_A_NT_LN1 0    // experiment: non-temporal activation fills in the LayerNorm-folded variants only (QKV, fc1: K = 768, A read once per n-group)
 #endif
     auto issue_a = [&](int p, int slot) {
         if constexpr (W4_A_NT_LN1 && LN == 1) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, " nt"); }
@@ -915,9 +650,6 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         for (int p = 0; p < W4_WSPLIT; ++p) issue_w(p, 1);     // (what an odd sub-step would have issued of chunk 1's W part)
     }
     issue_advance();
-#ifndef W4_RD_LN2
-#define W4_RD_LN2 2
-#endif
     constexpr int RD = LN == 2 ? W4_RD_LN2 : 3;   // residual rows in flight (m-tiles); the stats epilogue needs the registers
     half8 rq[RD][4];
 #pragma unroll
@@ -1008,7 +740,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     {                                                                                                            \
         const unsigned so = cslot * SLOT;                                                                        \
         W4_LGKM(0);                                                                                              \
-        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_odd += t - t_sub; t_sub = t; } \
+        W4_PROBE_SUB(t_odd)                                                                                      \
         W4_SUB(fwA, faA, Z, W4_H_EVEN)                                                                           \
     }
 #define W4_ODD()                                                                                                 \
@@ -1016,14 +748,14 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         const unsigned no = (cslot ^ 1) * SLOT; /* past the last chunk: a stale slot, values unused */           \
         /* all of this wave's reads of the chunk have completed: after the barrier the slot can be refilled */   \
         W4_LGKM(0);                                                                                              \
-        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_even += t - t_sub; t_sub = t; } \
+        W4_PROBE_SUB(t_even)                                                                                     \
         /* chunk g+1: A part issued under the previous odd sub-step, W part under the even one just finished; an epilogue's  \
            stores, if any, sit between the two in the in-order queue, so this waits for them as well */                 \
         if (LATE_BAR) { W4_SUB_RANGE(fwB, faB, 0, W4_H_NONE, 0, W4_LATE_TM) }   /* MFMAs that need nothing new */    \
         if (!(xmode & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_s_barrier();                                                                            \
         asm volatile("" ::: "memory");                                                                           \
-        if (xmode & 128) { const unsigned long long t = __builtin_readcyclecounter(); t_bar += ((xmode & 2048) && !tile_first) ? 0ull : t - t_sub; t_sub = t; } \
+        W4_PROBE_BAR()                                                                                           \
         tile_first = false;                                                                                      \
         /* past this block's last chunk the refill re-reads the current tile's first chunk into the free slot: no branch  \
            around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
@@ -1033,8 +765,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         cslot ^= 1;                                                                                              \
         ++g;                                                                                                     \
     }
-    unsigned long long t_main = 0, t_epi = 0, t_begin = __builtin_readcyclecounter();
-    unsigned long long t_even = 0, t_odd = 0, t_bar = 0, t_sub = t_begin;
+    W4_PROBE_DECL()
     bool tile_first = true;      // (-DSCD_ABLATE, SCD_GEMM_X & 2048: the wait + barrier counter takes a tile's FIRST chunk only - the one behind the previous tile's stores)
     for (int ti = 0; ti < my_tiles; ++ti) {
         tile_first = true;
@@ -1046,7 +777,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         const size_t tile_el = ((size_t)((xmode & 1024) ? 0 : bm) * BM + wm * 128) * N + ((xmode & 1024) ? wn * 128 : nb0);
         const half_t* const Rt = HAS_RES ? R + tile_el : nullptr;
         half_t* const Ct = C + tile_el;
-        const unsigned long long t0 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
+        W4_PROBE_MARK(t0)
         f32x4v acc[8][8];   // [tn][tm]; first written by the C = 0 MFMAs of the first sub-step
         f32x4v bq[8], sq[8];
         float2 lrs[8];
@@ -1090,7 +821,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #undef W4_PRE
         W4_LGKM(0);                                            // next tile's first fragments (read under the last group)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last MFMA -> accumulator read
-        const unsigned long long t1 = (xmode & 64) ? __builtin_readcyclecounter() : 0;
+        W4_PROBE_MARK(t1)
         if (!(xmode & 16)) {
             // epilogue, one 16-row m-tile at a time through a per-wave LDS patch [16 m][128 n] fp16 (256-B rows, chunk XOR row):
             // lane (c16 = m, q16) holds n = tn*16 + q16*4 + 0..3; rows leave as whole 256-byte segments.  No lgkmcnt waits
@@ -1250,24 +981,9 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
             }
         }
         if (ti + 1 < my_tiles) it_step(cit);
-        if (xmode & 64) {
-            const unsigned long long t2 = __builtin_readcyclecounter();
-            t_main += t1 - t0;
-            t_epi += t2 - t1;
-        }
+        W4_PROBE_TILE_END()
     }
-    if ((xmode & 64) && tid == 0) {
-        g_w4_dbg[blockIdx.x * 4 + 0] = t_main;
-        g_w4_dbg[blockIdx.x * 4 + 1] = t_epi;
-        g_w4_dbg[blockIdx.x * 4 + 2] = my_tiles;
-        g_w4_dbg[blockIdx.x * 4 + 3] = __builtin_readcyclecounter() - t_begin;
-        if (xmode & 128) {   // per sub-step: even, wait+barrier, odd (the odd figure of a tile's last chunk includes the epilogue)
-            g_w4_dbg[blockIdx.x * 4 + 0] = t_even;
-            g_w4_dbg[blockIdx.x * 4 + 1] = t_bar;
-            g_w4_dbg[blockIdx.x * 4 + 2] = t_odd;
-            g_w4_dbg[blockIdx.x * 4 + 3] = chunks;
-        }
-    }
+    W4_PROBE_FINISH()
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail refills must land before the LDS is handed to another block
     if (W4_PROBE_VALU && pv0 + pv1 + pv2 + pv3 == 12345.678f) C[0] = (half_t)pv0;
 #undef W4_PROBE
@@ -1284,276 +1000,8 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 }
 
 #ifdef SCD_ABLATE   // A/B kernel (SCD_GEMM_MFMA=8): not in the default build
-// ------------------------------------------------------------------------------------------------
-// Eight-wave sibling of gemm_w4_kernel (SCD_GEMM_MFMA=8, A/B candidate): the same 256x256 block tile, 64-deep chunks, LDS
-// image, tile order, non-temporal stores and LayerNorm folding, but two waves per SIMD with 128(m) x 64(n) wave tiles
-// (128 accumulator VGPRs), MFMAs left to the compiler's scheduler.  The idea: the ~25 % of a chunk that the four-wave kernel
-// loses to instruction-issue stalls (ring fills, ds_read issue, the barrier) is covered by the other wave of the SIMD.
-template <int ACT, bool HAS_BIAS, bool HAS_RES, int LN>
-__global__ void __launch_bounds__(512, 2)
-gemm_w8_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
-               const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
-               int xmode, int ng, const long long* __restrict__ ln_stats, const float* __restrict__ ln_colsum, float ln_invk,
-               float ln_eps, long long* __restrict__ ln_out, long long* __restrict__ ln_zero) {
-    constexpr int BM = 256, BN = 256, SLOT = 65536, WPART = 32768, EPI = 2 * SLOT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int c16 = lane & 15, q16 = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int nkc = K >> 6;
-    const int tiles_m = total_tiles / tiles_n;
-    const int per_group = tiles_m * ng;
-    struct TileIt { int t, bm, bnl, n0, w, q, r; };
-    auto it_init = [&](TileIt& it, int t) {
-        it.t = t;
-        const int g = t / per_group;
-        const int local = t - g * per_group;
-        it.n0 = g * ng;
-        it.w = tiles_n - it.n0 < ng ? tiles_n - it.n0 : ng;
-        it.bm = local / it.w;
-        it.bnl = local - it.bm * it.w;
-    };
-    const int nxcd = gridDim.x >= 8 ? 8 : 1;
-    const int xcd = blockIdx.x % nxcd, slot_id = blockIdx.x / nxcd, per_xcd = gridDim.x / nxcd;
-    const int c0 = (int)((long long)xcd * total_tiles / nxcd), c1 = (int)((long long)(xcd + 1) * total_tiles / nxcd);
-    const int tb = c0 + slot_id;
-    const int my_tiles = tb < c1 ? (c1 - tb + per_xcd - 1) / per_xcd : 0;
-    if (LN == 1 && ln_zero) {
-        float4* z = (float4*)ln_zero;
-        for (int i = blockIdx.x * 512 + tid; i < M; i += gridDim.x * 512) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int chunks = my_tiles * nkc;
-    if (chunks <= 0) return;
-    const int tstride = per_xcd;
-    auto it_step = [&](TileIt& it) {
-        it.t += tstride;
-        it.bnl += it.r;
-        it.bm += it.q;
-        if (it.bnl >= it.w) { it.bnl -= it.w; ++it.bm; }
-        if (it.bm >= tiles_m) {
-            it_init(it, it.t);
-            it.q = tstride / it.w;
-            it.r = tstride - it.q * it.w;
-        }
-    };
-    // DMA: instruction p (0..3) of a wave covers rows wave*32 + p*8 + (lane>>3); lane&7 = physical chunk
-    const int drow = lane >> 3, dpc = lane & 7;
-    unsigned voff[2];
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-        const int rowl = wave * 32 + par * 8 + drow;
-        voff[par] = (unsigned)(rowl * K + ((dpc ^ ((rowl >> 1) & 7)) << 3)) * 2;
-    }
-    const int k16 = 16 * K;
-    const unsigned sbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned dma_lds = sbase + wave * 4096;
-    auto issue = [&](const TileIt& it, int kc, int slot) {
-        int bm = it.bm, bn = it.n0 + it.bnl;
-        if (xmode & 4) { bm = 0; bn = 0; }
-        const half_t* ga = A + (size_t)bm * BM * K + kc * 64;
-        const half_t* gw = W + (size_t)bn * BN * K + kc * 64;
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         ::"s"(dma_lds + slot * SLOT + p * 1024), "v"(voff[p & 1]), "s"(ga + (p >> 1) * k16) : "memory");
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         ::"s"(dma_lds + slot * SLOT + WPART + p * 1024), "v"(voff[p & 1]), "s"(gw + (p >> 1) * k16) : "memory");
-    };
-    // fragment byte offsets inside a slot (tile t adds t * 2048): k-half j uses chunk (q16 + 4j) ^ sw
-    const int fsw = (c16 >> 1) & 7;
-    const int fa_off[2] = {(wm * 128 + c16) * 128 + ((q16 ^ fsw) << 4), (wm * 128 + c16) * 128 + (((q16 + 4) ^ fsw) << 4)};
-    const int fw_off[2] = {WPART + (wn * 64 + c16) * 128 + ((q16 ^ fsw) << 4), WPART + (wn * 64 + c16) * 128 + (((q16 + 4) ^ fsw) << 4)};
-
-    TileIt cit, nit;
-    it_init(cit, tb);
-    cit.q = tstride / cit.w;
-    cit.r = tstride - cit.q * cit.w;
-    nit = cit;
-    int nkt = 0, ntiles = 0;
-    auto issue_advance = [&]() {
-        if (++nkt == nkc) {
-            nkt = 0;
-            if (++ntiles < my_tiles) it_step(nit);
-        }
-    };
-    issue(nit, nkt, 0);
-    issue_advance();
-    if (chunks > 1) issue(nit, nkt, 1); else issue(cit, 0, 1);
-    issue_advance();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    constexpr int RD = 2;
-    int g = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        const int bm = cit.bm, bn = cit.n0 + cit.bnl;
-        const int nb0 = bn * BN + wn * 64;
-        f32x4v acc[4][8];
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[tn][tm][q] = 0.f;
-        for (int kc = 0; kc < nkc; ++kc) {
-            const char* sl = smem + (g & 1) * SLOT;
-            {   // k-half 0
-                half8 fw[4], fa[8];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fw[t] = *(const half8*)(sl + fw_off[0] + t * 2048);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) fa[t] = *(const half8*)(sl + fa_off[0] + t * 2048);
-#pragma unroll
-                for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
-            }
-            {   // k-half 1: once its fragments are in registers this wave is done with the slot; the chunk's barrier (chunk g+1
-                // has landed, everybody is done with slot g&1 -> refill it with chunk g+2) sits behind the first 8 MFMAs
-                half8 fw[4], fa[8];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fw[t] = *(const half8*)(sl + fw_off[1] + t * 2048);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) fa[t] = *(const half8*)(sl + fa_off[1] + t * 2048);
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (g + 2 < chunks) issue(nit, nkt, g & 1); else issue(cit, 0, g & 1);
-                issue_advance();
-#pragma unroll
-                for (int tm = 2; tm < 8; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[tn], fa[tm], acc[tn][tm], 0, 0, 0);
-            }
-            ++g;
-        }
-        // epilogue: per 16-row m-tile through a per-wave LDS patch [16][64] fp16 (128-B rows, chunk XOR (row & 7))
-        {
-            char* ep = smem + EPI + wave * 2048;
-            f32x4v bq[4], sq[4];
-            if (HAS_BIAS) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const float4 b4 = *(const float4*)(bias + nb0 + tn * 16 + q16 * 4);
-                    bq[tn][0] = b4.x; bq[tn][1] = b4.y; bq[tn][2] = b4.z; bq[tn][3] = b4.w;
-                }
-            }
-            if (LN == 1) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const float4 c4 = *(const float4*)(ln_colsum + nb0 + tn * 16 + q16 * 4);
-                    sq[tn][0] = c4.x; sq[tn][1] = c4.y; sq[tn][2] = c4.z; sq[tn][3] = c4.w;
-                }
-            }
-            float keep1[2] = {0.f, 0.f}, keep2[2] = {0.f, 0.f};
-            half8 rq[RD][2];
-            const int rrow = lane >> 3, rch = lane & 7;
-            if (HAS_RES) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    rq[0][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + p * 8 + rrow) * N + nb0 + rch * 8);
-            }
-#pragma unroll
-            for (int tm = 0; tm < 8; ++tm) {
-                if (HAS_RES && tm + 1 < 8) {
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        rq[(tm + 1) % RD][p] = *(const half8*)(R + ((size_t)bm * BM + wm * 128 + (tm + 1) * 16 + p * 8 + rrow) * N + nb0 + rch * 8);
-                }
-                float rstd = 1.f, nmr = 0.f;
-                if (LN == 1) {
-                    const longlong2 qs = *(const longlong2*)(ln_stats + 2 * ((size_t)bm * BM + wm * 128 + tm * 16 + c16));
-                    const float mu = __ll2float_rn(qs.x) * (5.9604644775390625e-8f * ln_invk);
-                    const float var = fmaxf(fmaf(-mu, mu, __ll2float_rn(qs.y) * (9.5367431640625e-7f * ln_invk)), 0.f);
-                    rstd = __builtin_amdgcn_rsqf(var + ln_eps);
-                    nmr = -mu * rstd;
-                }
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    float2v v01 = {acc[tn][tm][0], acc[tn][tm][1]}, v23 = {acc[tn][tm][2], acc[tn][tm][3]};
-                    if (LN == 1) {
-                        const float2v r2 = {rstd, rstd}, m2 = {nmr, nmr};
-                        float2v t01 = m2 * sq[tn].lo, t23 = m2 * sq[tn].hi;
-                        if (HAS_BIAS) { t01 += bq[tn].lo; t23 += bq[tn].hi; }
-                        v01 = v01 * r2 + t01;
-                        v23 = v23 * r2 + t23;
-                    } else if (HAS_BIAS) {
-                        v01 += bq[tn].lo;
-                        v23 += bq[tn].hi;
-                    }
-                    if (ACT == SCD_ACT_QUICKGELU) {
-                        const float2v c2 = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
-                        const float2v one2 = {1.f, 1.f};
-                        float2v e01 = v01 * c2, e23 = v23 * c2;
-                        e01.x = __builtin_amdgcn_exp2f(e01.x); e01.y = __builtin_amdgcn_exp2f(e01.y);
-                        e23.x = __builtin_amdgcn_exp2f(e23.x); e23.y = __builtin_amdgcn_exp2f(e23.y);
-                        e01 += one2; e23 += one2;
-                        e01.x = __builtin_amdgcn_rcpf(e01.x); e01.y = __builtin_amdgcn_rcpf(e01.y);
-                        e23.x = __builtin_amdgcn_rcpf(e23.x); e23.y = __builtin_amdgcn_rcpf(e23.y);
-                        v01 *= e01; v23 *= e23;
-                    } else if (ACT != SCD_ACT_NONE) {
-                        v01.x = act_apply(v01.x, ACT); v01.y = act_apply(v01.y, ACT);
-                        v23.x = act_apply(v23.x, ACT); v23.y = act_apply(v23.y, ACT);
-                    }
-                    const half2v h01 = __builtin_convertvector(v01, half2v), h23 = __builtin_convertvector(v23, half2v);
-                    const half4 o = {h01.x, h01.y, h23.x, h23.y};
-                    *(half4*)(ep + c16 * 128 + (((tn * 2 + (q16 >> 1)) ^ (c16 & 7)) << 4) + (q16 & 1) * 8) = o;
-                }
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int rr = p * 8 + rrow;
-                    half8 hv = *(const half8*)(ep + rr * 128 + ((rch ^ (rr & 7)) << 4));
-                    const size_t off = ((size_t)bm * BM + wm * 128 + tm * 16 + rr) * N + nb0 + rch * 8;
-                    if (HAS_RES) hv = hv + rq[tm % RD][p];
-                    if (LN == 2) {
-                        float s1 = 0.f, s2 = 0.f;
-                        const half2v ones = {(half_t)1.f, (half_t)1.f};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const half2v pr = {hv[2 * q], hv[2 * q + 1]};
-                            s1 = __builtin_amdgcn_fdot2(pr, ones, s1, false);
-                            s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
-                        }
-#define W8_DPP_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xF, 0xF, true))
-                        W8_DPP_ADD(s1, 0x141); W8_DPP_ADD(s2, 0x141);   // row_half_mirror: lane i <-> 7-i of its group of 8
-                        W8_DPP_ADD(s1, 0x4E); W8_DPP_ADD(s2, 0x4E);     // quad_perm [2,3,0,1]
-                        W8_DPP_ADD(s1, 0xB1); W8_DPP_ADD(s2, 0xB1);     // quad_perm [1,0,3,2]
-#undef W8_DPP_ADD
-                        const bool mine = ((tm * 2 + p) & 7) == rch;
-                        keep1[tm >> 2] = mine ? s1 : keep1[tm >> 2];
-                        keep2[tm >> 2] = mine ? s2 : keep2[tm >> 2];
-                    }
-                    if (xmode & 2) {
-                    } else if (xmode & 512) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(C + off), "v"(hv) : "memory");
-                    else *(half8*)(C + off) = hv;
-                }
-            }
-            if (LN == 2) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    unsigned long long* dst = (unsigned long long*)(ln_out + 2 * ((size_t)bm * BM + wm * 128 + 8 * (rch + 8 * j) + rrow));
-                    atomicAdd(dst, (unsigned long long)__float2ll_rn(keep1[j] * 16777216.f));
-                    atomicAdd(dst + 1, (unsigned long long)__float2ll_rn(keep2[j] * 1048576.f));
-                }
-            }
-        }
-        if (ti + 1 < my_tiles) it_step(cit);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-#endif  // SCD_ABLATE
+#include "ablate/gemm_w8_kernel.h"
+#endif
 
 // n-tiles per group: the W panels of a group (ng*256*K*2 bytes) should stay inside one XCD's 4 MB L2; every extra group
 // re-reads the activations once.  Estimate the beyond-L2 traffic of each candidate and keep the cheapest.
@@ -1578,27 +1026,8 @@ static int choose_ng(int M, int K, int tiles_n, int total, int resident) {
 }
 
 #ifdef SCD_ABLATE
-template <int ACT, bool B, bool RR, int LN>
-static int launch_w8(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
-                     const scd_gemm_ln* ln, hipStream_t st) {
-    constexpr int LDS = 2 * 65536 + 16384;
-    if (M % 256 || N % 256 || K % 64) return SCD_EINVAL;
-    { const int rc_ = scd_set_max_lds((const void*)gemm_w8_kernel<ACT, B, RR, LN>, LDS); if (rc_) return rc_; }
-    const int tiles_m = M / 256, tiles_n = N / 256, total = tiles_m * tiles_n;
-    static const int xenv = SCD_ABLATE_ENV("SCD_GEMM_X", 0);
-    static const int nt_env = getenv("SCD_GEMM_NT") ? atoi(getenv("SCD_GEMM_NT")) : -1;
-    const bool nt = nt_env >= 0 ? nt_env != 0 : 2.0 * M * (double)N > 64e6;
-    const int xmode = xenv | (nt ? 512 : 0);
-    const int ng = choose_ng(M, K, tiles_n, total, 256);
-    const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
-    gemm_w8_kernel<ACT, B, RR, LN><<<grid, 512, LDS, st>>>(A, W, bias, R, C, M, N, K, tiles_n, total, xmode, ng,
-                                                           LN == 1 ? ln->stats_in : nullptr, LN == 1 ? ln->colsum : nullptr,
-                                                           LN == 1 ? ln->inv_k : 0.f, LN == 1 ? ln->eps : 0.f,
-                                                           LN == 2 ? ln->stats_out : nullptr, LN == 1 ? ln->zero_out : nullptr);
-    return SCD_OK;
-}
-
-#endif  // SCD_ABLATE
+#include "ablate/gemm_w8_launch.h"
+#endif
 
 template <int NT, int ACT, bool B, bool RR, int LN>
 static int launch_w4(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int M, int N, int K,
@@ -1622,18 +1051,7 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
                                                                      LN == 2 ? ln->stats_out : nullptr, stagger)
     if (nt) W4_GO(true); else W4_GO(false);
 #undef W4_GO
-    if (xmode & 64) {
-        static unsigned long long h[256 * 4];
-        SCD_HIP(hipDeviceSynchronize());
-        SCD_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w4_dbg), sizeof(h)));
-        double tm = 0, te = 0, tt = 0, nt2 = 0;
-        for (int b = 0; b < grid; ++b) { tm += h[b * 4]; te += h[b * 4 + 1]; nt2 += h[b * 4 + 2]; tt += h[b * 4 + 3]; }
-        if (xmode & 128)
-            fprintf(stderr, "[w4 m=%d n=%d k=%d] per chunk: even %.0f, wait+barrier %.0f, odd(+epilogue share) %.0f cyc\n", M, N, K, tm / tt, te / tt, nt2 / tt);
-        else
-            fprintf(stderr, "[w4 m=%d n=%d k=%d] per tile: main %.0f cyc, epilogue %.0f cyc; per block total %.0f cyc, tiles %.1f\n", M, N, K,
-                    tm / nt2, te / nt2, tt / grid, nt2 / grid);
-    }
+    W4_PROBE_REPORT()
     return SCD_OK;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B build of the library with extra -D flags on ONE source: tools/build_variant.sh NAME SRC.hip -DFOO=1 ...  -> scd_amd/lib/libscd_hip_NAME.so
-# (the other objects come from the default build; load the result through SCD_HIP_LIB, e.g. tools/gpu_r04_ab.sh)
+# (the other objects come from the default build; load the result through SCD_HIP_LIB, e.g. tools/history/gpu_r04_ab.sh)
 set -eu
 name=$1; src=$2; shift 2
 L=scd_amd/lib; python -m scd_amd.build > /dev/null
