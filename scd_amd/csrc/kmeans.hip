@@ -3500,9 +3500,24 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
     const size_t kd = (size_t)S.k * S.d, per = kd + (size_t)S.k;
     LloydStreams* ls = nullptr;
     const int ns = n_streams > R ? R : n_streams;
+    // Every error return below leaves through this guard: the library-owned streams may still be using the caller's buffers (label and
+    // centre rings, the E-step workspaces, best_labels), and the caller frees them as soon as it sees the status - so a failed call
+    // drains its side streams first (the success path joins them into the caller's stream with events instead, at the end).
+    // The stream / event pool is per device: one lock-step fit per device at a time (scd_kmeans_lloyd_run_multi is not re-entrant).
+    struct Drain {
+        LloydStreams* ls = nullptr;
+        int ns = 0;
+        bool joined = false;
+        ~Drain() {
+            if (ls && !joined)
+                for (int j = 0; j < ns; ++j) (void)hipStreamSynchronize(ls->st[j]);
+        }
+    } drain;
     if (ns > 1) {
         ls = lloyd_streams(rs[0].h->device, ns, R + 2);
         SCD_REQUIRE(ls, "scd_kmeans_lloyd_run_multi: could not create streams / events");
+        drain.ls = ls;
+        drain.ns = ns;
         SCD_HIP(hipEventRecord(ls->ev[R], st));                       // whatever the caller enqueued before the call
         for (int j = 0; j < ns; ++j) SCD_HIP(hipStreamWaitEvent(ls->st[j], ls->ev[R], 0));
     }
@@ -3651,6 +3666,7 @@ static int lloyd_run_multi_impl(std::vector<LloydRestart>& rs, const LloydShared
             SCD_HIP(hipStreamWaitEvent(st, ls->ev[j], 0));
         }
     }
+    drain.joined = true;
     return SCD_OK;
 }
 

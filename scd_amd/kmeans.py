@@ -99,9 +99,6 @@ class HipBackend:
         return self.ops.transport_solve_batch(costs, size_min, size_max, labels_out=labels_out)
 
 
-_FLAT_GATHER = {}      # (backend, device type) -> the backend has all_gather_into_tensor (agreed across ranks)
-
-
 class _Dist:
     """Thin wrapper over torch.distributed for the three exchanges k-means needs."""
 
@@ -131,24 +128,11 @@ class _Dist:
         return torch.cat([allp[r, : lens[r]] for r in range(self.world)]), lens
 
     def allgather_into(self, out, inp):
-        """rank w's `inp` (flat, equal sizes) -> out[w * len(inp): (w + 1) * len(inp)] on every rank.  Which form the backend offers
-        (the flat all_gather_into_tensor, or all_gather on views) is settled ONCE per (backend, device type) by a probe whose outcome the
-        ranks agree on with an all-reduce; afterwards exactly one form is issued and a collective's own errors propagate - a rank that
-        fell back on its own would issue a different collective from its peers."""
-        key = (str(self.d.get_backend(self.group)), inp.device.type)
-        flat = _FLAT_GATHER.get(key)
-        if flat is None:
-            ok = 1
-            try:
-                probe_in = torch.zeros(4, dtype=torch.uint8, device=inp.device)
-                probe_out = torch.zeros(4 * self.world, dtype=torch.uint8, device=inp.device)
-                self.d.all_gather_into_tensor(probe_out, probe_in, group=self.group)
-            except (RuntimeError, NotImplementedError, AttributeError):
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=inp.device)
-            self.d.all_reduce(flag, op=self.d.ReduceOp.MIN, group=self.group)
-            flat = _FLAT_GATHER[key] = bool(int(flag.item()) == 1)
-        if flat:
+        """rank w's `inp` (flat, equal sizes) -> out[w * len(inp): (w + 1) * len(inp)] on every rank.  Which form is issued follows from
+        the group's backend NAME alone - RCCL ("nccl") has the flat all_gather_into_tensor, every other backend gets all_gather on views -
+        so that every rank of every group issues the same collective without a probe: a probe's extra collectives, cached per process,
+        would be issued by some ranks of a sub-group and not by others (advisor, round 5)."""
+        if str(self.d.get_backend(self.group)) == "nccl":
             self.d.all_gather_into_tensor(out, inp, group=self.group)
         else:
             parts = list(out.view(self.world, -1).unbind(0))

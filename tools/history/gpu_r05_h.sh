@@ -13,10 +13,13 @@ import json
 d=json.load(open("$out/ls.json")); print("$tag:", d["value"], d["stage_ms_per_step"])
 PY
 }
-run "c2 merged filter, 4 streams"
-export SCD_LLOYD_STREAMS=10; run "c2 merged filter, 10 streams"; unset SCD_LLOYD_STREAMS
-export SCD_LLOYD_STREAMS=1; run "c2 merged filter, 1 stream"; unset SCD_LLOYD_STREAMS
-export SCD_ESTEP_MERGED=0; run "c2 per-restart filters, 4 streams"; unset SCD_ESTEP_MERGED
+# (labels as of the tree this script was written for, where the merged filter was the default; since the end of round 5 it is opt-in:
+# SCD_ESTEP_MERGED=1 selects it, unset / 0 = per-restart filters.  The runs below say what they set.)
+export SCD_ESTEP_MERGED=1
+run "c2 merged filter (SCD_ESTEP_MERGED=1), 4 streams"
+export SCD_LLOYD_STREAMS=10; run "c2 merged filter (SCD_ESTEP_MERGED=1), 10 streams"; unset SCD_LLOYD_STREAMS
+export SCD_LLOYD_STREAMS=1; run "c2 merged filter (SCD_ESTEP_MERGED=1), 1 stream"; unset SCD_LLOYD_STREAMS
+unset SCD_ESTEP_MERGED; run "c2 per-restart filters (default), 4 streams"
 timeout -k 10 400 python bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $out/r05_bench_c3.json 2> $out/bench_c3.err; rc=$?
 echo "[bench c3] rc=$rc"; tail -n 5 $out/bench_c3.err
 python - <<PY
