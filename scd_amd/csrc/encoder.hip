@@ -186,6 +186,116 @@ __global__ void __launch_bounds__(256) assemble_visual_kernel(const half_t* __re
     if (stats) stats_store(s1, s2, stats, r, lane);
 }
 
+// The same rows, a wave taking ONE token position t of RB consecutive images: the position's embedding, the class token / patch bias and
+// ln_pre's gamma / beta are loaded once per wave instead of once per row.  assemble_visual_kernel (one row per wave) read 10.5 KB per
+// 1.5-KB row out of L2 - 856 us per 3,990-image launch, 2.8 TB/s of HBM traffic and ~10 TB/s of L2 traffic: the L2 was the bound.  Same
+// arithmetic in the same order (ln_row's), so the rows and their statistics keep their bits.  Items: T x ceil(batch / RB) wave items in
+// (image chunk, t) order - the four waves of a block write neighbouring rows -, then one item per zero padding row.
+template <int RB>
+__global__ void __launch_bounds__(256) assemble_visual_rows_kernel(const half_t* __restrict__ patch, const float* __restrict__ patch_b,
+                                                                   const float* __restrict__ cls, const float* __restrict__ pos,
+                                                                   long long rows, int batch, int T, int width, const float* __restrict__ lg,
+                                                                   const float* __restrict__ lb, float eps, half_t* __restrict__ out,
+                                                                   long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nbc = (batch + RB - 1) / RB;
+    const long long n_main = (long long)T * nbc;
+    const int groups = width >> 8;
+    if (item >= n_main) {   // padding rows (the row count is rounded up to the GEMM tile): zeros
+        const long long r = (long long)batch * T + (item - n_main);
+        if (r >= rows) return;
+        for (int c = lane * 4; c < width; c += 256) *(half4*)(out + r * width + c) = half4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (stats && lane < 2) stats[2 * r + lane] = 0;
+        return;
+    }
+    const int t = (int)(item % T);
+    const int b0 = (int)(item / T) * RB;
+    float4 pp[4], ca[4], gg[4], bb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < groups) {
+            const int c = (i * 64 + lane) * 4;
+            pp[i] = *(const float4*)(pos + (size_t)t * width + c);
+            ca[i] = t == 0 ? *(const float4*)(cls + c) : (patch_b ? *(const float4*)(patch_b + c) : make_float4(0.f, 0.f, 0.f, 0.f));
+            if (lg) { gg[i] = *(const float4*)(lg + c); bb[i] = *(const float4*)(lb + c); }
+        }
+    // all RB rows' patch values first: 3 x RB loads in flight per wave before the first reduction (one row at a time, a wave had 1.5 KB
+    // in flight and the launch ran at the latency of its dependent load -> reduce -> store chains)
+    half4 hv[RB][4];
+    if (t != 0) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int b = b0 + q < batch ? b0 + q : batch - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < groups) hv[q][i] = *(const half4*)(patch + ((size_t)b * (T - 1) + (t - 1)) * width + (i * 64 + lane) * 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int b = b0 + q;
+        if (b >= batch) break;
+        const long long r = (long long)b * T + t;
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < groups) {
+                float4 a;
+                if (t == 0) {
+                    a = ca[i];
+                } else {
+                    const half4 h4 = hv[q][i];
+                    a = make_float4((float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]);
+                    if (patch_b) { a.x += ca[i].x; a.y += ca[i].y; a.z += ca[i].z; a.w += ca[i].w; }
+                }
+                v[i][0] = a.x + pp[i].x; v[i][1] = a.y + pp[i].y; v[i][2] = a.z + pp[i].z; v[i][3] = a.w + pp[i].w;
+            }
+        float s1 = 0.f, s2 = 0.f;
+        half_t* o_row = out + r * width;
+        if (lg) {   // ln_row's arithmetic with gamma / beta already in registers
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < groups) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            const float mean = wave_sum_f32(s) / (float)width;
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < groups) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dd = v[i][j] - mean;
+                        qq = fmaf(dd, dd, qq);
+                    }
+                }
+            const float rstd = rsqrtf(wave_sum_f32(qq) / (float)width + eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < groups) {
+                    half4 o;
+                    o[0] = (half_t)((v[i][0] - mean) * rstd * gg[i].x + bb[i].x);
+                    o[1] = (half_t)((v[i][1] - mean) * rstd * gg[i].y + bb[i].y);
+                    o[2] = (half_t)((v[i][2] - mean) * rstd * gg[i].z + bb[i].z);
+                    o[3] = (half_t)((v[i][3] - mean) * rstd * gg[i].w + bb[i].w);
+                    *(half4*)(o_row + (i * 64 + lane) * 4) = o;
+                    if (stats) stats_acc(o, &s1, &s2);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < groups) {
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (half_t)v[i][j];
+                    *(half4*)(o_row + (i * 64 + lane) * 4) = o;
+                    if (stats) stats_acc(o, &s1, &s2);
+                }
+        }
+        if (stats) stats_store(s1, s2, stats, r, lane);
+    }
+}
+
 // text: x[b][t] = tok_emb[token] + pos[t]; eot_row[b] = b*T + argmax_t token (first maximum, like torch.argmax)
 // S = positions per row of `tokens` (77), T <= S = positions computed; the EOT position (argmax over all S) must be < T
 __global__ void __launch_bounds__(256) embed_text_kernel(const int* __restrict__ tokens, int batch, const half_t* __restrict__ emb,
@@ -1044,15 +1154,35 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
     const long long total8 = pad.prows * kk / 8;
     half_t* cols = w.qkv;      // [prows, kk] scratch (fits: kk <= 3*width, prows <= rows)
     SCD_REQUIRE(kk <= 3 * d.width, "scd_vit_encode_image: patch too large for scratch");
-    if (dtype == SCD_F32) im2col_kernel<float><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const float*)pixels, batch, pad.prows, d.image, d.patch, cols);
-    else im2col_kernel<half_t><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const half_t*)pixels, batch, pad.prows, d.image, d.patch, cols);
-    int rc = scd_gemm_launch(cols, (const half_t*)e->w[W_PATCH], nullptr, nullptr, w.y, pad.prows, d.width, kk, SCD_ACT_NONE, st);
+    int rc;
+    // fp16 pixels, 16 x 16 patches, a row count the four-wave GEMM takes: the patch GEMM gathers its operand from the image (round 6);
+    // anything else goes through the im2col matrix as before (same products in the same order: the features do not change)
+    static const bool img_env = !(getenv("SCD_PATCH_FROM_IMAGE") && atoi(getenv("SCD_PATCH_FROM_IMAGE")) == 0);   // =0: the im2col path (A/B; same bits)
+    const bool from_image = img_env && dtype == SCD_F16 && d.patch == 16 && d.image % 16 == 0 && pad.prows % 256 == 0 && d.width % 256 == 0 &&
+                            (double)batch * 3.0 * d.image * d.image * 2.0 < 4294967296.0;
+    if (from_image) {
+        rc = scd_gemm_launch_img((const half_t*)pixels, (const half_t*)e->w[W_PATCH], w.y, pad.prows, d.width, batch, d.image, st);
+    } else {
+        if (dtype == SCD_F32) im2col_kernel<float><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const float*)pixels, batch, pad.prows, d.image, d.patch, cols);
+        else im2col_kernel<half_t><<<(unsigned)scd_cdiv(total8, 256), 256, 0, st>>>((const half_t*)pixels, batch, pad.prows, d.image, d.patch, cols);
+        rc = scd_gemm_launch(cols, (const half_t*)e->w[W_PATCH], nullptr, nullptr, w.y, pad.prows, d.width, kk, SCD_ACT_NONE, st);
+    }
     if (rc) return rc;
     const long long rows = pad.rows;
-    assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
-                                                                         (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
-                                                                         (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
-                                                                         d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);
+    static const int asm_rb = getenv("SCD_ASSEMBLE_ROWS") ? atoi(getenv("SCD_ASSEMBLE_ROWS")) : 8;     // 1: one row per wave (round 1-5 kernel; A/B, same bits)
+    if (asm_rb > 1 && d.width <= 1024) {
+        constexpr int RB = 8;
+        const long long items = (long long)d.tokens * ((batch + RB - 1) / RB) + (rows - (long long)batch * d.tokens);
+        assemble_visual_rows_kernel<RB><<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
+                                                                                      (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
+                                                                                      (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
+                                                                                      d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);
+    } else {
+        assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
+                                                                             (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
+                                                                             (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
+                                                                             d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);
+    }
     cls_rows_kernel<<<(pad.bh + 255) / 256, 256, 0, st>>>(w.rows, pad.bh, d.tokens, batch, 0);
     bool selected = false;
     rc = run_blocks(e, w, pad, st, &selected);

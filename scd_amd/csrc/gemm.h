@@ -4,6 +4,9 @@
 enum { SCD_ACT_NONE = 0, SCD_ACT_QUICKGELU = 1, SCD_ACT_GELU = 2 };
 int scd_gemm_launch(const half_t* A, const half_t* W, const float* bias, const half_t* R, half_t* C, int64_t M, int N, int K,
                     int act, hipStream_t st);
+// The patch-embedding GEMM of a ViT fed from the fp16 image batch itself (patch 16; gemm_w4_kernel IMG): no im2col matrix.  M = rows
+// of C, a multiple of 256 >= batch * (image / 16)^2; N % 256 == 0.
+int scd_gemm_launch_img(const half_t* pixels, const half_t* W, half_t* C, int64_t M, int N, int batch, int image, hipStream_t st);
 
 // LayerNorm folded into the four-wave GEMM (gemm.hip, gemm_w4_kernel LN = 1 / 2).  Requires M % 256 = N % 256 = K % 64 = 0.
 struct scd_gemm_ln {

@@ -490,12 +490,18 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 // LN = 2: this GEMM produces the rows the NEXT LayerNorm normalises: the epilogue adds each row's {sum, sum of squares} of
 //         the fp16 values it stores into ln_out[m] (64-bit integer atomics - order-independent, so the encoder stays
 //         bit-reproducible - one 64-row instruction per 64 rows).
-template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN, bool NTS>
+// IMG: A is not a row-major [M, K] matrix but the fp16 image batch [B, 3, img_w, img_w] itself, and row m = patch (b, py, px) of the
+//      16 x 16 / stride-16 patch convolution (K = 768, k = c * 256 + i * 16 + j as in conv1.weight.reshape(width, -1)): the ring fills
+//      gather the patch rows from the image - a 64-deep chunk is four image rows of one channel, a lane's 16-byte piece half a patch row,
+//      and neighbouring patches continue each other's image rows, so the fills still move whole cache lines.  Per-lane byte offsets of
+//      the tile's eight fill instructions (the patch's place in the image; recomputed per tile) + a scalar offset per chunk (channel and
+//      image-row group).  Replaces im2col_kernel and its 1.2-GB round trip per 3,990-image launch (round 6; main_unsup.py:114-147).
+template <int NT, int ACT, bool HAS_BIAS, bool HAS_RES, int LN, bool NTS, bool IMG = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const float* __restrict__ bias,
                const half_t* __restrict__ R, half_t* __restrict__ C, int M, int N, int K, int tiles_n, int total_tiles,
                int xmode_in, int ng, const float2* __restrict__ ln_rs, const float* __restrict__ ln_colsum,
-               long long* __restrict__ ln_out, int stagger_in) {
+               long long* __restrict__ ln_out, int stagger_in, int img_w = 0, int img_gp = 0, int img_rows = 0) {
     static_assert(NT == 8, "wave tile is 128 x 128");
 #ifdef SCD_ABLATE
     const int xmode = xmode_in, stagger = stagger_in;
@@ -573,11 +579,29 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     }
     const int k16 = 16 * K;
     const half_t *ga = A, *gw = W;      // panel pointers of the chunk being issued
+    // IMG: element offset of chunk kc inside a patch's image window = channel kc / 4, image rows 4 (kc % 4) .. + 3
+    auto img_chunk = [&](int kc) { return (kc >> 2) * img_w * img_w + (kc & 3) * 4 * img_w; };
+    unsigned vimg[8];                   // IMG: per-lane byte offsets of the tile's eight A fills (img_rows = valid patch rows)
+    auto img_offsets = [&](int bm) {
+        const int np = img_gp * img_gp;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rowl = wave * 64 + (p & 1) * 8 + drow;
+            int row = bm * BM + rowl + (p >> 1) * 16;
+            row = row < img_rows ? row : img_rows - 1;      // padding rows of the last tile: any valid patch (their output is not read)
+            const int b = row / np, pp = row - b * np, py = pp / img_gp, px = pp - py * img_gp;
+            const int lp = dpc ^ ((rowl >> 1) & 7);         // logical 16-byte piece of the 128-byte LDS row: image row lp / 2, half lp % 2
+            vimg[p] = 2u * (unsigned)(b * 3 * img_w * img_w + (py * 16 + (lp >> 1)) * img_w + px * 16 + (lp & 1) * 8);
+        }
+    };
     auto chunk_ptrs = [&](const TileIt& it, int kc) {
         int bm = it.bm, bn = it.n0 + it.bnl;
         if (xmode & 4) { bm = 0; bn = 0; }
-        ga = A + (size_t)bm * BM * K + kc * 64;
+        ga = IMG ? A + img_chunk(kc) : A + (size_t)bm * BM * K + kc * 64;
         gw = W + (size_t)bn * BN * K + kc * 64;
+        // the per-lane offsets change where the scalar pointer does - with the first chunk of a tile, never earlier: the A fills of the
+        // previous tile's last chunk are still being issued when the tile iterator has already moved on
+        if constexpr (IMG) { if (kc == 0) img_offsets(bm); }
     };
     // one ring-fill instruction (p = 0..7 of the A part or of the W part): scalar panel base + per-lane byte offset, so it
     // costs the wave no VALU work between the MFMAs it is interleaved with.  M0 carries the LDS destination.
@@ -596,7 +620,10 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
 #define W4_RLOAD(P) (*(const half8*)(P))
 #endif
     auto issue_a = [&](int p, int slot) {
-        if constexpr (W4_A_NT_LN1 && LN == 1) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, " nt"); }
+        if constexpr (IMG) {
+            asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         ::"s"(dma_lds + slot * SLOT), "v"(vimg[p]), "s"(ga), "n"(p * 1024) : "memory", "scc");
+        } else if constexpr (W4_A_NT_LN1 && LN == 1) { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, " nt"); }
         else { W4_DMA(ga, p, dma_lds + slot * SLOT, 0, W4_A_MOD); }
     };
     auto issue_w = [&](int p, int slot) { W4_DMA(gw, p, dma_lds + slot * SLOT, WPART, W4_W_MOD); };
@@ -627,7 +654,7 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
     auto tile_ptrs = [&]() {
         int bm = nit.bm, bn = nit.n0 + nit.bnl;
         if (xmode & 4) { bm = 0; bn = 0; }
-        ga_t = A + (size_t)bm * BM * K;
+        ga_t = IMG ? A : A + (size_t)bm * BM * K;
         gw_t = W + (size_t)bn * BN * K;
     };
     tile_ptrs();
@@ -759,7 +786,11 @@ gemm_w4_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, const
         tile_first = false;                                                                                      \
         /* past this block's last chunk the refill re-reads the current tile's first chunk into the free slot: no branch  \
            around the asm groups (a diamond makes hipcc copy accumulators between paths), and nothing reads the slot */   \
-        if (g + 2 < chunks) { ga = ga_t + nkt * 64; gw = gw_t + nkt * 64; } else chunk_ptrs(cit, 0);             \
+        if (g + 2 < chunks) {                                                                                    \
+            ga = ga_t + (IMG ? img_chunk(nkt) : nkt * 64);                                                       \
+            gw = gw_t + nkt * 64;                                                                                \
+            if constexpr (IMG) { if (nkt == 0) img_offsets(nit.bm); }                                            \
+        } else chunk_ptrs(cit, 0);                                                                               \
         issue_advance();                                                                                         \
         if (LATE_BAR) { W4_SUB_RANGE(fwB, faB, 0, W4_H_ODD, W4_LATE_TM, 8) } else { W4_SUB(fwB, faB, 0, W4_H_ODD) }  \
         cslot ^= 1;                                                                                              \
@@ -1052,6 +1083,26 @@ static int launch_w4(const half_t* A, const half_t* W, const float* bias, const 
     if (nt) W4_GO(true); else W4_GO(false);
 #undef W4_GO
     W4_PROBE_REPORT()
+    return SCD_OK;
+}
+
+// The patch-embedding GEMM fed from the image (gemm_w4_kernel<..., IMG>): C[b * np + p][n] = sum_k patch(b, p)[k] W[n][k], no bias, no
+// activation.  pixels fp16 [batch, 3, image, image], patch 16, M = rows of C (a multiple of 256 >= batch * np; rows beyond are scratch).
+int scd_gemm_launch_img(const half_t* pixels, const half_t* W, half_t* C, int64_t M, int N, int batch, int image, hipStream_t st) {
+    const int gp = image / 16, K = 768;
+    SCD_REQUIRE(pixels && W && C && batch > 0 && image % 16 == 0 && M % 256 == 0 && N % 256 == 0 && M >= (int64_t)batch * gp * gp && M < (1ll << 31),
+                "gemm_img: bad shape (m=%lld n=%d batch=%d image=%d)", (long long)M, N, batch, image);
+    SCD_REQUIRE((double)batch * 3.0 * image * image * 2.0 < 4294967296.0, "gemm_img: the image batch exceeds 32-bit byte offsets (batch %d)", batch);
+    constexpr int LDS = 2 * 65536 + 16384;
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<8, SCD_ACT_NONE, false, false, 0, false, true>, LDS); if (rc_) return rc_; }
+    { const int rc_ = scd_set_max_lds((const void*)gemm_w4_kernel<8, SCD_ACT_NONE, false, false, 0, true, true>, LDS); if (rc_) return rc_; }
+    const int tiles_m = (int)(M / 256), tiles_n = N / 256, total = tiles_m * tiles_n;
+    const bool nt = 2.0 * M * (double)N > 64e6;
+    const int ng = choose_ng((int)M, K, tiles_n, total, 256);
+    const int grid = total < 256 ? (total >= 8 ? total / 8 * 8 : total) : 256;
+    if (nt) gemm_w4_kernel<8, SCD_ACT_NONE, false, false, 0, true, true><<<grid, 256, LDS, st>>>(pixels, W, nullptr, nullptr, C, (int)M, N, K, tiles_n, total, 512, ng, nullptr, nullptr, nullptr, 0, image, gp, batch * gp * gp);
+    else gemm_w4_kernel<8, SCD_ACT_NONE, false, false, 0, false, true><<<grid, 256, LDS, st>>>(pixels, W, nullptr, nullptr, C, (int)M, N, K, tiles_n, total, 0, ng, nullptr, nullptr, nullptr, 0, image, gp, batch * gp * gp);
+    SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
 

@@ -117,5 +117,22 @@ pmc_mfma)
   rc=$?; echo "[pmc mfma] rc=$rc"; [ $rc -eq 0 ] || { tail -n 20 $out/pm_enc.log; exit 1; }
   { echo "# rocprofv3 --kernel-trace --pmc $CTR -- python3 bench.py --steps 1 --warmup 0 --images 7980 --no-cpu-baseline"; python3 $R/tools/pmc_mfma_util.py $out/pm_enc gemm_w4 attention sim_topk; } > $out/${ROUND}_pmc_mfma_encoder.txt
   cut -c1-140 $out/${ROUND}_pmc_mfma_encoder.txt; rm -rf $out/pm_enc ;;
+front_end)   # round 6's encoder front end against the round-5 one: patch GEMM fed from the image / im2col, eight rows per wave / one row per
+             # wave in the token assembly - bit-identity of both towers' features, then a same-box tower A/B of the four combinations
+  python tools/patch_img_check.py save $out/feat_new.pt > /dev/null 2> $out/front_end.err || { tail -n 20 $out/front_end.err; exit 1; }
+  SCD_PATCH_FROM_IMAGE=0 python tools/patch_img_check.py save $out/feat_im2col.pt > /dev/null 2>> $out/front_end.err || { tail -n 20 $out/front_end.err; exit 1; }
+  SCD_ASSEMBLE_ROWS=1 python tools/patch_img_check.py save $out/feat_rows1.pt > /dev/null 2>> $out/front_end.err || { tail -n 20 $out/front_end.err; exit 1; }
+  { python tools/patch_img_check.py cmp $out/feat_new.pt $out/feat_im2col.pt && python tools/patch_img_check.py cmp $out/feat_new.pt $out/feat_rows1.pt; } | tee $out/front_end_check.txt || exit 1
+  rm -f $out/feat_new.pt $out/feat_im2col.pt $out/feat_rows1.pt
+  for rep in 1 2; do
+    for v in "default" "SCD_PATCH_FROM_IMAGE=0" "SCD_ASSEMBLE_ROWS=1" "SCD_PATCH_FROM_IMAGE=0 SCD_ASSEMBLE_ROWS=1"; do
+      if [ "$v" = default ]; then python tools/tower_bench.py 6 3990 both > $out/fe.json; else env $v python tools/tower_bench.py 6 3990 both > $out/fe.json; fi
+      python - "$v" $out/fe.json <<'PY' | tee -a $out/front_end_ab.txt
+import json, sys
+d = json.load(open(sys.argv[2]))
+print("rep %-44s clip %8.1f %8.1f  dino %8.1f %8.1f images/s" % (sys.argv[1], d["clip_rep0"]["images_per_s"], d["clip_rep1"]["images_per_s"], d["dino_rep0"]["images_per_s"], d["dino_rep1"]["images_per_s"]))
+PY
+    done
+  done ;;
 *) echo "unknown step $step"; exit 2 ;;
 esac
