@@ -94,7 +94,7 @@ imagenet_templates = [
 ]
 
 
-def zeroshot_classifier(classnames, templates, model, names_per_batch=256, length_groups=4, min_group=2048):
+def zeroshot_classifier(classnames, templates, model, names_per_batch=1024, length_groups=4, min_group=2048):
     """[embed_dim, n_names] fp16 on the device: per name normalise(encode_text(prompts)) -> mean -> normalise, stacked
     along dim=1.  The reference runs one 80x77 forward per name; here names are batched (names_per_batch*len(templates)
     prompts per step), the prompts of a step are encoded in `length_groups` groups of similar length - each group only up to ITS

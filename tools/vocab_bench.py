@@ -11,6 +11,9 @@ from scd_amd import ops
 
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 2100
 NPB = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+LG = int(os.environ.get("VB_GROUPS", "4"))
+MG = int(os.environ.get("VB_MIN_GROUP", "2048"))
+NAMES = os.environ.get("VB_NAMES", "syllables")
 clip.allow_synthetic()
 model, _ = clip.load("ViT-B/16", device="cuda")
 if len(sys.argv) > 3 and sys.argv[3] == "bpe":
@@ -37,11 +40,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "bpe":
     clip._tokenizer = clip.SimpleTokenizer(path)
 syll = ["ba", "ri", "ton", "mek", "lu", "sha", "vor", "ine", "qua", "dro", "pel", "ast"]
 names = ["%s%s%s %s" % (syll[i % 12], syll[(i // 12) % 12], syll[(i // 144) % 12], syll[(i // 1728) % 12]) for i in range(V)]
+if NAMES == "numbered":
+    names = ["name_%05d" % i for i in range(V)]          # bench.py --config c5's names
 T = len(imagenet_templates)
-zeroshot_classifier(names[:NPB * 2], imagenet_templates, model, NPB)          # warm-up
+zeroshot_classifier(names[:NPB * 2], imagenet_templates, model, NPB, LG, MG)          # warm-up
 torch.cuda.synchronize()
 t0 = time.time()
-w = zeroshot_classifier(names, imagenet_templates, model, NPB)
+w = zeroshot_classifier(names, imagenet_templates, model, NPB, LG, MG)
 torch.cuda.synchronize()
 wall = time.time() - t0
 t0 = time.time()
