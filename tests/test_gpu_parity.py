@@ -256,6 +256,25 @@ def test_dist_and_costs(ops):
     assert out.device.type == "cpu" and np.array_equal(out.numpy(), d2)   # CPU result when batched (:209)
 
 
+@pytest.mark.parametrize("n,d,k,seed", [(1, 5, 1, 0), (63, 64, 31, 1), (65, 65, 33, 2), (300, 130, 8, 3), (1000, 768, 120, 4), (4097, 512, 100, 5),
+                                        (257, 3, 40, 6)])
+def test_dist_tile_kernel_ragged_shapes(ops, n, d, k, seed):
+    # scd_kmeans_dist at the corners of its tiling: fewer rows than a 64-row block, one row past a block, centre counts that do not fill
+    # a wave's eight / a block's 32, row lengths that are not multiples of the 64-column chunk (or of 4): float32(float64 difference
+    # form) bit for bit, sqrt and the ConSSKM integer costs from it (sskm_constrained.py:189-224, 277-287)
+    rs = np.random.RandomState(seed)
+    a = (rs.randn(n, d) * 3.0).astype(np.float32)
+    b = (rs.randn(k, d) * 3.0).astype(np.float32)
+    if n > 2 and k > 2:
+        b[1] = a[2]                                               # an exact zero distance
+    data = ops.KMeansData(dev(a))
+    d2 = data.dist(dev(b)).cpu().numpy()
+    ref = ko.pairwise_distance(a, b)
+    assert d2.shape == (n, k) and np.array_equal(d2, ref)
+    ds, cost = data.dist(dev(b), sqrt=True, with_cost=True)
+    assert np.array_equal(ds.cpu().numpy(), np.sqrt(ref)) and np.array_equal(cost.cpu().numpy(), to.int_costs(ref))
+
+
 def test_mstep_finalize_and_inertia(ops):
     x, y, cent = synth.clustered_features(5000, 768, 37, seed=9)
     rs = np.random.RandomState(1)
