@@ -154,7 +154,10 @@ __device__ __forceinline__ void prep_center_row(const float* C, int c, int k, in
         ch[(size_t)c * dp + j] = (half_t)(float)v;
         // fragment order of estep_stream_kernel: [wave c/32][segment j/128][k-step][lane (c%32) + 32 hh][8]
         if (chf) chf[(((((size_t)(c >> 5) * (dp >> 7) + (j >> 7)) * 8 + ((j & 127) >> 4)) * 64 + (c & 31) + 32 * ((j >> 3) & 1)) << 3) + (j & 7)] = (half_t)(float)v;
-        ct[(size_t)j * kp + c] = (c < k && j < d) ? C[(size_t)c * d + j] : NAN;     // untouched float32 values
+        // untouched float32 values, transposed.  ct == null: the caller transposes all centres at once (ct_transpose_kernel) - written
+        // from here, a centre's column is dp separate 4-byte writes at a stride of 4 kp bytes, and with a thousand centres doing that
+        // at once finalize_kernel took 113 us at K = 1000 (round 6)
+        if (ct) ct[(size_t)j * kp + c] = (c < k && j < d) ? C[(size_t)c * d + j] : NAN;
     }
     ss = wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
@@ -175,6 +178,47 @@ __device__ __forceinline__ void prep_center_row(const float* C, int c, int k, in
             atomicMax(&eh->cmax_bits, __float_as_uint((float)sqrt(t) * 1.0000002f));
         }
     }
+}
+
+// ct [dp][kp] = C^T (float32 values untouched; NaN in the padding) through a 32 x 32 LDS tile: whole 128-byte pieces both ways
+__global__ void __launch_bounds__(256) ct_transpose_kernel(const float* __restrict__ C, int k, int d, int dp, int kp, float* __restrict__ ct) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, j0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, j = j0 + tx;
+        t[ty + 8 * i][tx] = (c < k && j < d) ? C[(size_t)c * d + j] : NAN;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = j0 + ty + 8 * i, c = c0 + tx;
+        if (j < dp && c < kp) ct[(size_t)j * kp + c] = t[tx][ty + 8 * i];
+    }
+}
+// many centres: the transposed copy by ct_transpose_kernel behind the per-centre blocks instead of from inside them
+static inline bool ct_separate(int kp) { return kp >= 512; }
+// Only estep_refine_full_kernel reads the transposed copy: the legacy path (Kp > 2048 or Dp > 768) and, in -DSCD_ABLATE builds, the
+// split-refine switch of the streaming path.  The single-pass and the streaming path of the default build re-evaluate rows against the
+// row-major centres (refine_full_row), so there the copy is not written at all (2 MB of scattered writes per E-step at K = 1000).
+static inline bool ct_dead(int dp, int kp) {
+#ifdef SCD_ABLATE
+    (void)dp; (void)kp;
+    return false;
+#else
+    static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
+    return use_stream && kp <= 2048 && dp <= 768;
+#endif
+}
+// what the per-centre blocks are handed / whether the tiled transpose follows them
+static inline float* ct_inline(float* ct, int dp, int kp) { return (ct_dead(dp, kp) || ct_separate(kp)) ? nullptr : ct; }
+static inline bool ct_after(int dp, int kp) { return !ct_dead(dp, kp) && ct_separate(kp); }
+// the fragment-order copy `chf` serves the streaming filter (K <= 128) only; on the single-pass path of 128 < K <= 2048 at Dp = 512 its
+// place holds 16 bytes per centre written by estep_ext_kernel, so the per-centre blocks do not write it there
+static inline bool chf_unused(int dp, int kp) {
+    static const int use_stream = getenv("SCD_ESTEP_STREAM") ? atoi(getenv("SCD_ESTEP_STREAM")) : 1;
+    static const int use_rb = getenv("SCD_ESTEP_RB") ? atoi(getenv("SCD_ESTEP_RB")) : 1;
+    return use_stream && use_rb && dp == 512 && kp > 128 && kp <= 2048;
 }
 
 __global__ void __launch_bounds__(256) prep_centers_kernel(const float* __restrict__ C, int k, int d, int dp,
@@ -1589,7 +1633,10 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
     static const int use_rb = getenv("SCD_ESTEP_RB") ? atoi(getenv("SCD_ESTEP_RB")) : 1;
     if (use_stream && use_rb && dp == 512 && kp > 128 && kp <= 2048) {
         // single-pass filter (128 < K <= 2048 at Dp = 512): the rows of a block stay in registers, the centres stream past them once
-        if (!handover) prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
+        if (!handover) {
+            prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct_inline(ct, dp, kp), kp, 1, nullptr);
+            if (ct_after(dp, kp)) ct_transpose_kernel<<<dim3(kp / 32, dp / 32), 256, 0, st>>>(C, k, d, dp, kp, ct);
+        }
         half_t* ext = chf;                                       // the fragment-order copy is not used on this path: 16 B per centre
         estep_ext_kernel<<<(unsigned)scd_cdiv(kp, 256), 256, 0, st>>>(cn, kp, ext);
         { const int rc_ = scd_set_max_lds((const void*)estep_rb_kernel, ERB_LDS); if (rc_) return rc_; }
@@ -1629,7 +1676,10 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
         // streaming filter (D <= 768): centre prep (unless scd_kmeans_finalize has just produced these very centres and their
         // operands into this workspace), one filter launch per 128 centres, refine; no memset
         const bool prepared = handover;
-        if (!prepared) prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 1, chf);
+        if (!prepared) {
+            prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct_inline(ct, dp, kp), kp, 1, chf);
+            if (ct_after(dp, kp)) ct_transpose_kernel<<<dim3(kp / 32, dp / 32), 256, 0, st>>>(C, k, d, dp, kp, ct);
+        }
         const long long g32 = (n + 31) / 32;               // units of 32 rows
         long long grid = g32 < h->n_cu ? g32 : h->n_cu;
         if (grid < scd_cdiv(g32, ES_RMAX / 32)) grid = scd_cdiv(g32, ES_RMAX / 32);
@@ -1679,7 +1729,9 @@ extern "C" int scd_kmeans_estep(scd_handle h, const float* X, const void* prep, 
         return SCD_OK;
     }
     SCD_HIP(hipMemsetAsync(eh, 0, 64, st));
-    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct, kp, 0, nullptr);
+    // (legacy path: Kp > 2048 or Dp > 768 - estep_refine_full_kernel below reads the transposed copy)
+    prep_centers_kernel<<<kp, 256, 0, st>>>(C, k, d, dp, ph, (const double*)(p + 64), eh, cn, ch, ct_separate(kp) ? nullptr : ct, kp, 0, nullptr);
+    if (ct_separate(kp)) ct_transpose_kernel<<<dim3(kp / 32, dp / 32), 256, 0, st>>>(C, k, d, dp, kp, ct);
     estep_mfma_kernel<<<(unsigned)scd_cdiv(n, 128), 256, 0, st>>>((const half_t*)(p + xh_off), (const float*)(p + xnorm_off),
                                                                     ch, cn, eh, flags, fcand, fulls, n, dp, kp, labels_out);
     estep_refine_kernel<<<2048, 64, 0, st>>>(X, C, eh, flags, fcand, d, k, labels_out);
@@ -2033,9 +2085,11 @@ static int finalize_impl(scd_handle h, const double* sums, const int64_t* counts
         const char* p = (const char*)prep;
         finalize_kernel<<<kp, 256, 0, (hipStream_t)stream_>>>(sums, (const long long*)counts, k, d, C_old, C_out, shift_out,
                                                               (double*)h->scratch, (unsigned*)((char*)h->scratch + 262144), shift_mode,
-                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct, kp, chf, refined_out,
+                                                              (const PrepHdr*)p, (const double*)(p + 64), eh, cn, ch, ct_inline(ct, dp, kp), kp,
+                                                              chf_unused(dp, kp) ? nullptr : chf, refined_out,
                                                               changed_out, changed_acc, stats5, mirror, seq, sums_lab, (const long long*)counts_lab,
                                                               sumsq4, inertia_out);
+        if (ct_after(dp, kp)) ct_transpose_kernel<<<dim3(kp / 32, dp / 32), 256, 0, (hipStream_t)stream_>>>(C_out, k, d, dp, kp, ct);
         h->prep_C = C_out;
         h->prep_ws = estep_ws;
         h->prep_k = k;
