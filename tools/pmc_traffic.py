@@ -25,10 +25,12 @@ fd, wd, M, N, K, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv
 fetch, write = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
 fc1 = [k for k in fetch if "gemm_w4_kernel" in k and "Li1ELb1ELb0ELi1" in k]   # QuickGELU, bias, no residual, LN-folded
 ln = [k for k in fetch if "im2col_kernel" in k]      # a copy of known size, but its reads are 32-byte pieces of image rows (<= 64-B requests)
-av = [k for k in fetch if "assemble_visual_kernel" in k]   # reads the patch rows as whole 512-B wave loads (128-B requests), writes x
-assert fc1 and ln, (list(fetch)[:5])
+av = [k for k in fetch if "assemble_visual" in k]   # reads the patch rows as whole 512-B wave loads (128-B requests), writes x (round 6: assemble_visual_rows_kernel)
+assert fc1 and (ln or av), (list(fetch)[:5])
 nf, f_kb = full(fetch[fc1[0]]); nw, w_kb = full(write[fc1[0]])
-nlf, lf_kb = full(fetch[ln[0]]); nlw, lw_kb = full(write[ln[0]])
+# round 6: the patch GEMM gathers from the image and im2col_kernel no longer runs on fp16 pixels; its same-run check is then absent
+nlf, lf_kb = full(fetch[ln[0]]) if ln else (0, float("nan"))
+nlw, lw_kb = full(write[ln[0]]) if ln else (0, float("nan"))
 BATCH = int(sys.argv[7]) if len(sys.argv) > 7 else M // 197          # images per launch
 ln_bytes = BATCH * 3 * 224 * 224 * 2
 ln_wbytes = (M // 197 * 196 + 255) // 256 * 256 * 768 * 2
@@ -36,7 +38,7 @@ cal128 = None
 if av:
     naf, af_kb = full(fetch[av[0]]); naw, aw_kb = full(write[av[0]])
     rows_p = BATCH * 196
-    cal128 = {"kernel": "assemble_visual_kernel", "raw_fetch_mb": af_kb * 1024 / 1e6, "expected_read_mb": rows_p * 768 * 2 / 1e6,
+    cal128 = {"kernel": av[0].split("(")[0][:60], "raw_fetch_mb": af_kb * 1024 / 1e6, "expected_read_mb": rows_p * 768 * 2 / 1e6,
               "ratio_raw_over_expected": af_kb * 1024 / (rows_p * 768 * 2), "write_mb": aw_kb * 1024 / 1e6, "expected_write_mb": M * 768 * 2 / 1e6}
 res = {
     "kernel": "gemm_w4_kernel<QuickGELU,bias,no-residual,LN-folded> (ViT fc1) m=%d n=%d k=%d" % (M, N, K),
