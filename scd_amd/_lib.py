@@ -156,6 +156,14 @@ def load():
         if not os.path.exists(_LIB_PATH):
             from . import build as _build
             _build.build(verbose=False)
+        # torch first: it ships a HIP runtime of its own, and whichever libamdhip64 is loaded first is the process's only one (same SONAME).
+        # Loaded before torch, this library pulled in /opt/rocm's runtime and torch's later initialisation left it without a device
+        # (round 6: __graft_entry__.build() followed by smoke() in one process failed in hipGetDeviceCount).  Hosts without torch
+        # (examples/c_abi_host.cpp, a foreign-language binding) load the library directly and are not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(_LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
