@@ -43,10 +43,24 @@ def cluster_counters(name_idx, top_k, u_preds, clusters, m, known=None):
     return {c: TopCounter(keys[i], counts[i]) for i, c in enumerate(clusters)}
 
 
+_FIRST = {}
+
+
 def _first_index(nouns):
+    """name -> its first position in `nouns` (`nouns.index(name)`), as a dict.  Built once per vocabulary list and kept (the last few
+    lists): a 100,000-name list costs ~10 ms to index, every vote call needs it, and `nouns.index` itself - one linear search per candidate
+    name and iteration, main_ptsup.py:664 - was 76 % of the partially supervised vote loop's time at K = 120, V = 21,000 (round 6).  A
+    list changed in place since is noticed through the hash of its contents (the strings' own hashes are cached: ~0.3 ms at V = 21,000)."""
+    key = (id(nouns), len(nouns), hash(tuple(nouns)))
+    ent = _FIRST.get(key)
+    if ent is not None and ent[0] is nouns:
+        return ent[1]
     first = {}
     for j, n in enumerate(nouns):
         first.setdefault(n, j)
+    if len(_FIRST) >= 4:
+        _FIRST.clear()
+    _FIRST[key] = (nouns, first)
     return first
 
 
@@ -92,8 +106,9 @@ def vote_loop_ptsup(name_idx, all_preds, mask_lab, clip_u_feats, wt, nouns, lab_
     lab_class_index = list(set(all_preds[mask_lab].tolist()))
     all_class_index = list(set(all_preds.tolist()))
     cand = nouns
+    first = _first_index(nouns)                         # first[n] == nouns.index(n)
     num_unlab = n_cluster - len(lab_names)
-    known = [cand.index(n) for n in lab_names]
+    known = [first[n] if n in first else cand.index(n) for n in lab_names]     # (a missing name raises ValueError here, as .index does)
     unlab_cluster_idx = list(set(all_class_index) - set(lab_class_index))
     m = max(num_common_vote, num_common_linear)
     cur, prev, trace = [0], [1], []
@@ -110,7 +125,7 @@ def vote_loop_ptsup(name_idx, all_preds, mask_lab, clip_u_feats, wt, nouns, lab_
         lab_class_index = [cand.index(n) for n in lab_names]
         unlab_cluster_idx = [cand.index(n) for n in list(set(cand) - set(lab_names))]
         known = copy.deepcopy(lab_class_index)
-        cols = torch.tensor([nouns.index(n) for n in cand], dtype=torch.int64, device=dev)
+        cols = torch.tensor([first[n] for n in cand], dtype=torch.int64, device=dev)        # nouns.index(n): every candidate is a name of the list
         w_sel = ops.gather_rows_f16(wt, cols)
         u_preds, _ = ops.sim_argmax(clip_u_feats, w_sel)
         trace.append(dict(voted=np.array(voted, dtype=np.int64), ind=ind, cand=cols.cpu().numpy(),
