@@ -111,15 +111,21 @@ class KMeans:
         for it in range(self.max_iter):
             labels = data.estep(centers)
             sums, counts, _ = ops.kmeans_mstep(x, labels, None, k, 0)
-            flags = torch.cat([(counts == 0).sum().reshape(1), ops.labels_changed(labels, labels_old)]).cpu().numpy()
+            # the centres on the assumption that no cluster is empty (the common case), so that the iteration's three host-side
+            # decisions - empty clusters, changed labels, centre shift - come back in ONE read instead of two (4,500 rows: the device
+            # work of an iteration is ~0.1 ms, a read-back's round trip about as much); with an empty cluster the step is redone
+            new_centers, shift = ops.kmeans_finalize(sums, counts, centers, shift_mode=1, data=data)      # (+ the next E-step's centre operands)
+            flags = torch.cat([(counts == 0).sum().reshape(1).to(torch.float64), ops.labels_changed(labels, labels_old).to(torch.float64),
+                               shift.reshape(1).to(torch.float64)]).cpu().numpy()
             if flags[0] > 0:
                 self._relocate_empty(data, centers, labels, sums, counts, int(flags[0]))
-            new_centers, shift = ops.kmeans_finalize(sums, counts, centers, shift_mode=1)
+                new_centers, shift = ops.kmeans_finalize(sums, counts, centers, shift_mode=1, data=data)
+                flags[2] = float(shift.item())
             centers = new_centers
             if flags[1] == 0:
                 strict = True
                 break
-            if float(shift.item()) <= tol_abs:
+            if float(flags[2]) <= tol_abs:
                 break
             labels_old = labels
         if not strict:

@@ -461,9 +461,13 @@ static int mstep_impl(scd_handle h, const float* X, const half_t* X16, const int
         SCD_HIP(rocprim::radix_sort_keys(temp, need, k0, k1, (size_t)n, 32, 32 + bits, st));
     }
     static const int ms_var = getenv("SCD_MSTEP_VAR") ? atoi(getenv("SCD_MSTEP_VAR")) : 3;      // rows per wave / rows in flight: 3 = 64/8 (default), 1 = 64/4, 2 = 32/8, 0 = 32/4
+    // few rows (CUB-sized inputs: 4,500 x 768): 64 rows per wave are 18 blocks on a 256-CU chip and one long dependent chain per wave
+    // (55 us per launch); 8 rows per wave fill the chip.  The sums are float64 atomics either way (order-free after the one rounding).
+    const bool few_rows = scd_cdiv(n, 4 * 64) < 128;
 #define MSTEP_LAUNCH(G)                                                                                                      \
     do {                                                                                                                     \
-        if (ms_var == 1) mstep_segment_kernel<G, 64, 4><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+        if (few_rows) mstep_segment_kernel<G, 8, 8><<<(unsigned)scd_cdiv(n, 4 * 8), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
+        else if (ms_var == 1) mstep_segment_kernel<G, 64, 4><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
         else if (ms_var == 2) mstep_segment_kernel<G, 32, 8><<<(unsigned)scd_cdiv(n, 4 * 32), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
         else if (ms_var == 3) mstep_segment_kernel<G, 64, 8><<<(unsigned)scd_cdiv(n, 4 * 64), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
         else mstep_segment_kernel<G, 32, 4><<<(unsigned)scd_cdiv(n, 4 * 32), 256, 0, st>>>(X, k1, C_old, n, d, k, split, sums, (unsigned long long*)counts, inertia); \
