@@ -75,11 +75,11 @@ SCD_HOST_SIMD int64_t min_key(const int64_t* __restrict__ key, int nn) {
 // attaining it.  relax_row: Dijkstra, leaving a settled centre u: dist[v] = min(dist[v], du + r[v] - pi[v]) for the centres not yet
 // settled (reduced cost r[v] + pi[u] - pi[v] >= 0); returns the smallest selection key of the centres after the update (the next
 // node to settle, up to G's own key: one pass per settled node).
-#define SCD_ROW_FUNCS(T)                                                                                                                   \
+#define SCD_ROW_FUNCS(T, U)                                                                                                                \
     SCD_HOST_SIMD void row_add(T* __restrict__ r, int32_t* __restrict__ rp, const int32_t* __restrict__ c, int a, int32_t p, int k) {      \
         const T ca = c[a];                                                                                                                 \
         for (int b = 0; b < k; ++b) {                                                                                                      \
-            const T dlt = (T)c[b] - ca;                                                                                                    \
+            const T dlt = (T)((U)(T)c[b] - (U)ca); /* (wraps instead of overflowing: the optimistic 32-bit pass may meet huge costs) */ \
             const bool m = (dlt < r[b]) | ((dlt == r[b]) & (p < rp[b]));                                                                   \
             r[b] = m ? dlt : r[b];                                                                                                         \
             rp[b] = m ? p : rp[b];                                                                                                         \
@@ -101,8 +101,8 @@ SCD_HOST_SIMD int64_t min_key(const int64_t* __restrict__ key, int nn) {
         }                                                                                                                                  \
         return best;                                                                                                                       \
     }
-SCD_ROW_FUNCS(int32_t)
-SCD_ROW_FUNCS(int64_t)
+SCD_ROW_FUNCS(int32_t, uint32_t)
+SCD_ROW_FUNCS(int64_t, uint64_t)
 #undef SCD_ROW_FUNCS
 // nearest centre of one point, lowest index among ties; also the row's largest cost
 SCD_HOST_SIMD int row_argmin(const int32_t* __restrict__ c, int k, int32_t* mx_io) {
@@ -171,20 +171,38 @@ struct Solver {
 
 // steps 1 and 2 on tables of type T; `a0` = every point's nearest centre (lowest index among ties)
 template <class T>
-int repair(const int32_t* cost, int64_t n, int k, int size_min, int size_max, const int32_t* a0, bool packed, int32_t* labels_out,
-           int64_t* total_cost_out) {
-    Solver<T> s;
+void solver_init(Solver<T>& s, const int32_t* cost, int64_t n, int k) {
     s.cost = cost; s.n = n; s.k = k;
     s.assign.assign(n, -1);
     s.pos.assign(n, 0);
+    s.mem.clear();
     s.mem.resize(k);
     s.best.assign((size_t)k * k, Lim<T>::INF);
     s.bestp.assign((size_t)k * k, -1);
-    // 1. nearest centre
-    for (int64_t p = 0; p < n; ++p) {
-        s.attach((int32_t)p, a0[p]);
-        s.add(a0[p], (int32_t)p);
+}
+
+// step 1 in ONE pass over the cost matrix: a point's nearest centre (lowest index among ties) and its row of the table while the cost
+// row is in cache; also the largest and the smallest cost seen (they decide whether 32-bit tables were admissible)
+template <class T>
+void first_pass(Solver<T>& s, int32_t* mx_out, int32_t* mn_out) {
+    int32_t mx = 0, mn = 0;
+    for (int64_t p = 0; p < s.n; ++p) {
+        const int32_t* c = s.cost + p * s.k;
+        const int a = row_argmin(c, s.k, &mx);
+        if (c[a] < mn) mn = c[a];
+        s.attach((int32_t)p, a);
+        s.add(a, (int32_t)p);
     }
+    *mx_out = mx;
+    *mn_out = mn;
+}
+
+// step 2 on a solver whose step 1 is done
+template <class T>
+int repair(Solver<T>& s, int size_min, int size_max, bool packed, int32_t* labels_out, int64_t* total_cost_out) {
+    const int32_t* cost = s.cost;
+    const int64_t n = s.n;
+    const int k = s.k;
     // 2. repair the balances.  Node k is G, the free sink.  cnt(a) = members of a.
     const int G = k;
     const int nn = k + 1;
@@ -323,20 +341,23 @@ static int transport_solve_one(const int32_t* cost, int64_t n, int k, int size_m
         return SCD_EINFEASIBLE;
     }
     SCD_REQUIRE(n < INT32_MAX, "scd_transport_solve: more than 2^31 points");
-    // nearest centres into labels_out (the repair reads them before it writes the final labels); the largest cost picks the table type
+    // optimistic: 32-bit tables (every cost in [0, 2^30): always, for round(1000 * distance)); the pass itself finds out whether that held
     int32_t mx = 0, mn = 0;
-    for (int64_t p = 0; p < n; ++p) {
-        const int32_t* c = cost + p * k;
-        labels_out[p] = row_argmin(c, k, &mx);
-        if (c[labels_out[p]] < mn) mn = c[labels_out[p]];
+    {
+        Solver<int32_t> s32;
+        solver_init(s32, cost, n, k);
+        first_pass(s32, &mx, &mn);
+        if (mn >= 0 && mx < (1 << 30)) {
+            // a search's distances are sums of at most k + 1 reduced costs, each below 2 (mx + 1) in magnitude: packed selection keys
+            // while that stays below 2^42
+            const bool packed = k + 1 < (1 << KEY_BITS) && (int64_t)(k + 2) * 2 * ((int64_t)mx + 1) < ((int64_t)1 << 42);
+            return repair(s32, size_min, size_max, packed, labels_out, total_cost_out);
+        }
     }
-    std::vector<int32_t> a0(labels_out, labels_out + n);
-    // a search's distances are sums of at most k + 1 reduced costs, each below 2 (mx + 1) in magnitude: packed selection keys while
-    // that stays below 2^42
-    const bool small = mn >= 0 && mx < (1 << 30);
-    const bool packed = small && k + 1 < (1 << KEY_BITS) && (int64_t)(k + 2) * 2 * ((int64_t)mx + 1) < ((int64_t)1 << 42);
-    if (small) return repair<int32_t>(cost, n, k, size_min, size_max, a0.data(), packed, labels_out, total_cost_out);
-    return repair<int64_t>(cost, n, k, size_min, size_max, a0.data(), false, labels_out, total_cost_out);
+    Solver<int64_t> s64;
+    solver_init(s64, cost, n, k);
+    first_pass(s64, &mx, &mn);
+    return repair(s64, size_min, size_max, false, labels_out, total_cost_out);
 }
 
 // no exception crosses the C boundary or ends a worker thread (std::terminate): an allocation failure becomes a status
