@@ -204,6 +204,69 @@ def test_transport_batch_equals_single_solves():
         ops.transport_solve_batch(costs, 80, smax, threads=4)                 # 12 x 80 > 900
 
 
+def test_transport_labels_equal_round5_solver():
+    """The flow step's optimum is not unique, so which optimal labelling comes out is a property of the solver's tie-breaking rules
+    (lowest index wins: nearest centre, cheapest member, next node of the search).  Round 6 rewrote the solver's loops for the host's
+    vector units with the promise of the SAME augmentations in the same order: the labels of round 5's solver on five problems (two with
+    costs quantised to multiples of 50, i.e. thousands of ties; one at k = 120) are kept in tests/golden/transport_labels_r5.npz
+    (generated with round 5's library from the seeds below) and must come out again, bit for bit, single and batched
+    (sskm_constrained.py:331-356)."""
+    from scd_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "transport_labels_r5.npz"))
+    cases = [(900, 12, 50, 110, 21, False), (2000, 40, 30, 80, 22, False), (1500, 20, 60, 90, 23, True), (3000, 120, 15, 60, 24, False),
+             (700, 7, 100, 100, 25, True)]
+    for i, (n, k, smin, smax, seed, tie) in enumerate(cases):
+        rs = np.random.RandomState(seed)
+        pts, cen = rs.randn(n, 6), rs.randn(k, 6) * 1.3
+        cost = to.int_costs(((pts[:, None] - cen[None]) ** 2).sum(-1).astype(np.float32))
+        if tie:
+            cost = (cost // 50 * 50).astype(np.int32)
+        assert list(g["bounds%d" % i]) == [smin, smax]
+        lab, tot = ops.transport_solve(cost, smin, smax)
+        assert tot == int(g["tot%d" % i]) and np.array_equal(lab, g["lab%d" % i]), i
+        labs, tots = ops.transport_solve_batch(np.stack([cost, cost]), smin, smax, threads=2)
+        assert np.array_equal(labs[0], lab) and np.array_equal(labs[1], lab) and tots[0] == tots[1] == tot
+        assert to.check_optimal(cost, lab, smin, smax)
+
+
+def test_first_index_cache_follows_the_list():
+    """naming._first_index (the vote loops' `nouns.index(n)`, main_ptsup.py:664 / main_unsup.py:599): the dict is built once per vocabulary
+    list, equals `.index` on duplicates, and a list changed in place gets a fresh one."""
+    from scd_amd import naming
+    nouns = ["a", "b", "c", "b", "d"]
+    first = naming._first_index(nouns)
+    assert all(first[n] == nouns.index(n) for n in nouns) and naming._first_index(nouns) is first
+    nouns[0], nouns[4] = "d", "a"
+    first2 = naming._first_index(nouns)
+    assert first2 is not first and all(first2[n] == nouns.index(n) for n in nouns)
+    assert naming._first_index(list(nouns)) == first2                      # another list object with the same names: its own entry
+
+
+def test_hash_tokenizer_junction_rule():
+    """The synthetic stand-in for the BPE merges pre-tokenises like the real tokenizer (letter runs, single digits, runs of other
+    characters; '_' = space), so clip.tokenize_templates assembles prompts from pieces exactly where encode(x + y) == encode(x) +
+    encode(y): checked on every pair of a junction alphabet, and the assembled 80-template prompt set equals prompt-by-prompt
+    tokenisation (clip_lang_util.py:96-108)."""
+    import scd_amd.clip as clip
+    from scd_amd.local_utils.clip_lang_util import imagenet_templates
+    tk = clip.HashTokenizer()
+    chars = ["a", "Z", "7", ".", ",", " ", "_", "-", "'", "!", "é"]
+    for a in chars:
+        for b in chars:
+            x, y = "xy" + a, b + "zw"
+            if tk.separable(a, b):
+                assert tk.encode(x + y) == tk.encode(x) + tk.encode(y), (a, b)
+    old_tok, old_allow = clip._tokenizer, clip._allow_synthetic
+    try:
+        clip._tokenizer = tk
+        names = ["name_%05d" % i for i in range(40)] + ["golden retriever", "x-ray", "o'neil", "a.b", "it's", "d_7", "42", "e."]
+        a = clip.tokenize_templates(names, imagenet_templates).numpy()
+        b = clip.tokenize([t.format(n) for n in names for t in imagenet_templates]).numpy()
+        assert np.array_equal(a, b)
+    finally:
+        clip._tokenizer, clip._allow_synthetic = old_tok, old_allow
+
+
 def test_transport_infeasible_raises_like_reference():
     from scd_amd import ops
     from scd_amd.local_utils.sskm_constrained import _labels_constrained
