@@ -999,6 +999,30 @@ print("done")
         assert a.dtype == b.dtype and torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8)), key
 
 
+def test_encoder_front_end_variants_are_bit_identical(ops, tmp_path):
+    """Round 6's front end - the patch GEMM gathering its operand from the fp16 image (gemm_w4_kernel<..., IMG>) and the token assembly
+    with eight images of a token position per wave - against the round-5 kernels it replaces (SCD_PATCH_FROM_IMAGE=0: im2col + plain
+    GEMM; SCD_ASSEMBLE_ROWS=1: one row per wave): the CLIP and DINO features of 3 / 257 / 1,000 images (one row tile with padding rows,
+    many tiles per block, a partly padded last tile) are equal bit for bit.  The switches are read once per process, hence the child
+    processes (main_unsup.py:114-147)."""
+    import subprocess
+    import sys
+    tool = os.path.join(ROOT, "tools", "patch_img_check.py")
+    outs = {}
+    for tag, extra in (("new", {}), ("im2col", {"SCD_PATCH_FROM_IMAGE": "0"}), ("rows1", {"SCD_ASSEMBLE_ROWS": "1"})):
+        env = dict(os.environ, **extra)
+        env.pop("SCD_HIP_LIB", None)
+        outs[tag] = str(tmp_path / ("feat_%s.pt" % tag))
+        r = subprocess.run([sys.executable, tool, "save", outs[tag]], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+    a = torch.load(outs["new"])
+    for tag in ("im2col", "rows1"):
+        b = torch.load(outs[tag])
+        assert set(a) == set(b) and len(a) == 6
+        for key in a:
+            assert torch.isfinite(a[key].float()).all() and torch.equal(a[key], b[key]), (tag, key)
+
+
 @pytest.mark.parametrize("longest", [9, 32, 33, 64, 65, 76])
 def test_text_tower_trimmed_context_is_bit_identical(ops, longest):
     """encode_text reads only the EOT position of a causal tower (clip model.py encode_text): computing the first
