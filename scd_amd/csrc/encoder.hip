@@ -1169,14 +1169,18 @@ extern "C" int scd_vit_encode_image(scd_handle h, const scd_encoder* e, const vo
     }
     if (rc) return rc;
     const long long rows = pad.rows;
-    static const int asm_rb = getenv("SCD_ASSEMBLE_ROWS") ? atoi(getenv("SCD_ASSEMBLE_ROWS")) : 8;     // 1: one row per wave (round 1-5 kernel; A/B, same bits)
+    static const int asm_rb = getenv("SCD_ASSEMBLE_ROWS") ? atoi(getenv("SCD_ASSEMBLE_ROWS")) : 4;     // 1: one row per wave (round 1-5 kernel; A/B, same bits); 8: eight
     if (asm_rb > 1 && d.width <= 1024) {
-        constexpr int RB = 8;
-        const long long items = (long long)d.tokens * ((batch + RB - 1) / RB) + (rows - (long long)batch * d.tokens);
-        assemble_visual_rows_kernel<RB><<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
-                                                                                      (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,
-                                                                                      (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],
-                                                                                      d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);
+#define ASM_GO(RB)                                                                                                                        \
+    do {                                                                                                                                  \
+        const long long items = (long long)d.tokens * ((batch + RB - 1) / RB) + (rows - (long long)batch * d.tokens);                     \
+        assemble_visual_rows_kernel<RB><<<(unsigned)scd_cdiv(items, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS], \
+                                                                                      (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,      \
+                                                                                      (const float*)e->w[W_LNPRE_W], (const float*)e->w[W_LNPRE_B],   \
+                                                                                      d.ln_eps, w.x, ln_fused(e, pad) ? w.stats_a : nullptr);          \
+    } while (0)
+        if (asm_rb == 8) ASM_GO(8); else ASM_GO(4);       // measured (tools/asm_rows_sweep.sh): 1: 864, 2: 600, 3: 524, 4: 504, 6: 578, 8: 566, 16: 761 us
+#undef ASM_GO
     } else {
         assemble_visual_kernel<<<(unsigned)scd_cdiv(rows, 4), 256, 0, st>>>(w.y, (const float*)e->w[W_PATCH_B], (const float*)e->w[W_CLS],
                                                                              (const float*)e->w[W_POS], rows, batch, d.tokens, d.width,

@@ -1001,7 +1001,7 @@ print("done")
 
 def test_encoder_front_end_variants_are_bit_identical(ops, tmp_path):
     """Round 6's front end - the patch GEMM gathering its operand from the fp16 image (gemm_w4_kernel<..., IMG>) and the token assembly
-    with eight images of a token position per wave - against the round-5 kernels it replaces (SCD_PATCH_FROM_IMAGE=0: im2col + plain
+    with four images of a token position per wave - against the round-5 kernels it replaces (SCD_PATCH_FROM_IMAGE=0: im2col + plain
     GEMM; SCD_ASSEMBLE_ROWS=1: one row per wave): the CLIP and DINO features of 3 / 257 / 1,000 images (one row tile with padding rows,
     many tiles per block, a partly padded last tile) are equal bit for bit.  The switches are read once per process, hence the child
     processes (main_unsup.py:114-147)."""
