@@ -1872,9 +1872,14 @@ extern "C" int scd_kmeans_dist(scd_handle h, const float* X, const float* C, int
                                int32_t* cost_out, void* stream_) {
     SCD_DEVICE_ENTRY(h, "scd_kmeans_dist");
     SCD_REQUIRE(h && X && C && out && n > 0 && d > 0 && k > 0, "scd_kmeans_dist: bad arguments");
-    SCD_REQUIRE(scd_cdiv(n, 64) < (1ll << 31) && scd_cdiv(k, 32) < 65536, "scd_kmeans_dist: n = %lld, k = %d exceed the launch grid", (long long)n, k);
-    const dim3 grid((unsigned)scd_cdiv(n, 64), (unsigned)scd_cdiv(k, 32));
-    dist_tile_kernel<8><<<grid, 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
+    SCD_REQUIRE(scd_cdiv(n, 64) < (1ll << 31) && scd_cdiv(k, 16) < 65536, "scd_kmeans_dist: n = %lld, k = %d exceed the launch grid", (long long)n, k);
+    // centres per lane: 8, or 4 while the 8-centre grid is below four blocks per CU (the ConSSKM shape, 9,000 x 120: 564 blocks -> 1,128,
+    // 168 -> 143 us; at 95,000 x 100 and 30,000 x 200 the two are within 3 %, 8 ahead).  16 is register- and grid-starved (358 us), 2 re-reads
+    // the rows too often (156 us).  Same sums either way (a lane's sum does not depend on how many centres it carries).
+    static const int cg_env = getenv("SCD_DIST_CG") ? atoi(getenv("SCD_DIST_CG")) : 0;
+    const int cg = cg_env == 4 || cg_env == 8 ? cg_env : (scd_cdiv(n, 64) * scd_cdiv(k, 32) < 1024 ? 4 : 8);
+    if (cg == 4) dist_tile_kernel<4><<<dim3((unsigned)scd_cdiv(n, 64), (unsigned)scd_cdiv(k, 16)), 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
+    else dist_tile_kernel<8><<<dim3((unsigned)scd_cdiv(n, 64), (unsigned)scd_cdiv(k, 32)), 256, 0, (hipStream_t)stream_>>>(X, C, n, d, k, mode, out, cost_out);
     SCD_LAUNCH_CHECK();
     return SCD_OK;
 }
