@@ -816,10 +816,100 @@ class ConstrainedEngine(KMeansEngine):
             be.transport_batch(host_cost[a:a + 1].numpy(), self.size_min, self.size_max, labels_out=host_lab[a:a + 1].numpy())
 
         try:
-            return self._lockstep_iterations(be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, active, n_iters, host_cost, host_lab,
-                                             pool, solve, prof, ph)
+            if prof or os.environ.get("SCD_CONSSKM_ASYNC", "1") == "0":
+                return self._lockstep_iterations(be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, active, n_iters, host_cost, host_lab,
+                                                 pool, solve, prof, ph)
+            return self._async_iterations(be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, n_iters, host_cost, host_lab, pool, solve)
         finally:
             release()
+
+    def _async_iterations(self, be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, n_iters, host_cost, host_lab, pool, solve):
+        """The restarts' loops without a common beat (round 6).  In lock-step every iteration ended with one read-back for all restarts:
+        the device idled while the last solve finished, and the host threads idled while the device formed the next cost matrices
+        (phases of a C3 fit: distances + copies 24 ms, waiting for solves 19 ms, M-steps 15 ms, one after the other).  Here a restart is
+        a small state machine - cost matrix issued -> solving on its host thread -> M-step and its four statistics issued -> statistics
+        back (an event) -> next iteration - and this thread drives all of them round robin, so that one restart's solve runs under
+        another's distance kernel and a third's M-step.  Each restart still performs exactly the sequential loop's operations on its
+        own state in its own order (the device work of all restarts shares the one stream, in issue order), so labels, centres,
+        inertia and iteration counts are the same bits; `SCD_CONSSKM_ASYNC=0` (or the phase profile) selects the lock-step loop."""
+        import concurrent.futures as cf
+        R = len(centers)
+        SOLVE, STATS, DONE = 0, 1, 2
+        phase, it_of = [DONE] * R, [0] * R
+        fut, ev, d_sqrt, c_new = [None] * R, [None] * R, [None] * R, [None] * R
+        host_stats = torch.empty((R, 4), dtype=torch.float64).pin_memory()
+
+        def start_iter(j):
+            d_sqrt[j], cost = be.dist(data_u, centers[j], sqrt=True, with_cost=True)
+            host_cost[j].copy_(cost, non_blocking=True)
+            e = torch.cuda.Event()
+            e.record()
+            fut[j] = pool.submit(solve, j, e)
+            phase[j] = SOLVE
+            self.stats["transport_solves"] = self.stats.get("transport_solves", 0) + 1
+
+        def after_solve(j):
+            u_lab = host_lab[j].to(dev, non_blocking=True)
+            # distances[:] = D[arange, labels] ** 2 in float32, inertia = sum (sskm_constrained.py:271-272)
+            picked = d_sqrt[j].gather(1, u_lab.to(torch.int64).reshape(-1, 1)).reshape(-1)
+            tot = be.sum_f32((picked * picked).contiguous())
+            labels[j][l_num:] = u_lab.to(torch.int64)
+            lab32 = labels[j].to(torch.int32).contiguous()
+            old = centers[j]
+            sums, counts, inertia2 = be.mstep(cat, lab32, old, k, l_num, cat16) if cat16 is not None else be.mstep(cat, lab32, old, k, l_num)
+            c_new[j], shift = be.finalize(sums, counts, old, None)       # (no E-step follows: no centre operands to prepare)
+            stats = torch.cat([inertia2.to(torch.float64), shift.reshape(1).to(torch.float64), tot.reshape(1).to(torch.float64)])
+            host_stats[j].copy_(stats, non_blocking=True)
+            ev[j] = torch.cuda.Event()
+            ev[j].record()
+            d_sqrt[j] = None
+            phase[j] = STATS
+
+        def after_stats(j):
+            host = host_stats[j].numpy().copy()
+            centers[j] = c_new[j]
+            ui = np.float32(np.float32(float(host[3])))
+            inertia = np.float32(ui + np.float32(host[0]))
+            if best[j][1] is None or inertia < best[j][1]:
+                best[j] = (labels[j].clone(), inertia, centers[j].clone())
+            n_iters[j] = it_of[j] + 1
+            if (not host[2] < self.tolerance) and it_of[j] + 1 < self.max_iterations:
+                it_of[j] += 1
+                start_iter(j)
+            else:
+                phase[j] = DONE
+
+        try:
+            for j in range(R):
+                start_iter(j)
+            while any(p != DONE for p in phase):
+                progressed = False
+                for j in range(R):
+                    if phase[j] == SOLVE and fut[j].done():
+                        fut[j].result()                                   # (a failed solve raises here, as the batch call did)
+                        after_solve(j)
+                        progressed = True
+                    elif phase[j] == STATS and ev[j].query():
+                        after_stats(j)
+                        progressed = True
+                if not progressed:
+                    waiting = [fut[j] for j in range(R) if phase[j] == SOLVE]
+                    if waiting:
+                        cf.wait(waiting, timeout=2e-4, return_when=cf.FIRST_COMPLETED)
+                    else:
+                        time.sleep(2e-5)
+        except BaseException:
+            for f in fut:                                                 # no solver may still be writing the staging buffers when they are released
+                if f is not None:
+                    f.cancel()
+            for f in fut:
+                if f is not None and not f.cancelled():
+                    try:
+                        f.result()
+                    except BaseException:
+                        pass
+            raise
+        return [(best[j][0], best[j][1], best[j][2], n_iters[j]) for j in range(R)]
 
     def _lockstep_iterations(self, be, dev, data_u, cat, cat16, l_num, k, labels, centers, best, active, n_iters, host_cost, host_lab, pool, solve,
                              prof, ph):
