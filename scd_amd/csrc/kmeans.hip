@@ -2453,8 +2453,9 @@ template <int RB, bool VEC, int J>
 // blockIdx.y = trial l of a greedy k-means++ round (gridDim.y = 1 otherwise): centres Cn + l * lc, output d2 + l * lo.  d2in: the current
 // distances when the result goes elsewhere (out = min(d2in, dist): the trials of a round all start from the same d2), null = in place.
 __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restrict__ X, const float* __restrict__ Cn, long long n, int d,
-                                                          int r0, int R, float* d2, long long ld, long long ldc, const float* d2in,
+                                                          int r0_in, int R, float* d2, long long ld, long long ldc, const float* d2in,
                                                           long long lc, long long lo) {
+    const int r0 = r0_in + (int)blockIdx.z * RB;       // gridDim.z > 1: the restarts of a group split over blocks (small inputs)
     Cn += (size_t)blockIdx.y * lc;
     d2 += (size_t)blockIdx.y * lo;
     const float* din = d2in ? d2in : d2;
@@ -2562,14 +2563,14 @@ __global__ void __launch_bounds__(256) minupd_tile_kernel(const float* __restric
 
 template <int RB>
 static int minupd_launch(const float* X, const float* Cn, long long n, int d, int r0, int R, float* d2, long long ld, hipStream_t st,
-                         long long ldc, const float* d2in, int L, long long lc, long long lo) {
+                         long long ldc, const float* d2in, int L, long long lc, long long lo, int zsplit = 1) {
     if (scd_cdiv(n, MU_ROWS) * L < 256) {             // fewer 256-row blocks than CUs: 128-row blocks (same bits)
-        const dim3 g((unsigned)scd_cdiv(n, 128), (unsigned)L);
+        const dim3 g((unsigned)scd_cdiv(n, 128), (unsigned)L, (unsigned)zsplit);
         if ((d & 3) == 0) minupd_tile_kernel<RB, true, 1><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
         else minupd_tile_kernel<RB, false, 1><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
         return SCD_OK;
     }
-    const dim3 g((unsigned)scd_cdiv(n, MU_ROWS), (unsigned)L);
+    const dim3 g((unsigned)scd_cdiv(n, MU_ROWS), (unsigned)L, (unsigned)zsplit);
     if ((d & 3) == 0) minupd_tile_kernel<RB, true, 2><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
     else minupd_tile_kernel<RB, false, 2><<<g, 256, 0, st>>>(X, Cn, n, d, r0, R, d2, ld, ldc, d2in, lc, lo);
     return SCD_OK;
@@ -2580,6 +2581,10 @@ static int minupd_launch(const float* X, const float* Cn, long long n, int d, in
 static int minupd_all(const float* X, const float* c_new, long long n, int d, int R, float* d2, long long ld, long long ldc, hipStream_t st,
                       const float* d2in = nullptr, int L = 1, long long lc = 0, long long lo = 0) {
     int r0 = 0;
+    // small inputs (one chip round of 128-row blocks at most): ten restarts as two groups of five in the SAME launch (gridDim.z = 2) -
+    // twice the blocks, two per CU, so that one block's loads hide behind the other's float64 arithmetic; a (row, restart) sum is the
+    // same arithmetic in the same order whatever the group size
+    while (R - r0 >= 10 && scd_cdiv(n, 128) * L <= 256) { minupd_launch<5>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo, 2); r0 += 10; }
     while (R - r0 >= 10) { minupd_launch<10>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 10; }
     while (R - r0 >= 3) { minupd_launch<4>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 4; }
     while (R - r0 >= 1) { minupd_launch<1>(X, c_new, n, d, r0, R, d2, ld, st, ldc, d2in, L, lc, lo); r0 += 1; }
