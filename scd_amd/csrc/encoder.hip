@@ -497,6 +497,122 @@ __global__ void __launch_bounds__(256, 2) attention_kernel(const half_t* __restr
     }
 }
 
+// Short contexts (T <= 32: the text tower after context trimming, 10-20 tokens): ONE WAVE per (prompt, head), four items per block.
+// attention_kernel<1> gave such an item a whole 256-thread block of which three waves only helped to stage 2 x 2 KB and then idled: at
+// 20,480 prompts x 8 heads a launch was 163,840 blocks of almost no work, 383 us for 1.3 GB (round 6: 16 % of the vocabulary build).
+// Here a wave stages its item's K and V into its own LDS region (no block barrier: a wave's LDS operations execute in order) and runs the
+// one 32-query block exactly as attention_kernel does - the same MFMAs on the same operands, so the same bits.
+__global__ void __launch_bounds__(256) attention_short_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int T, int width,
+                                                              int heads, int causal, int items) {
+    constexpr int VS = 192;
+    __shared__ __attribute__((aligned(16))) char kl_all[4][32 * 128];
+    __shared__ __attribute__((aligned(16))) char vl_all[4][32 * VS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= items) return;
+    char* kl = kl_all[wave];
+    char* vl = vl_all[wave];
+    const int r = lane & 31, hh = lane >> 5;
+    const int img = item / heads, head = item % heads;
+    const size_t row0 = (size_t)img * T;
+    const int ld = 3 * width;
+    const half_t* qbase = qkv + row0 * ld + head * 64;
+    const half_t* kbase = qbase + width;
+    const half_t* vbase = qbase + 2 * width;
+    {   // 32 rows x 8 chunks of 16 bytes each for K and V: four per lane, all loads issued before the first LDS write
+        uint4 kv[4], vv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = it * 64 + lane, row = i >> 3, ch = i & 7;
+            kv[it] = make_uint4(0, 0, 0, 0);
+            vv[it] = make_uint4(0, 0, 0, 0);
+            if (row < T) {
+                kv[it] = *(const uint4*)(kbase + (size_t)row * ld + 8 * ch);
+                vv[it] = *(const uint4*)(vbase + (size_t)row * ld + 8 * ch);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = it * 64 + lane, row = i >> 3, ch = i & 7;
+            *(uint4*)(kl + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv[it];
+            *(uint4*)(vl + row * VS + ch * 16) = vv[it];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's LDS writes have landed (no other wave touches the region)
+    __builtin_amdgcn_wave_barrier();
+    const int L = lane & 15;
+    const int tr_off = (4 * hh + (L >> 2)) * VS + (16 * ((lane >> 4) & 1) + 4 * (L & 3)) * 2;
+    const int query = r;
+    const int qrow = query < T ? query : T - 1;
+    half8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qbase + (size_t)qrow * ld + 16 * s + 8 * hh);
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = r;
+        const half8 kf = *(const half8*)(kl + row * 128 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 4));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = sacc[i];
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= T || (causal && key > query)) v = -INFINITY;
+        sacc[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float cs = 0.125f * 1.4426950408889634f;
+    const float mxs = mx * cs;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[i], cs, -mxs));
+        sacc[i] = p;
+        sum += p;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (half_t)sacc[8 * s + j];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const char* base = vl + (16 * s) * VS + db * 64 + tr_off;
+            const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base));
+            const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(base + 8 * VS));
+            const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+            half8 vf;
+            vf[0] = l4[0]; vf[1] = l4[1]; vf[2] = l4[2]; vf[3] = l4[3];
+            vf[4] = h4[0]; vf[5] = h4[1]; vf[6] = h4[2]; vf[7] = h4[3];
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[db], 0, 0, 0);
+        }
+    }
+    if (query < T) {
+        half_t* orow = out + (row0 + query) * width + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 o;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) o[q4] = (half_t)(oacc[db][4 * g + q4] * inv);
+                *(half4*)(orow + db * 32 + 8 * g + 4 * hh) = o;
+            }
+    }
+}
+
 // Persistent attention for the ViT towers (T <= 224 tokens, head_dim 64): one 8-wave block per CU loops over its
 // (image, head) items.  Wave 7 is the producer: it streams the NEXT item's K and V head slices into the other half of a
 // double-buffered LDS image with LDS-DMA (8 rows x 128 B per instruction, the bank swizzles applied to the per-lane source
@@ -1042,7 +1158,11 @@ static int run_blocks(const scd_encoder* e, const EncWs& w, const EncPad& pad, h
             else
                 attention_persist_kernel<false><<<items < 256 ? items : 256, 512, attn_lds, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, items, attn_xmode());
         } else if (pad.tokens == 197) attention_kernel<7><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
-        else if (pad.tokens <= 32) attention_kernel<1><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
+        else if (pad.tokens <= 32) {
+            static const int attn_short = getenv("SCD_ATTN_SHORT") ? atoi(getenv("SCD_ATTN_SHORT")) : 1;      // 0: a block per item (attention_kernel<1>; A/B, same bits)
+            if (attn_short) attention_short_kernel<<<(bp * d.heads + 3) / 4, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, bp * d.heads);
+            else attention_kernel<1><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
+        }
         else if (pad.tokens <= 64) attention_kernel<2><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         else attention_kernel<3><<<bp * d.heads, 256, 0, st>>>(w.qkv, w.y, pad.tokens, d.width, d.heads, causal, attn_xmode());
         if (last_sel && l == d.layers - 1) {

@@ -1009,16 +1009,16 @@ def test_encoder_front_end_variants_are_bit_identical(ops, tmp_path):
     import sys
     tool = os.path.join(ROOT, "tools", "patch_img_check.py")
     outs = {}
-    for tag, extra in (("new", {}), ("im2col", {"SCD_PATCH_FROM_IMAGE": "0"}), ("rows1", {"SCD_ASSEMBLE_ROWS": "1"})):
+    for tag, extra in (("new", {}), ("im2col", {"SCD_PATCH_FROM_IMAGE": "0"}), ("rows1", {"SCD_ASSEMBLE_ROWS": "1"}), ("attn_block", {"SCD_ATTN_SHORT": "0"})):
         env = dict(os.environ, **extra)
         env.pop("SCD_HIP_LIB", None)
         outs[tag] = str(tmp_path / ("feat_%s.pt" % tag))
-        r = subprocess.run([sys.executable, tool, "save", outs[tag]], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        r = subprocess.run([sys.executable, tool, "save", outs[tag], "--text"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
     a = torch.load(outs["new"])
-    for tag in ("im2col", "rows1"):
+    for tag in ("im2col", "rows1", "attn_block"):       # (attn_block: the text tower's short-context attention, a block per item instead of a wave)
         b = torch.load(outs[tag])
-        assert set(a) == set(b) and len(a) == 6
+        assert set(a) == set(b) and len(a) == 8
         for key in a:
             assert torch.isfinite(a[key].float()).all() and torch.equal(a[key], b[key]), (tag, key)
 

@@ -1,5 +1,5 @@
-"""The patch GEMM fed from the image (default) against the im2col path (SCD_PATCH_FROM_IMAGE=0): features of both towers must be equal bit
-for bit; run once per setting with an output file, then compare:  python tools/patch_img_check.py save out.pt | cmp a.pt b.pt"""
+"""Features of the towers under one setting of the A/B switches (SCD_PATCH_FROM_IMAGE, SCD_ASSEMBLE_ROWS, SCD_ATTN_SHORT, ...), saved for a
+bit-for-bit comparison with another setting's:  python tools/patch_img_check.py save out.pt [--text]  |  python tools/patch_img_check.py cmp a.pt b.pt"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scd_amd.clip import weights as W
@@ -13,6 +13,13 @@ if sys.argv[1] == "save":
         x = torch.randn((b, 3, 224, 224), device="cuda", generator=g).half()
         out["clip%d" % b] = clip.visual.enc.encode_image(x).cpu()
         out["dino%d" % b] = dino._enc.encode_image(x).cpu()
+    if "--text" in sys.argv:                  # the text tower at trimmed contexts (<= 32 positions: attention_short_kernel / attention_kernel<1>)
+        import scd_amd.clip as cl
+        cl.allow_synthetic()
+        model = CLIP(W.synthetic_clip_state_dict(seed=0)).cuda()
+        for tag, names in (("short", ["cat", "a dog", "x"] * 50), ("long", ["a fairly long name of seven words here", "golden retriever puppy"] * 333)):
+            tok = cl.tokenize(["a photo of a %s." % n for n in names])
+            out["text_" + tag] = model.encode_text(tok).cpu()
     torch.save(out, sys.argv[2])
 else:
     a, b = torch.load(sys.argv[2]), torch.load(sys.argv[3])
